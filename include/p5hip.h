@@ -1,0 +1,112 @@
+/* p5hip.h -- C ABI of libp5hip.so: the MI355X-native T5 training + constrained-beam-search path that
+ * replaces OpenP5's `P5_T5` model object (the seam is the Python `model` handed to the runner,
+ * /root/reference/src/src_t5/main.py:184-206).
+ *
+ * The reference has no FFI of its own (pure Python over torch + HF transformers).  The entry points below are
+ * therefore what a binding for this path needs, one per reference call it replaces:
+ *
+ *   p5_forward            <- P5_T5.forward(input_ids, whole_word_ids, attention_mask, labels) -> per-token NLL
+ *                            (model/P5_T5.py:275-386, called at runner/DistributedRunner.py:63-70)
+ *   p5_backward           <- loss.backward()                               (DistributedRunner.py:80)
+ *   p5_grad_sumsq +
+ *   p5_adamw_step         <- clip_grad_norm_ + AdamW.step + scheduler      (DistributedRunner.py:81,85-86;
+ *                                                                           SingleRunner.py:191-217)
+ *   p5_generate           <- P5_T5.generate(..., prefix_allowed_tokens_fn, num_beams)  (DistributedRunner.py:361-371)
+ *   p5_param_table        <- state_dict()/load_state_dict() key layout     (utils/utils.py:119-129)
+ *
+ * plus per-kernel entry points (p5_op_*) used by the parity tests.
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (torch's allocator); nothing is allocated,
+ * freed or synchronised inside (graph-capturable); `stream` is a hipStream_t passed as void*; return value
+ * 0 = ok, negative = error (message via p5_last_error()).  dtype: 0 = fp32 parity mode, 1 = bf16 fast mode.
+ */
+#ifndef P5HIP_H
+#define P5HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct P5Config {
+  int vocab_size, d_model, d_kv, d_ff, n_enc_layers, n_dec_layers, n_heads;
+  int rel_buckets, rel_max_distance, whole_word_size;
+  int gated_gelu;      /* 0: ReLU FFN (t5-small/base/large), 1: gated gelu_new (v1.1 / Flan) */
+  int dtype;           /* 0 fp32, 1 bf16 */
+  float eps, dropout;
+  int pad_id, eos_id;
+} P5Config;
+
+typedef struct P5Engine P5Engine;
+
+const char* p5_last_error(void);
+int p5_abi_version(void);
+int p5_is_emulator(void);   /* 1 only for the test-only host emulation build under tests/emu */
+
+/* ---- engine lifetime + parameter arena layout ---- */
+int p5_engine_create(const P5Config* cfg, P5Engine** out);
+int p5_engine_destroy(P5Engine* e);
+int64_t p5_param_count(const P5Engine* e);
+/* idx-th tensor of the arena in HF state-dict naming; returns 0, or 1 when idx is past the end */
+int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols);
+/* params/grads: fp32 arenas of p5_param_count elements; shadow: bf16 arena (dtype=1) or NULL;
+ * lut_enc/lut_dec: int32 [2*lut_half+1] bucket of rel=key-query (bidirectional / unidirectional);
+ * rng_state: uint32[2] {seed, step} */
+int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const int* lut_enc, const int* lut_dec,
+                   int lut_half, uint32_t* rng_state);
+int p5_refresh_shadow(P5Engine* e, void* stream);
+
+/* ---- training step pieces ---- */
+int64_t p5_train_workspace_bytes(const P5Engine* e, int B, int L, int T);
+/* nll_out: fp32 [B*T]; keeps activations in ws for p5_backward */
+int p5_forward(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+               const int64_t* labels, int B, int L, int T, int training, float* nll_out, void* ws, int64_t ws_bytes,
+               void* stream);
+/* stages: 0 = head + decoder-final, 1..n_dec = decoder layers (top first), then decoder embedding,
+ * then encoder-final + encoder layers (top first), last = encoder embedding.  p5_backward runs them all. */
+int p5_backward_num_stages(const P5Engine* e);
+int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream);
+int p5_backward(P5Engine* e, const float* dnll, void* stream);
+/* arena range [begin,end) whose gradients are final once `stage` has run (for bucketed all-reduce) */
+int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end);
+
+int p5_grad_sumsq(const float* grads, int64_t n, float* out_scalar, void* stream);   /* out += sum g^2 */
+int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n,
+                  const float* sumsq /* or NULL */, float max_norm, float grad_scale, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step_t, void* stream);
+
+/* ---- generation ---- */
+int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children);
+/* trie in CSR: child_off[n_nodes+1], child_tok/child_node[n_edges]; node 0 = empty prefix.
+ * out_seq int32 [B,K,max_len] (pad-filled, starts with pad=decoder start), out_score fp32 [B,K], out_len int32 [B,K].
+ * host_flags: 2 ints of HOST-visible pinned memory used for the early-exit check (or NULL: run all steps). */
+int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+                int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
+/* step-wise variant for arbitrary Python prefix_allowed_tokens_fn callables is built from the two calls below */
+int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+              int B, int L, void* enc_out /* T [B*L, d] */, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- per-kernel entry points (parity tests) ---- */
+int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* aux, int M, int N, int K, int lda, int ldb,
+               int ldc, int ldaux, int a_ks, int b_ks, int epi, int c_f32, int splitk, float alpha,
+               const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
+int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream);
+int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
+                      const float* rstd, const float* dres_in, int rows, int d, void* stream);
+int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table,
+                   const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
+                   int ldv, int ldo, int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
+int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                   float* Dvec, void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, const int* lut,
+                   int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                   int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
+                   void* stream);
+int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream);
+int p5_op_tr_probe(void* out64x4_u16, const void* in256_u16, void* stream);  /* ds_read_b64_tr_b16 semantics probe */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

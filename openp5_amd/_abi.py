@@ -1,0 +1,67 @@
+"""ctypes prototypes for include/p5hip.h (one table, used by the product loader and by the test-only emulator
+loader so both bind exactly the symbols the header declares)."""
+import ctypes as C
+
+c_i64p = C.POINTER(C.c_int64)
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+
+class P5Config(C.Structure):
+    _fields_ = [
+        ("vocab_size", i32), ("d_model", i32), ("d_kv", i32), ("d_ff", i32), ("n_enc_layers", i32),
+        ("n_dec_layers", i32), ("n_heads", i32), ("rel_buckets", i32), ("rel_max_distance", i32),
+        ("whole_word_size", i32), ("gated_gelu", i32), ("dtype", i32), ("eps", f32), ("dropout", f32),
+        ("pad_id", i32), ("eos_id", i32),
+    ]
+
+
+# name -> (restype, argtypes)
+PROTOTYPES = {
+    "p5_last_error": (C.c_char_p, []),
+    "p5_abi_version": (i32, []),
+    "p5_is_emulator": (i32, []),
+    "p5_engine_create": (i32, [C.POINTER(P5Config), C.POINTER(vp)]),
+    "p5_engine_destroy": (i32, [vp]),
+    "p5_param_count": (i64, [vp]),
+    "p5_param_table": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
+    "p5_engine_bind": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    "p5_refresh_shadow": (i32, [vp, vp]),
+    "p5_train_workspace_bytes": (i64, [vp, i32, i32, i32]),
+    "p5_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp]),
+    "p5_backward_num_stages": (i32, [vp]),
+    "p5_backward_stage": (i32, [vp, vp, i32, vp]),
+    "p5_backward": (i32, [vp, vp, vp]),
+    "p5_backward_stage_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
+    "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32]),
+    "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp]),
+    "p5_encode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i64, vp]),
+    "p5_op_gemm": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, u32, f32, vp]),
+    "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "p5_op_rmsnorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "p5_op_attn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u32, f32, vp]),
+    "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                            i32, i32, i32, i32, vp, u32, f32, vp]),
+    "p5_op_ce_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "p5_op_tr_probe": (i32, [vp, vp, vp]),
+}
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every symbol of include/p5hip.h; raises AttributeError if one is missing."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+class P5Error(RuntimeError):
+    pass
+
+
+def check(lib, rc, what=""):
+    if rc != 0:
+        msg = lib.p5_last_error()
+        raise P5Error(f"{what} failed: {msg.decode() if msg else rc}")

@@ -1,0 +1,331 @@
+// p5_decode.h -- device-resident trie-constrained beam search (the `generate()` half of the hot path).
+//
+// Restates HF beam search as called by DistributedRunner.py:361-371 (generate(num_beams=K, num_return_sequences=K,
+// prefix_allowed_tokens_fn=trie)), following transformers 5.15.0 generation/utils.py:3008-3560 (vectorised
+// _beam_search) and PrefixConstrainedLogitsProcessor (logits_process.py:1536-1553):
+//   log_softmax over the FULL vocab, candidates outside the trie children of the beam's prefix are -inf (not
+//   renormalised), + running beam score, top-2K per batch item, EOS candidates ranked < K finish with
+//   score / generated_len, best K non-finished continue, early_stopping=False heuristic.
+// The reference walks a Python dict trie per (batch x beam) row per step with a D2H sync each
+// (generation_trie.py:47-70,91-97); here every beam carries its trie NODE id and the children come from a CSR
+// copy of the trie in HBM, so only the <= fan-out allowed logits are ever gathered.
+// KV-cache: self-attention K/V are stored per (step, row) and never permuted -- an ancestry table maps
+// (step, current beam) -> row that produced it; cross-attention K/V are kept per batch item and
+// shared by its K beams (the reference expands the encoder states xK, P5_T5.py:571-576).
+#pragma once
+#include "p5_device.h"
+
+// ---- single-token self-attention over the ancestry-indexed cache: one wave per (row, head) ----
+template <class T>
+__global__ __launch_bounds__(256) void p5_dec_self_attn_kernel(T* __restrict__ out, const T* __restrict__ qkv, T* __restrict__ cache,
+                                                              const int* __restrict__ anc, const float* __restrict__ rel_table,
+                                                              const int* __restrict__ lut, int lut_half, int R, int H, int pos,
+                                                              int max_len) {
+  const int lane = threadIdx.x & 63;
+  const int rh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rh >= R * H) return;
+  const int r = rh / H, h = rh % H;
+  const int inner = H * 64;
+  const float q = to_f<T>(qkv[(size_t)r * 3 * inner + h * 64 + lane]);
+  const T kcur = qkv[(size_t)r * 3 * inner + inner + h * 64 + lane];
+  const T vcur = qkv[(size_t)r * 3 * inner + 2 * inner + h * 64 + lane];
+  // cache layout: [max_len][R][2*inner]  (K then V)
+  cache[((size_t)pos * R + r) * 2 * inner + h * 64 + lane] = kcur;
+  cache[((size_t)pos * R + r) * 2 * inner + inner + h * 64 + lane] = vcur;
+  float mys = P5_NEG_INF;
+  for (int t = 0; t <= pos; ++t) {
+    float kv;
+    if (t == pos) kv = to_f<T>(kcur);
+    else kv = to_f<T>(cache[((size_t)t * R + anc[(size_t)t * R + r]) * 2 * inner + h * 64 + lane]);
+    float s = wave_sum(q * kv);
+    s += rel_table[lut[(t - pos) + lut_half] * H + h];
+    if (lane == t) mys = s;
+  }
+  const float m = wave_max(mys);
+  const float p = (lane <= pos) ? expf(mys - m) : 0.f;
+  const float l = wave_sum(p);
+  float o = 0.f;
+  for (int t = 0; t <= pos; ++t) {
+    const float pt = __shfl(p, t);
+    float vv;
+    if (t == pos) vv = to_f<T>(vcur);
+    else vv = to_f<T>(cache[((size_t)t * R + anc[(size_t)t * R + r]) * 2 * inner + inner + h * 64 + lane]);
+    o += pt * vv;
+  }
+  out[(size_t)r * inner + h * 64 + lane] = from_f<T>(o / l);
+}
+
+// ---- single-token cross-attention; K/V of batch item r / Kb are shared by its beams ----
+template <class T>
+__global__ __launch_bounds__(256) void p5_dec_cross_attn_kernel(T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ kv,
+                                                               const int64_t* __restrict__ mask, int R, int H, int Kb, int L) {
+  __shared__ float sq[4][64];
+  __shared__ float sp[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rh = blockIdx.x * 4 + wave;
+  const bool active = rh < R * H;
+  const int r = active ? rh / H : 0, h = active ? rh % H : 0;
+  const int b = r / Kb;
+  const int inner = H * 64;
+  if (active) sq[wave][lane] = to_f<T>(q[(size_t)r * inner + h * 64 + lane]);
+  __syncthreads();
+  float s[8];
+  float m = P5_NEG_INF;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    s[i] = P5_NEG_INF;
+    if (active && j < L && mask[(size_t)b * L + j] != 0) {
+      const T* kr = kv + ((size_t)b * L + j) * 2 * inner + h * 64;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 64 / TT<T>::EPF; ++c) {
+        float x[8];
+        unpack16<T>(ld16(kr + c * TT<T>::EPF), x);
+#pragma unroll
+        for (int e = 0; e < TT<T>::EPF; ++e) acc += x[e] * sq[wave][c * TT<T>::EPF + e];
+      }
+      s[i] = acc;
+    }
+    m = fmaxf(m, s[i]);
+  }
+  m = wave_max(m);
+  if (m == P5_NEG_INF) m = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + i * 64;
+    const float p = expf(s[i] - m);
+    if (j < 512) sp[wave][j] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  if (!active) return;
+  float o = 0.f;
+  for (int j = 0; j < L; ++j) o += sp[wave][j] * to_f<T>(kv[((size_t)b * L + j) * 2 * inner + inner + h * 64 + lane]);
+  out[(size_t)r * inner + h * 64 + lane] = from_f<T>(l > 0.f ? o / l : 0.f);
+}
+
+// ---- per row: full-vocab log-sum-exp, then gather only the trie children's log-probs (+ running score) ----
+__global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ cand_score, int* __restrict__ n_cand,
+                                                          const float* __restrict__ logits, int ldl, int V,
+                                                          const int* __restrict__ node, const float* __restrict__ run_score,
+                                                          const int* __restrict__ child_off, const int* __restrict__ child_tok,
+                                                          int max_c) {
+  __shared__ float sred[4];
+  const int r = blockIdx.x;
+  const int nd = node[r];
+  if (nd < 0) {  // dead beam: no candidates (uniform per block)
+    if (threadIdx.x == 0) n_cand[r] = 0;
+    return;
+  }
+  const float* lr = logits + (size_t)r * ldl;
+  float m = P5_NEG_INF;
+  for (int j = threadIdx.x; j < V; j += 256) m = fmaxf(m, lr[j]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int j = threadIdx.x; j < V; j += 256) s += expf(lr[j] - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = sred[0] + sred[1] + sred[2] + sred[3];
+  const float lse = m + logf(s);
+  const int c0 = child_off[nd], nc = child_off[nd + 1] - c0;
+  const float rs = run_score[r];
+  for (int c = threadIdx.x; c < nc && c < max_c; c += 256) cand_score[(size_t)r * max_c + c] = (lr[child_tok[c0 + c]] - lse) + rs;
+  if (threadIdx.x == 0) n_cand[r] = nc < max_c ? nc : max_c;
+}
+
+struct P5BeamState {
+  int* run_seq; int* run_seq_next;   // [B,K,max_len]
+  float* run_score;                  // [B,K]
+  int* run_node;                     // [B,K] trie node after the beam's prefix, -1 = dead
+  int* fin_seq; int* fin_seq_next;   // [B,K,max_len]
+  float* fin_score;                  // [B,K]
+  int* fin_flag;                     // [B,K]
+  int* fin_len;                      // [B,K]
+  int* unsat;                        // [B]
+  int* anc; int* anc_next;           // [max_len, R]
+  int64_t* last_tok;                 // [R] decoder input for the next step
+  int* flags;                        // [0] any_unsat, [1] not_all_hits  (host zeroes before each step)
+};
+
+// ---- one workgroup per batch item: top-2K over the item's candidates, then HF steps d-g ----
+__global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, float* __restrict__ cand_score, const int* __restrict__ n_cand,
+                                                          const int* __restrict__ child_off, const int* __restrict__ child_tok,
+                                                          const int* __restrict__ child_node, int max_c, int Kb, int max_len,
+                                                          int cur_len, int eos_id, int R) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float top_lp[128];
+  __shared__ int top_beam[128], top_tok[128], top_node[128];
+  __shared__ int sel_run[64];       // candidate index chosen for each new running beam
+  __shared__ int fin_src[64];       // >=0: old finished slot; <0: -(cand+1)
+  __shared__ float fin_sc[64];
+  __shared__ int fin_fl[64];
+  __shared__ int fin_ln[64];
+  __shared__ float run_sc[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int K2 = 2 * Kb;
+  // ---- top-2K by repeated block arg-max (ties -> lowest flat index = lowest beam, then lowest token) ----
+  for (int it = 0; it < K2; ++it) {
+    float bv = P5_NEG_INF;
+    int bi = 0x7fffffff;
+    for (int j = 0; j < Kb; ++j) {
+      const int r = b * Kb + j, nc = n_cand[r];
+      for (int c = tid; c < nc; c += 256) {
+        const float v = cand_score[(size_t)r * max_c + c];
+        const int fi = j * max_c + c;
+        if (v > bv || (v == bv && fi < bi)) { bv = v; bi = fi; }
+      }
+    }
+    // wave arg-max
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const float ov = __shfl_xor(bv, msk);
+      const int oi = __shfl_xor(bi, msk);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+      if (bi != 0x7fffffff && bv > P5_NEG_INF) {
+        const int j = bi / max_c, c = bi % max_c;
+        const int nd = st.run_node[b * Kb + j];
+        top_lp[it] = bv; top_beam[it] = j;
+        top_tok[it] = child_tok[child_off[nd] + c];
+        top_node[it] = child_node[child_off[nd] + c];
+        cand_score[(size_t)(b * Kb + j) * max_c + c] = P5_NEG_INF;   // taken
+      } else {  // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries
+        top_lp[it] = P5_NEG_INF; top_beam[it] = 0; top_tok[it] = 0; top_node[it] = -1;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- sequential bookkeeping on <= 2K + K entries (HF utils.py:3131-3204, 3008-3075) ----
+  if (tid == 0) {
+    const bool at_max = (cur_len + 1 >= max_len);
+    bool all_hits = true;
+    float run_lp[128];
+    bool hit[128];
+    for (int i = 0; i < K2; ++i) {
+      hit[i] = (top_tok[i] == eos_id) || at_max;
+      all_hits = all_hits && hit[i];
+      run_lp[i] = top_lp[i] + (hit[i] ? -1.0e9f : 0.f);
+    }
+    // e. next running beams: stable top-K of run_lp
+    bool used[128];
+    for (int i = 0; i < K2; ++i) used[i] = false;
+    for (int j = 0; j < Kb; ++j) {
+      int best = -1;
+      for (int i = 0; i < K2; ++i)
+        if (!used[i] && (best < 0 || run_lp[i] > run_lp[best])) best = i;
+      used[best] = true;
+      sel_run[j] = best;
+    }
+    // f. finished beams: stable top-K over [old finished ; new candidates]
+    const bool uns = st.unsat[b] != 0;
+    float msc[192];
+    for (int j = 0; j < Kb; ++j) msc[j] = st.fin_score[b * Kb + j];
+    for (int i = 0; i < K2; ++i) {
+      float v = top_lp[i] / (float)cur_len;
+      if (!uns) v += -1.0e9f;
+      if (!(hit[i] && i < Kb)) v += -1.0e9f;
+      msc[Kb + i] = v;
+    }
+    bool mused[192];
+    for (int i = 0; i < Kb + K2; ++i) mused[i] = false;
+    for (int j = 0; j < Kb; ++j) {
+      int best = -1;
+      for (int i = 0; i < Kb + K2; ++i)
+        if (!mused[i] && (best < 0 || msc[i] > msc[best])) best = i;
+      mused[best] = true;
+      fin_sc[j] = msc[best];
+      if (best < Kb) { fin_src[j] = best; fin_fl[j] = st.fin_flag[b * Kb + best]; fin_ln[j] = st.fin_len[b * Kb + best]; }
+      else { fin_src[j] = -(best - Kb + 1); fin_fl[j] = (hit[best - Kb] && (best - Kb) < Kb) ? 1 : 0; fin_ln[j] = cur_len; }
+    }
+    // g. early-stop heuristic with the NEW running / finished sets
+    const float best_possible = run_lp[sel_run[0]] / (float)cur_len;   // (cur_len+1) - prompt_len(1)
+    float mn = fin_sc[0];
+    for (int j = 1; j < Kb; ++j) mn = fminf(mn, fin_sc[j]);
+    bool any = false;
+    for (int j = 0; j < Kb; ++j) {
+      const float worst = fin_fl[j] ? mn : -1.0e9f;
+      any = any || (best_possible > worst);
+    }
+    const int new_unsat = (uns && any) ? 1 : 0;
+    st.unsat[b] = new_unsat;
+    if (new_unsat) atomicAdd(&st.flags[0], 1);
+    if (!all_hits) atomicAdd(&st.flags[1], 1);
+    for (int j = 0; j < Kb; ++j) run_sc[j] = run_lp[sel_run[j]];
+  }
+  __syncthreads();
+  // ---- materialise the new finished set (reads OLD fin_seq / run_seq, writes fin_seq_next) ----
+  for (int t = tid; t < Kb * max_len; t += 256) {
+    const int j = t / max_len, p = t % max_len;
+    int v;
+    if (fin_src[j] >= 0) v = st.fin_seq[((size_t)b * Kb + fin_src[j]) * max_len + p];
+    else {
+      const int i = -fin_src[j] - 1;
+      v = (p == cur_len) ? top_tok[i] : st.run_seq[((size_t)b * Kb + top_beam[i]) * max_len + p];
+    }
+    st.fin_seq_next[((size_t)b * Kb + j) * max_len + p] = v;
+  }
+  if (tid < Kb) {
+    st.fin_len[b * Kb + tid] = fin_ln[tid];
+    st.fin_score[b * Kb + tid] = fin_sc[tid];
+    st.fin_flag[b * Kb + tid] = fin_fl[tid];
+  }
+  // ---- new running sequences / nodes / ancestry (reads OLD run_seq / anc, writes *_next) ----
+  for (int t = tid; t < Kb * max_len; t += 256) {
+    const int j = t / max_len, p = t % max_len;
+    const int i = sel_run[j];
+    st.run_seq_next[((size_t)b * Kb + j) * max_len + p] =
+        (p == cur_len) ? top_tok[i] : st.run_seq[((size_t)b * Kb + top_beam[i]) * max_len + p];
+  }
+  const int pos = cur_len - 1;   // K/V of this step were stored at `pos` by row (b*Kb + old beam)
+  for (int t = tid; t < Kb * (pos + 1); t += 256) {
+    const int j = t / (pos + 1), p = t % (pos + 1);
+    const int parent_row = b * Kb + top_beam[sel_run[j]];
+    st.anc_next[(size_t)p * R + b * Kb + j] = (p == pos) ? parent_row : st.anc[(size_t)p * R + parent_row];
+  }
+  if (tid < Kb) {
+    const int i = sel_run[tid];
+    st.run_node[b * Kb + tid] = top_node[i];
+    st.last_tok[b * Kb + tid] = (int64_t)top_tok[i];
+    st.run_score[b * Kb + tid] = run_sc[tid];
+  }
+}
+
+// initial state: every beam at the trie node reached by the decoder start token, scores [0, -1e9, ...]
+__global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const int* __restrict__ child_off, const int* __restrict__ child_tok,
+                                                          const int* __restrict__ child_node, const int* __restrict__ roots, int B, int Kb, int max_len,
+                                                          int start_id) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int R = B * Kb;
+  if (i < R * max_len) {
+    const int v0 = ((i % max_len) == 0) ? start_id : 0;
+    st.run_seq[i] = v0; st.run_seq_next[i] = v0; st.fin_seq[i] = v0; st.fin_seq_next[i] = v0;
+    st.anc[i] = 0; st.anc_next[i] = 0;
+  }
+  if (i < R) {
+    int nd = -1;
+    const int root = roots ? roots[i / Kb] : 0;
+    for (int c = child_off[root]; c < child_off[root + 1]; ++c)
+      if (child_tok[c] == start_id) nd = child_node[c];
+    st.run_node[i] = nd;
+    st.run_score[i] = (i % Kb == 0) ? 0.f : -1.0e9f;
+    st.fin_score[i] = -1.0e9f;
+    st.fin_flag[i] = 0;
+    st.fin_len[i] = 0;
+    st.last_tok[i] = start_id;
+  }
+  if (i < B) st.unsat[i] = 1;
+}

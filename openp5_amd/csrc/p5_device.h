@@ -1,0 +1,196 @@
+// p5_device.h -- device-side building blocks shared by every kernel file (gfx950 / CDNA4).
+//
+// Wave = 64 lanes.  All matrix work goes through ONE fragment convention so that the same kernel
+// template serves both precisions of the engine:
+//   * T = bf16 : v_mfma_f32_16x16x32_bf16   (fast mode; fp32 accumulate)
+//   * T = float: v_mfma_f32_16x16x4_f32 x4  (parity mode; exact fp32 FMA chain, MI355X guide section 3)
+// A "fragment" is always 16 bytes of reduction-dim-contiguous data per lane; one `mma16` call consumes a
+// 64-byte K-chunk (32 bf16 or 16 f32) of a 16-row A tile and a 16-row B^T tile:
+//   lane l supplies A[row = l & 15][chunk_k = (l >> 4) * (16 / sizeof(T)) + 0..]  and
+//                   B[col = l & 15][same k range],
+//   result tile C[row = (l >> 4) * 4 + r][col = l & 15], r = 0..3   (guide section 3, C/D layout).
+// For f32 the four MFMAs take element i of the lane's float4, i.e. lane group g contributes
+// k = 4g + i to MFMA i -- a k-permutation applied identically to A and B, which leaves the sum unchanged.
+#pragma once
+#include <stdint.h>
+
+#ifndef P5_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct bf16 {
+  unsigned short v;
+};
+
+// ---- scalar conversions (round-to-nearest-even, written out so host emulation and device agree) ----
+__host__ __device__ static __forceinline__ float bf2f(bf16 x) {
+  union { unsigned u; float f; } c;
+  c.u = ((unsigned)x.v) << 16;
+  return c.f;
+}
+__host__ __device__ static __forceinline__ bf16 f2bf(float f) {
+  union { unsigned u; float f; } c;
+  c.f = f;
+  unsigned u = c.u;
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) {  // NaN stays NaN
+    bf16 r; r.v = (unsigned short)((u >> 16) | 0x40); return r;
+  }
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  bf16 r;
+  r.v = (unsigned short)(u >> 16);
+  return r;
+}
+template <class T> __host__ __device__ static __forceinline__ float to_f(T x);
+template <> __host__ __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __host__ __device__ __forceinline__ float to_f<bf16>(bf16 x) { return bf2f(x); }
+template <class T> __host__ __device__ static __forceinline__ T from_f(float x);
+template <> __host__ __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __host__ __device__ __forceinline__ bf16 from_f<bf16>(float x) { return f2bf(x); }
+
+template <class T> struct TT;
+template <> struct TT<float> { static constexpr int EPF = 4; static constexpr int KCH = 16; static constexpr int DT = 0; };
+template <> struct TT<bf16> { static constexpr int EPF = 8; static constexpr int KCH = 32; static constexpr int DT = 1; };
+// EPF = elements per 16-byte fragment, KCH = elements of K consumed per mma16 (64 bytes).
+
+#define P5_NEG_INF (-__builtin_huge_valf())
+#define P5_DT_F32 0
+#define P5_DT_BF16 1
+
+// ---- launch + block primitives -------------------------------------------------------------------
+#ifdef P5_EMU
+#define P5_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+#define P5_DYN_SMEM(name) char* name = emu::B().dyn_smem
+#define P5_LANE() ((int)emu::lane())
+#else
+#define P5_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#define P5_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define P5_LANE() ((int)(threadIdx.x & 63))
+#endif
+
+// ---- MFMA -------------------------------------------------------------------------------------------
+#ifdef P5_EMU
+template <class T>
+static inline void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  emu::Wave& w = emu::wave();
+  const int l = (int)emu::lane();
+  memcpy(w.slot[l], &a, 16);
+  memcpy(w.slot[l] + 16, &b, 16);
+  emu::wave_barrier();
+  const int col = l & 15, rg = l >> 4;
+  constexpr int E = TT<T>::EPF;
+  for (int r = 0; r < 4; ++r) {
+    const int row = rg * 4 + r;
+    float s = acc[r];
+    for (int g = 0; g < 4; ++g) {
+      const T* pa = (const T*)(w.slot[g * 16 + row]);
+      const T* pb = (const T*)(w.slot[g * 16 + col] + 16);
+      for (int j = 0; j < E; ++j) s += to_f<T>(pa[j]) * to_f<T>(pb[j]);
+    }
+    acc[r] = s;
+  }
+  emu::wave_barrier();
+}
+#else
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <class T> __device__ static __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
+  f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
+}
+#endif
+
+// ---- LDS transpose read (gfx950 ds_read_b64_tr_b16) ---------------------------------------------------
+// Within each 16-lane group the 16 lanes' 8-byte rows form a [4][16] bf16 block (lane i owns row i/4,
+// columns (i%4)*4..+3); lane i receives column i, i.e. 4 values that sit in 4 different rows.
+#ifdef P5_EMU
+static inline u32x2 lds_tr16_b64(const void* p) {
+  emu::Wave& w = emu::wave();
+  const int l = (int)emu::lane();
+  memcpy(w.slot[l], p, 8);
+  emu::wave_barrier();
+  const int g = l & ~15, i = l & 15;
+  unsigned short v[4];
+  for (int j = 0; j < 4; ++j) {
+    const unsigned short* row = (const unsigned short*)w.slot[g + j * 4 + (i >> 2)];
+    v[j] = row[i & 3];
+  }
+  emu::wave_barrier();
+  u32x2 r;
+  r[0] = (unsigned)v[0] | ((unsigned)v[1] << 16);
+  r[1] = (unsigned)v[2] | ((unsigned)v[3] << 16);
+  return r;
+}
+#else
+__device__ static __forceinline__ u32x2 lds_tr16_b64(const void* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(u32x2, r);
+}
+#endif
+
+// ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
+__device__ static __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ static __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+// reduce across the 16 lanes that share (lane >> 4): one accumulator ROW of a 16x16 C tile
+__device__ static __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ static __forceinline__ float row16_max(float v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// ---- 16-byte vector load/store helpers --------------------------------------------------------------
+__device__ static __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+__device__ static __forceinline__ void st16(void* p, u32x4 v) { *(u32x4*)p = v; }
+__device__ static __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+template <class T> __device__ static __forceinline__ void unpack16(const u32x4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { union { unsigned u; float f; } c; c.u = v[i]; out[i] = c.f; }
+}
+template <> __device__ __forceinline__ void unpack16<bf16>(const u32x4& v, float* out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    union { unsigned u; float f; } lo, hi;
+    lo.u = v[i] << 16; hi.u = v[i] & 0xFFFF0000u;
+    out[2 * i] = lo.f; out[2 * i + 1] = hi.f;
+  }
+}
+template <class T> __device__ static __forceinline__ u32x4 pack16(const float* in);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { union { unsigned u; float f; } c; c.f = in[i]; v[i] = c.u; }
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16>(const float* in) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf(in[2 * i]).v | ((unsigned)f2bf(in[2 * i + 1]).v << 16);
+  return v;
+}

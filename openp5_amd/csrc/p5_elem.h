@@ -1,0 +1,336 @@
+// p5_elem.h -- HBM-bound row kernels of the T5 path: embedding gather(+whole-word add), T5 RMSNorm
+// forward/backward, fp32->T mask/cast, embedding-gradient scatter, token cross-entropy on materialised logits,
+// fused clip + HF-AdamW over the flat parameter arena.  All of them move 16 bytes per lane per access and use
+// one 64-lane wave per row (d_model <= 1024 -> <= 2 pieces per lane in bf16, 4 in f32).
+#pragma once
+#include "p5_device.h"
+#include "p5_rng.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: x[row,:] = E[ids[row],:] (+ WW[ww[row],:]), dropout.   P5_T5.py:94-100,125 (JointEncoder), decoder: E only
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void p5_embed_fwd_kernel(T* __restrict__ out, const T* __restrict__ E, const T* __restrict__ WW,
+                                                          const int64_t* __restrict__ ids, const int64_t* __restrict__ ww,
+                                                          int rows, int d, P5Drop drop) {
+  constexpr int EPF = TT<T>::EPF;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t id = ids[row];
+  const int64_t w = WW ? ww[row] : 0;
+  const bool do_drop = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+  for (int c = lane; c < d / EPF; c += 64) {
+    float x[8], y[8];
+    unpack16<T>(ld16(E + (size_t)id * d + c * EPF), x);
+    if (WW) {
+      unpack16<T>(ld16(WW + (size_t)w * d + c * EPF), y);
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) x[e] += y[e];
+    }
+    if (do_drop) {
+#pragma unroll
+      for (int e = 0; e < EPF; ++e)
+        x[e] = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c * EPF + e), drop.thr) ? x[e] * drop.scale : 0.f;
+    }
+    st16(out + (size_t)row * d + c * EPF, pack16<T>(x));
+  }
+}
+
+// dE[ids[row],:] += mask(dres[row,:]);  dWW[ww[row],:] += same   (SURVEY.md App. C "Embedding lookups")
+template <class T>
+__global__ __launch_bounds__(256) void p5_embed_bwd_kernel(float* __restrict__ dE, float* __restrict__ dWW,
+                                                          const float* __restrict__ dres, const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ ww, int rows, int d, P5Drop drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t id = ids[row];
+  const int64_t w = dWW ? ww[row] : 0;
+  const bool do_drop = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+  for (int c = lane; c < d; c += 64) {
+    float v = dres[(size_t)row * d + c];
+    if (do_drop) v = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c), drop.thr) ? v * drop.scale : 0.f;
+    atomicAdd(dE + (size_t)id * d + c, v);
+    if (dWW) atomicAdd(dWW + (size_t)w * d + c, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: T5LayerNorm (HF modeling_t5.py:59-72): y = w * x * rsqrt(mean(x^2) + eps), fp32 statistics.
+// Optional dropout on y (final norms, P5_T5.py:179-180).  Saves rstd for the backward.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void p5_rmsnorm_fwd_kernel(T* __restrict__ y, float* __restrict__ rstd_out, const T* __restrict__ x,
+                                                            const float* __restrict__ w, int rows, int d, float eps, P5Drop drop) {
+  constexpr int EPF = TT<T>::EPF;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int npc = d / EPF;
+  float xv[4][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    if (c < npc) {
+      unpack16<T>(ld16(x + (size_t)row * d + c * EPF), xv[i]);
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) ss += xv[i][e] * xv[i][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)d + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  const bool do_drop = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    if (c < npc) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) {
+        // reference order: (x * rstd) rounded to the activation dtype, then * weight
+        const float n = to_f<T>(from_f<T>(xv[i][e] * rstd));
+        o[e] = w[c * EPF + e] * n;
+        if (do_drop) o[e] = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c * EPF + e), drop.thr) ? o[e] * drop.scale : 0.f;
+      }
+      st16(y + (size_t)row * d + c * EPF, pack16<T>(o));
+    }
+  }
+}
+
+// Backward:  xh = x*rstd;  dw += sum_rows dy*xh;  dx = rstd*(dy*w - xh*mean_j(dy_j w_j xh_j))
+//   dres_out = (dres_in ? dres_in : 0) + dx                         (fp32 residual-stream gradient)
+//   dy_next  = dropmask_next(dres_out) cast to T                     (input to the PRECEDING sub-layer's dgrad)
+// drop_in masks the incoming dy (only for the final norms whose output is dropped).
+// Each workgroup walks rows with a grid stride and flushes its dw partials with one atomicAdd per column.
+template <class T>
+__global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__ dres_out, T* __restrict__ dy_next,
+                                                            float* __restrict__ dw, const T* __restrict__ dy,
+                                                            const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
+                                                            int rows, int d, P5Drop drop_in, P5Drop drop_next) {
+  constexpr int EPF = TT<T>::EPF;
+  __shared__ float sdw[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npc = d / EPF;
+  float dwacc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
+  const bool din = drop_in.state != nullptr && drop_in.thr != 0;
+  const bool dnx = drop_next.state != nullptr && drop_next.thr != 0;
+  const uint32_t seed_in = p5_seed(drop_in), seed_nx = p5_seed(drop_next);
+
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float rstd = rstd_in[row];
+    float dyv[4][8], xh[4][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64;
+      if (c < npc) {
+        unpack16<T>(ld16(dy + (size_t)row * d + c * EPF), dyv[i]);
+        unpack16<T>(ld16(x + (size_t)row * d + c * EPF), xh[i]);
+#pragma unroll
+        for (int e = 0; e < EPF; ++e) {
+          if (din) dyv[i][e] = p5_keep(seed_in, drop_in.site_key, (uint32_t)(row * d + c * EPF + e), drop_in.thr) ? dyv[i][e] * drop_in.scale : 0.f;
+          xh[i][e] *= rstd;
+          dwacc[i][e] += dyv[i][e] * xh[i][e];
+          dyv[i][e] *= w[c * EPF + e];
+          dot += dyv[i][e] * xh[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + i * 64;
+      if (c < npc) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < EPF; ++e) {
+          const size_t gi = (size_t)row * d + c * EPF + e;
+          float v = rstd * (dyv[i][e] - xh[i][e] * dot);
+          if (dres_in) v += dres_in[gi];
+          dres_out[gi] = v;
+          o[e] = dnx ? (p5_keep(seed_nx, drop_next.site_key, (uint32_t)gi, drop_next.thr) ? v * drop_next.scale : 0.f) : v;
+        }
+        if (dy_next) st16(dy_next + (size_t)row * d + c * EPF, pack16<T>(o));
+      }
+    }
+  }
+  // flush dw
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + i * 64;
+    if (c < npc) {
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) sdw[wave][c * EPF + e] = dwacc[i][e];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const float v = sdw[0][j] + sdw[1][j] + sdw[2][j] + sdw[3][j];
+    if (v != 0.f) atomicAdd(dw + j, v);
+  }
+}
+
+// out(T) = dropmask(in fp32)  -- top of the encoder backward (grad of drop(final_norm(x)) arrives in fp32)
+template <class T>
+__global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, const float* __restrict__ in, size_t n, P5Drop drop) {
+  const bool dd = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = in[i];
+    if (dd) v = p5_keep(seed, drop.site_key, (uint32_t)i, drop.thr) ? v * drop.scale : 0.f;
+    out[i] = from_f<T>(v);
+  }
+}
+
+// fp32 master -> compute-dtype shadow (bf16 fast mode)
+template <class T>
+__global__ __launch_bounds__(256) void p5_cast_kernel(T* __restrict__ out, const float* __restrict__ in, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = from_f<T>(in[i]);
+}
+
+// gated-gelu epilogue (T5 v1.1 / Flan: HF modeling_t5.py:97-123): h = gelu_new(u0) * u1, u = [u0 | u1] per row
+template <class T>
+__global__ __launch_bounds__(256) void p5_gated_gelu_fwd_kernel(T* __restrict__ h, const T* __restrict__ u, int rows, int F, P5Drop drop) {
+  const bool dd = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+  const size_t n = (size_t)rows * F;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / F, c = i % F;
+    const float a = to_f<T>(u[r * 2 * F + c]), b = to_f<T>(u[r * 2 * F + F + c]);
+    const float t = tanhf(0.7978845608028654f * (a + 0.044715f * a * a * a));
+    float v = 0.5f * a * (1.f + t) * b;
+    if (dd) v = p5_keep(seed, drop.site_key, (uint32_t)i, drop.thr) ? v * drop.scale : 0.f;
+    h[i] = from_f<T>(v);
+  }
+}
+// du = d(gelu_new(u0)*u1): dh arrives already multiplied by nothing; recomputes the dropout mask.
+template <class T>
+__global__ __launch_bounds__(256) void p5_gated_gelu_bwd_kernel(T* __restrict__ du, const T* __restrict__ dh, const T* __restrict__ u,
+                                                               int rows, int F, P5Drop drop) {
+  const bool dd = drop.state != nullptr && drop.thr != 0;
+  const uint32_t seed = p5_seed(drop);
+  const size_t n = (size_t)rows * F;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / F, c = i % F;
+    const float a = to_f<T>(u[r * 2 * F + c]), b = to_f<T>(u[r * 2 * F + F + c]);
+    float g = to_f<T>(dh[i]);
+    if (dd) g = p5_keep(seed, drop.site_key, (uint32_t)i, drop.thr) ? g * drop.scale : 0.f;
+    const float k = 0.7978845608028654f;
+    const float inner = k * (a + 0.044715f * a * a * a);
+    const float t = tanhf(inner);
+    const float gel = 0.5f * a * (1.f + t);
+    const float dgel = 0.5f * (1.f + t) + 0.5f * a * (1.f - t * t) * k * (1.f + 3.f * 0.044715f * a * a);
+    du[r * 2 * F + c] = from_f<T>(g * b * dgel);
+    du[r * 2 * F + F + c] = from_f<T>(g * gel);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K9/K10: token cross-entropy on fp32 logits [R, ldl] (P5_T5.py:368-369, reduction="none", ignore_index=-100)
+// ---------------------------------------------------------------------------------------------------------
+__device__ static __forceinline__ float block_reduce(float v, bool is_max, float* sred) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sred[wave] = v;
+  __syncthreads();
+  float r = sred[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sred[i]) : r + sred[i];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll, float* __restrict__ lse_out,
+                                                       const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                       int V, int ldl) {
+  __shared__ float sred[4];
+  const int row = blockIdx.x;
+  const float* lr = logits + (size_t)row * ldl;
+  float m = P5_NEG_INF;
+  for (int j = threadIdx.x; j < V; j += 256) m = fmaxf(m, lr[j]);
+  m = block_reduce(m, true, sred);
+  float s = 0.f;
+  for (int j = threadIdx.x; j < V; j += 256) s += expf(lr[j] - m);
+  s = block_reduce(s, false, sred);
+  if (threadIdx.x == 0) {
+    const float lse = m + logf(s);
+    lse_out[row] = lse;
+    const int64_t lab = labels[row];
+    nll[row] = (lab == -100) ? 0.f : lse - lr[lab];
+  }
+}
+
+// dlogits[row, j] = (softmax_j - [j == label]) * dnll[row]   -> T, padded columns (V..ldd) zeroed
+template <class T>
+__global__ __launch_bounds__(256) void p5_ce_bwd_kernel(T* __restrict__ dlogits, const float* __restrict__ logits,
+                                                       const float* __restrict__ lse, const int64_t* __restrict__ labels,
+                                                       const float* __restrict__ dnll, int V, int ldl, int ldd) {
+  const int row = blockIdx.x;
+  const float* lr = logits + (size_t)row * ldl;
+  const int64_t lab = labels[row];
+  const float g = (lab == -100) ? 0.f : dnll[row];
+  const float l = lse[row];
+  for (int j = threadIdx.x; j < ldd; j += 256) {
+    float v = 0.f;
+    if (j < V) v = (expf(lr[j] - l) - (j == lab ? 1.f : 0.f)) * g;
+    dlogits[(size_t)row * ldd + j] = from_f<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K11/K12: global-norm clip + HF AdamW (SingleRunner.py:191-217, DistributedRunner.py:81)
+// over the flat arena: one pass for sum(g^2), one pass for the update (also refreshes the bf16 shadow).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p5_sumsq_kernel(float* __restrict__ out, const float* __restrict__ g, size_t n) {
+  __shared__ float sred[4];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(g + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+  s = block_reduce(s, false, sred);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+struct P5AdamArgs {
+  float* p; const float* g; float* m; float* v;
+  void* shadow;            // bf16 compute copy or nullptr
+  const float* sumsq;      // device scalar: sum of squared grads (already all-reduced); nullptr => no clipping
+  size_t n;
+  float lr, beta1, beta2, eps, wd, max_norm, grad_scale;
+  float bc1, bc2;          // 1 - beta1^t, 1 - beta2^t
+};
+
+__global__ __launch_bounds__(256) void p5_adamw_kernel(P5AdamArgs a) {
+  float coef = a.grad_scale;
+  if (a.sumsq) {
+    const float norm = sqrtf(*a.sumsq) * a.grad_scale;
+    const float c = a.max_norm / (norm + 1e-6f);
+    coef *= (c < 1.f ? c : 1.f);
+  }
+  const float step_size = a.lr * sqrtf(a.bc2) / a.bc1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float g = a.g[i] * coef;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    float p = a.p[i];
+    p = p - step_size * (m / (sqrtf(v) + a.eps));
+    p = p - a.lr * a.wd * p;
+    a.p[i] = p;
+    if (a.shadow) ((bf16*)a.shadow)[i] = f2bf(p);
+  }
+}

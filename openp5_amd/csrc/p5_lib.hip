@@ -1,0 +1,911 @@
+// p5_lib.hip -- host side of libp5hip.so: kernel launchers, the T5 engine (forward / backward / generate
+// orchestration over one HIP stream) and the C ABI declared in include/p5hip.h.
+//
+// The engine replaces the Python object `P5_T5` (model/P5_T5.py:207) + HF T5ForConditionalGeneration + autograd:
+// it owns no memory; parameters live in ONE flat fp32 arena (plus a bf16 shadow in fast mode), gradients in a
+// second arena of the same layout (so clip + AdamW are two flat kernels and DDP buckets are contiguous
+// ranges), activations in a caller-provided workspace.
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+#include "p5_device.h"
+#include "p5_rng.h"
+#include "p5_gemm.h"
+#include "p5_attn.h"
+#include "p5_elem.h"
+#include "p5_decode.h"
+#include "../../include/p5hip.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define P5_REQUIRE(cond, msg) do { if (!(cond)) return fail(std::string(msg) + " [" #cond "]"); } while (0)
+#define P5_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
+#ifdef P5_EMU
+#define P5_KCHECK() 0
+#else
+static int kcheck(const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(std::string(where) + ": " + hipGetErrorString(e));
+  return 0;
+}
+#define P5_KCHECK() kcheck(__func__)
+#endif
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+template <class T, int BM, int BN>
+static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
+  const int mode = g.a_ks * 2 + g.b_ks;
+  if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false>), grid, block, 0, s, g);
+  else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true>), grid, block, 0, s, g);
+  else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true>), grid, block, 0, s, g);
+  else return fail("gemm: (A strided, B contiguous) is not instantiated");
+  return P5_KCHECK();
+}
+
+template <class T>
+static int launch_gemm(P5GemmArgs g, hipStream_t s) {
+  constexpr int EPF = TT<T>::EPF;
+  P5_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem");
+  P5_REQUIRE(g.lda % EPF == 0 && g.ldb % EPF == 0, "gemm: leading dims must be multiples of 16 bytes");
+  P5_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");
+  if (!g.a_ks) P5_REQUIRE(g.K % EPF == 0 || g.lda >= ((g.K + EPF - 1) / EPF) * EPF, "gemm: A K-extent");
+  if (!g.b_ks) P5_REQUIRE(g.K % EPF == 0 || g.ldb >= ((g.K + EPF - 1) / EPF) * EPF, "gemm: B K-extent");
+  if (g.a_ks) P5_REQUIRE(g.M % EPF == 0 || g.lda >= ((g.M + EPF - 1) / EPF) * EPF, "gemm: A M-extent (KS)");
+  if (g.b_ks) P5_REQUIRE(g.N % EPF == 0 || g.ldb >= ((g.N + EPF - 1) / EPF) * EPF, "gemm: B N-extent (KS)");
+  if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm: accumulate epilogues need fp32 C");
+  const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const bool big = t128 >= 160;
+  const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  if (g.splitk <= 0) {
+    g.splitk = 1;
+    if (g.epi == P5_EPI_ATOMIC) {
+      const int nkc = (g.K + TT<T>::KCH - 1) / TT<T>::KCH;
+      int want = (int)((768 + tiles - 1) / tiles);
+      int maxs = nkc / 4 > 0 ? nkc / 4 : 1;
+      g.splitk = want < maxs ? want : maxs;
+      if (g.splitk < 1) g.splitk = 1;
+    }
+  }
+  if (g.splitk > 1) P5_REQUIRE(g.epi == P5_EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
+  return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
+}
+
+template <class T>
+static int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) {
+  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  dim3 grid((a.Lq + 63) / 64, a.B * a.H), block(256);
+  if (a.Lk <= 64) P5_LAUNCH((p5_attn_fwd_kernel<T, 4>), grid, block, 0, s, a);
+  else if (a.Lk <= 128) P5_LAUNCH((p5_attn_fwd_kernel<T, 8>), grid, block, 0, s, a);
+  else if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_kernel<T, 16>), grid, block, 0, s, a);
+  else P5_LAUNCH((p5_attn_fwd_kernel<T, 32>), grid, block, 0, s, a);
+  return P5_KCHECK();
+}
+template <class T>
+static int launch_attn_bwd(const P5AttnArgs& a, hipStream_t s) {
+  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  dim3 block(256);
+  P5_LAUNCH((p5_attn_bwd_dq_kernel<T>), dim3((a.Lq + 63) / 64, a.B * a.H), block, 0, s, a);
+  P5_TRY(P5_KCHECK());
+  P5_LAUNCH((p5_attn_bwd_dkv_kernel<T>), dim3((a.Lk + 63) / 64, a.B * a.H), block, 0, s, a);
+  return P5_KCHECK();
+}
+
+__global__ __launch_bounds__(256) void p5_shift_right_kernel(int64_t* out, const int64_t* labels, int B, int T, int64_t start) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * T) return;
+  const int t = i % T;
+  int64_t v = (t == 0) ? start : labels[i - 1];
+  if (v == -100) v = start;
+  out[i] = v;
+}
+
+__global__ __launch_bounds__(64) void p5_tr_probe_kernel(unsigned short* out, const unsigned short* in) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[256];
+  const int l = threadIdx.x;
+  for (int i = l; i < 256; i += 64) lds[i] = in[i];
+  __syncthreads();
+  // 16-lane group g reads the [4][16] block starting at element g*64, lane i -> row i/4, cols (i%4)*4..
+  const u32x2 r = lds_tr16_b64(&lds[(l >> 4) * 64 + (l & 15) * 4]);
+  out[l * 4 + 0] = (unsigned short)(r[0] & 0xFFFF);
+  out[l * 4 + 1] = (unsigned short)(r[0] >> 16);
+  out[l * 4 + 2] = (unsigned short)(r[1] & 0xFFFF);
+  out[l * 4 + 3] = (unsigned short)(r[1] >> 16);
+}
+
+// =====================================================================================================
+// engine
+// =====================================================================================================
+struct ParamInfo { std::string name; int64_t off; int rows, cols; };
+struct AttnOff { int64_t q, k, v, o, ln; };
+struct LayerOff { AttnOff sa, ca; int64_t wi, wo, ff_ln; int64_t begin, end; };
+
+struct LayerSave {
+  void *x_sa, *n_sa, *qkv, *o_sa; float *rstd_sa, *lse_sa;
+  void *x_ca, *n_ca, *q_ca, *kv_ca, *o_ca; float *rstd_ca, *lse_ca;
+  void *x_ff, *n_ff, *u_ff, *h_ff; float *rstd_ff;
+};
+
+struct Bump {
+  char* base; size_t off;
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct P5Engine {
+  P5Config c;
+  int inner;
+  int64_t off_E, off_WW, off_enc_rel, off_dec_rel, off_enc_fln, off_dec_fln, n_params, off_small_end;
+  std::vector<LayerOff> enc, dec;
+  std::vector<ParamInfo> table;
+  float* P = nullptr; float* G = nullptr; void* S = nullptr;
+  const int* lut_enc = nullptr; const int* lut_dec = nullptr; int lut_half = 0;
+  uint32_t* rng = nullptr;
+  // ---- saved state of the last forward ----
+  int B = 0, L = 0, T = 0, training = 0, M = 0, Md = 0, Vp = 0;
+  const int64_t *ids = nullptr, *ww = nullptr, *mask = nullptr, *labels = nullptr;
+  std::vector<LayerSave> es, ds;
+  void *enc_x0 = nullptr, *enc_xf = nullptr, *enc_out = nullptr; float* enc_rstd_f = nullptr;
+  int64_t* dec_ids = nullptr; void *dec_x0 = nullptr, *dec_xf = nullptr, *dec_hn = nullptr; float* dec_rstd_f = nullptr;
+  float *logits = nullptr, *lse_tok = nullptr;
+  float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr;
+  void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
+  bool d_enc_started = false;
+};
+
+static void add_param(P5Engine* e, const std::string& name, int rows, int cols, int64_t& off_out) {
+  // every tensor starts on a 64-element boundary so 16-byte vector accesses stay aligned in both dtypes
+  e->n_params = (e->n_params + 63) & ~(int64_t)63;
+  off_out = e->n_params;
+  e->table.push_back({name, e->n_params, rows, cols});
+  e->n_params += (int64_t)rows * cols;
+}
+
+static void add_attn(P5Engine* e, const std::string& p, AttnOff& a) {
+  const int d = e->c.d_model, in = e->inner;
+  add_param(e, p + ".q.weight", in, d, a.q);
+  // q,k,v must be back-to-back ([3*inner, d] fused projection): inner*d is a multiple of 64, so no padding appears
+  add_param(e, p + ".k.weight", in, d, a.k);
+  add_param(e, p + ".v.weight", in, d, a.v);
+  add_param(e, p + ".o.weight", d, in, a.o);
+}
+
+static void build_layout(P5Engine* e) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, F = c.d_ff;
+  e->n_params = 0;
+  add_param(e, "shared.weight", c.vocab_size, d, e->off_E);
+  add_param(e, "encoder.whole_word_embeddings.weight", c.whole_word_size, d, e->off_WW);
+  add_param(e, "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.n_heads, e->off_enc_rel);
+  add_param(e, "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", c.rel_buckets, c.n_heads, e->off_dec_rel);
+  e->n_params = (e->n_params + 63) & ~(int64_t)63;
+  e->off_small_end = e->n_params;
+  auto add_ff = [&](const std::string& p, LayerOff& l) {
+    if (c.gated_gelu) {
+      int64_t t;
+      add_param(e, p + ".DenseReluDense.wi_0.weight", F, d, l.wi);
+      add_param(e, p + ".DenseReluDense.wi_1.weight", F, d, t);
+    } else {
+      add_param(e, p + ".DenseReluDense.wi.weight", F, d, l.wi);
+    }
+    add_param(e, p + ".DenseReluDense.wo.weight", d, F, l.wo);
+  };
+  e->enc.resize(c.n_enc_layers);
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    LayerOff& l = e->enc[i];
+    const std::string p = "encoder.block." + std::to_string(i);
+    e->n_params = (e->n_params + 63) & ~(int64_t)63;
+    l.begin = e->n_params;
+    add_attn(e, p + ".layer.0.SelfAttention", l.sa);
+    add_param(e, p + ".layer.0.layer_norm.weight", 1, d, l.sa.ln);
+    add_ff(p + ".layer.1", l);
+    add_param(e, p + ".layer.1.layer_norm.weight", 1, d, l.ff_ln);
+    l.end = e->n_params;
+  }
+  add_param(e, "encoder.final_layer_norm.weight", 1, d, e->off_enc_fln);
+  e->dec.resize(c.n_dec_layers);
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    LayerOff& l = e->dec[i];
+    const std::string p = "decoder.block." + std::to_string(i);
+    e->n_params = (e->n_params + 63) & ~(int64_t)63;
+    l.begin = e->n_params;
+    add_attn(e, p + ".layer.0.SelfAttention", l.sa);
+    add_param(e, p + ".layer.0.layer_norm.weight", 1, d, l.sa.ln);
+    add_attn(e, p + ".layer.1.EncDecAttention", l.ca);
+    add_param(e, p + ".layer.1.layer_norm.weight", 1, d, l.ca.ln);
+    add_ff(p + ".layer.2", l);
+    add_param(e, p + ".layer.2.layer_norm.weight", 1, d, l.ff_ln);
+    l.end = e->n_params;
+  }
+  add_param(e, "decoder.final_layer_norm.weight", 1, d, e->off_dec_fln);
+  e->n_params = (e->n_params + 63) & ~(int64_t)63;
+}
+
+template <class T> static const T* Wc(const P5Engine* e, int64_t off) {
+  if (sizeof(T) == 4) return (const T*)(e->P + off);
+  return (const T*)((const bf16*)e->S + off);
+}
+
+static P5Drop mk_drop(const P5Engine* e, int stack, int layer, int which) {
+  P5Drop d;
+  d.state = nullptr; d.site_key = 0; d.thr = 0; d.scale = 1.f;
+  if (e->training && e->c.dropout > 0.f) {
+    d.state = e->rng;
+    d.site_key = p5_site_key(p5_site_id(stack, layer, which));
+    d.thr = p5_drop_thr(e->c.dropout);
+    d.scale = 1.f / (1.f - e->c.dropout);
+  }
+  return d;
+}
+static P5Drop no_drop() { P5Drop d; d.state = nullptr; d.site_key = 0; d.thr = 0; d.scale = 1.f; return d; }
+
+template <class T>
+static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, int ldb, int bks, void* C, int ldc, int M, int N,
+                int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop) {
+  P5GemmArgs g;
+  g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+  g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.alpha = alpha; g.drop = drop;
+  return launch_gemm<T>(g, s);
+}
+// y = x W^T
+template <class T>
+static int linear_fwd(hipStream_t s, const void* x, int ldx, const T* W, void* y, int ldy, int M, int N, int K, int epi = P5_EPI_STORE,
+                      const void* aux = nullptr, int ldaux = 0, float alpha = 1.f, int c_f32 = 0, P5Drop drop = no_drop()) {
+  return gemm<T>(s, x, ldx, 0, W, K, 0, y, ldy, M, N, K, epi, aux, ldaux, alpha, c_f32, drop);
+}
+// dx = dy W     (W is [N_out, K_in] row-major; reduction over N_out)
+template <class T>
+static int linear_dgrad(hipStream_t s, const void* dy, int lddy, const T* W, void* dx, int lddx, int M, int N_out, int K_in,
+                        int epi = P5_EPI_STORE, const void* aux = nullptr, int ldaux = 0, float alpha = 1.f, int c_f32 = 0) {
+  return gemm<T>(s, dy, lddy, 0, W, K_in, 1, dx, lddx, M, K_in, N_out, epi, aux, ldaux, alpha, c_f32, no_drop());
+}
+// dW += dy^T x   (fp32 atomics into the grad arena)
+template <class T>
+static int linear_wgrad(hipStream_t s, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
+                        float alpha = 1.f) {
+  return gemm<T>(s, dy, lddy, 1, x, ldx, 1, dW, K_in, N_out, K_in, M, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop());
+}
+
+template <class T>
+static int rmsnorm_fwd(hipStream_t s, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, P5Drop drop) {
+  P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
+  P5_LAUNCH((p5_rmsnorm_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (T*)y, rstd, (const T*)x, w, rows, d, eps, drop);
+  return P5_KCHECK();
+}
+template <class T>
+static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
+                       const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext) {
+  P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
+  int blocks = (rows + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  P5_LAUNCH((p5_rmsnorm_bwd_kernel<T>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd,
+            dres_in, rows, d, din, dnext);
+  return P5_KCHECK();
+}
+
+static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with_bwd) {
+  const P5Config& c = e->c;
+  const size_t sz = c.dtype == 1 ? 2 : 4;
+  const int d = c.d_model, in = e->inner, F = c.d_ff, H = c.n_heads;
+  const size_t M = (size_t)B * L, Md = (size_t)B * T;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  Bump b{base, 0};
+  e->es.assign(c.n_enc_layers, LayerSave());
+  e->ds.assign(c.n_dec_layers, LayerSave());
+  e->enc_x0 = b.take(M * d * sz);
+  void* xprev = e->enc_x0;
+  for (auto& l : e->es) {
+    l.x_sa = xprev;
+    l.n_sa = b.take(M * d * sz); l.rstd_sa = (float*)b.take(M * 4);
+    l.qkv = b.take(M * 3 * in * sz); l.o_sa = b.take(M * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * L * 4);
+    l.x_ff = b.take(M * d * sz);
+    l.n_ff = b.take(M * d * sz); l.rstd_ff = (float*)b.take(M * 4);
+    l.u_ff = c.gated_gelu ? b.take(M * 2 * F * sz) : nullptr;
+    l.h_ff = b.take(M * F * sz);
+    xprev = b.take(M * d * sz);
+  }
+  e->enc_xf = xprev;
+  e->enc_rstd_f = (float*)b.take(M * 4);
+  e->enc_out = b.take(M * d * sz);
+  if (T > 0) {
+    e->dec_ids = (int64_t*)b.take(Md * 8);
+    e->dec_x0 = b.take(Md * d * sz);
+    xprev = e->dec_x0;
+    for (auto& l : e->ds) {
+      l.x_sa = xprev;
+      l.n_sa = b.take(Md * d * sz); l.rstd_sa = (float*)b.take(Md * 4);
+      l.qkv = b.take(Md * 3 * in * sz); l.o_sa = b.take(Md * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * T * 4);
+      l.x_ca = b.take(Md * d * sz);
+      l.n_ca = b.take(Md * d * sz); l.rstd_ca = (float*)b.take(Md * 4);
+      l.q_ca = b.take(Md * in * sz); l.kv_ca = b.take(M * 2 * in * sz); l.o_ca = b.take(Md * in * sz);
+      l.lse_ca = (float*)b.take((size_t)B * H * T * 4);
+      l.x_ff = b.take(Md * d * sz);
+      l.n_ff = b.take(Md * d * sz); l.rstd_ff = (float*)b.take(Md * 4);
+      l.u_ff = c.gated_gelu ? b.take(Md * 2 * F * sz) : nullptr;
+      l.h_ff = b.take(Md * F * sz);
+      xprev = b.take(Md * d * sz);
+    }
+    e->dec_xf = xprev;
+    e->dec_rstd_f = (float*)b.take(Md * 4);
+    e->dec_hn = b.take(Md * d * sz);
+    e->logits = (float*)b.take(Md * Vp * 4);
+    e->lse_tok = (float*)b.take(Md * 4);
+  }
+  if (with_bwd) {
+    const size_t Mx = M > Md ? M : Md;
+    e->dres_a = (float*)b.take(Mx * d * 4);
+    e->dres_b = (float*)b.take(Mx * d * 4);
+    e->d_enc = (float*)b.take(M * d * 4);
+    e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
+    e->dy = b.take(Mx * d * sz);
+    e->dn = b.take(Mx * d * sz);
+    e->dqkv = b.take(Mx * 3 * in * sz);
+    e->dkv = b.take(M * 2 * in * sz);
+    e->dO = b.take(Mx * in * sz);
+    e->dh = b.take(Mx * F * sz);
+    e->du = c.gated_gelu ? b.take(Mx * 2 * F * sz) : nullptr;
+    e->dlogits = b.take(Md * Vp * sz);
+  }
+  return (int64_t)((b.off + 255) & ~(size_t)255);
+}
+
+// ---- shared sub-layer forward helpers -----------------------------------------------------------------
+template <class T>
+static int ffn_fwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, void* xout, int rows, int stack, int li) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, F = c.d_ff;
+  P5_TRY(rmsnorm_fwd<T>(s, l.n_ff, l.rstd_ff, l.x_ff, e->P + lo.ff_ln, rows, d, c.eps, no_drop()));
+  if (c.gated_gelu) {
+    P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.u_ff, 2 * F, rows, 2 * F, d));
+    const size_t n = (size_t)rows * F;
+    P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
+              (T*)l.h_ff, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
+    P5_TRY(P5_KCHECK());
+  } else {
+    P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.h_ff, F, rows, F, d, P5_EPI_RELU_DROP, nullptr, 0, 1.f, 0, mk_drop(e, stack, li, 5)));
+  }
+  return linear_fwd<T>(s, l.h_ff, F, Wc<T>(e, lo.wo), xout, d, rows, d, F, P5_EPI_RESID_DROP, l.x_ff, d, 1.f, 0, mk_drop(e, stack, li, 6));
+}
+
+template <class T>
+static int encoder_fwd(P5Engine* e, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M;
+  P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, (T*)e->enc_x0, Wc<T>(e, e->off_E), Wc<T>(e, e->off_WW), e->ids,
+            e->ww, M, d, mk_drop(e, 0, 0, 0));
+  P5_TRY(P5_KCHECK());
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    const LayerOff& lo = e->enc[i];
+    LayerSave& l = e->es[i];
+    void* xnext = (i + 1 < c.n_enc_layers) ? e->es[i + 1].x_sa : e->enc_xf;
+    P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, M, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, M, 3 * in, d));
+    P5AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa;
+    a.rel_table = e->P + e->off_enc_rel; a.bucket_lut = e->lut_enc; a.lut_half = e->lut_half; a.kmask = e->mask;
+    a.B = e->B; a.H = H; a.Lq = e->L; a.Lk = e->L; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.causal = 0;
+    a.drop = mk_drop(e, 0, i, 1);
+    P5_TRY(launch_attn_fwd<T>(a, s));
+    P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 0, i, 2)));
+    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, M, 0, i));
+  }
+  return rmsnorm_fwd<T>(s, e->enc_out, e->enc_rstd_f, e->enc_xf, e->P + e->off_enc_fln, M, d, c.eps, mk_drop(e, 0, 0, 7));
+}
+
+template <class T>
+static int decoder_fwd(P5Engine* e, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
+  P5_LAUNCH(p5_shift_right_kernel, dim3((Md + 255) / 256), dim3(256), 0, s, e->dec_ids, e->labels, e->B, e->T, (int64_t)c.pad_id);
+  P5_TRY(P5_KCHECK());
+  P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, (T*)e->dec_x0, Wc<T>(e, e->off_E), (const T*)nullptr,
+            (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
+  P5_TRY(P5_KCHECK());
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const LayerOff& lo = e->dec[i];
+    LayerSave& l = e->ds[i];
+    void* xnext = (i + 1 < c.n_dec_layers) ? e->ds[i + 1].x_sa : e->dec_xf;
+    // self attention (causal, unidirectional buckets)
+    P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, Md, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, Md, 3 * in, d));
+    P5AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa;
+    a.rel_table = e->P + e->off_dec_rel; a.bucket_lut = e->lut_dec; a.lut_half = e->lut_half; a.kmask = nullptr;
+    a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->T; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.causal = 1;
+    a.drop = mk_drop(e, 1, i, 1);
+    P5_TRY(launch_attn_fwd<T>(a, s));
+    P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ca, d, Md, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 1, i, 2)));
+    // cross attention (zero position bias + encoder padding mask)
+    P5_TRY(rmsnorm_fwd<T>(s, l.n_ca, l.rstd_ca, l.x_ca, e->P + lo.ca.ln, Md, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, l.n_ca, d, Wc<T>(e, lo.ca.q), l.q_ca, in, Md, in, d));
+    P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, lo.ca.k), l.kv_ca, 2 * in, M, 2 * in, d));
+    memset(&a, 0, sizeof(a));
+    a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca;
+    a.rel_table = nullptr; a.bucket_lut = nullptr; a.kmask = e->mask;
+    a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = 2 * in; a.ldo = in; a.causal = 0;
+    a.drop = mk_drop(e, 1, i, 3);
+    P5_TRY(launch_attn_fwd<T>(a, s));
+    P5_TRY(linear_fwd<T>(s, l.o_ca, in, Wc<T>(e, lo.ca.o), l.x_ff, d, Md, d, in, P5_EPI_RESID_DROP, l.x_ca, d, 1.f, 0, mk_drop(e, 1, i, 4)));
+    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, Md, 1, i));
+  }
+  P5_TRY(rmsnorm_fwd<T>(s, e->dec_hn, e->dec_rstd_f, e->dec_xf, e->P + e->off_dec_fln, Md, d, c.eps, mk_drop(e, 1, 0, 7)));
+  // tied head, d^-0.5 rescale folded into alpha (P5_T5.py:352-361)
+  const float alpha = 1.0f / sqrtf((float)d);
+  P5_TRY(linear_fwd<T>(s, e->dec_hn, d, Wc<T>(e, e->off_E), e->logits, e->Vp, Md, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, alpha, 1));
+  return 0;
+}
+
+template <class T>
+static int forward_impl(P5Engine* e, float* nll_out, hipStream_t s) {
+  P5_TRY(encoder_fwd<T>(e, s));
+  P5_TRY(decoder_fwd<T>(e, s));
+  P5_LAUNCH(p5_ce_fwd_kernel, dim3(e->Md), dim3(256), 0, s, nll_out, e->lse_tok, (const float*)e->logits, e->labels, e->c.vocab_size, e->Vp);
+  return P5_KCHECK();
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+template <class T>
+static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int stack, int li) {
+  // in: e->dy = masked grad wrt the wo output (T), e->dres_cur = grad wrt the sub-layer output (fp32)
+  const P5Config& c = e->c;
+  const int d = c.d_model, F = c.d_ff;
+  const float hscale = (e->training && c.dropout > 0.f) ? 1.f / (1.f - c.dropout) : 1.f;
+  P5_TRY(linear_wgrad<T>(s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
+  if (c.gated_gelu) {
+    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F));
+    const size_t n = (size_t)rows * F;
+    P5_LAUNCH((p5_gated_gelu_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
+              (T*)e->du, (const T*)e->dh, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
+    P5_TRY(P5_KCHECK());
+    P5_TRY(linear_wgrad<T>(s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
+    P5_TRY(linear_dgrad<T>(s, e->du, 2 * F, Wc<T>(e, lo.wi), e->dn, d, rows, 2 * F, d));
+  } else {
+    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F, P5_EPI_MASK_POS, l.h_ff, F, hscale));
+    P5_TRY(linear_wgrad<T>(s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
+    P5_TRY(linear_dgrad<T>(s, e->dh, F, Wc<T>(e, lo.wi), e->dn, d, rows, F, d));
+  }
+  return 0;
+}
+
+template <class T>
+static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_off, const float* rstd, int rows, P5Drop din, P5Drop dnext,
+                         bool has_res_in = true) {
+  float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
+  P5_TRY(rmsnorm_bwd<T>(s, out, e->dy, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows,
+                        e->c.d_model, din, dnext));
+  e->dres_cur = out;
+  return 0;
+}
+
+template <class T>
+static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int Lq, bool is_dec, int li) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads;
+  P5_TRY(linear_wgrad<T>(s, e->dy, d, l.o_sa, in, e->G + lo.sa.o, rows, d, in));
+  P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.sa.o), e->dO, in, rows, d, in));
+  P5AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa; a.dO = e->dO;
+  a.dQ = e->dqkv; a.dK = (T*)e->dqkv + in; a.dV = (T*)e->dqkv + 2 * in; a.Dvec = e->Dvec;
+  a.rel_table = e->P + (is_dec ? e->off_dec_rel : e->off_enc_rel);
+  a.d_rel_table = e->G + (is_dec ? e->off_dec_rel : e->off_enc_rel);
+  a.bucket_lut = is_dec ? e->lut_dec : e->lut_enc; a.lut_half = e->lut_half; a.kmask = is_dec ? nullptr : e->mask;
+  a.B = e->B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.lddo = in;
+  a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
+  a.drop = mk_drop(e, is_dec ? 1 : 0, li, 1);
+  P5_TRY(launch_attn_bwd<T>(a, s));
+  P5_TRY(linear_wgrad<T>(s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
+  P5_TRY(linear_dgrad<T>(s, e->dqkv, 3 * in, Wc<T>(e, lo.sa.q), e->dn, d, rows, 3 * in, d));
+  return 0;
+}
+
+template <class T>
+static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
+  const int nd = c.n_dec_layers, ne = c.n_enc_layers;
+  if (stage == 0) {
+    hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);
+    e->d_enc_started = false;
+    P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
+              e->labels, dnll, c.vocab_size, e->Vp, e->Vp);
+    P5_TRY(P5_KCHECK());
+    const float alpha = 1.0f / sqrtf((float)d);
+    // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
+    P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 1, e->dec_hn, d, 1, e->G + e->off_E, d, c.vocab_size, d, Md, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+    P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dn, d, Md, d, c.vocab_size, P5_EPI_STORE, nullptr, 0, alpha, 0, no_drop()));
+    e->dres_cur = e->dres_a;
+    P5_TRY(swap_norm_bwd<T>(e, s, e->dec_xf, e->off_dec_fln, e->dec_rstd_f, Md, mk_drop(e, 1, 0, 7), mk_drop(e, 1, nd - 1, 6), false));
+    return 0;
+  }
+  if (stage >= 1 && stage <= nd) {
+    const int i = nd - stage;
+    const LayerOff& lo = e->dec[i];
+    LayerSave& l = e->ds[i];
+    P5_TRY(ffn_bwd<T>(e, s, lo, l, Md, 1, i));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4)));
+    // cross attention
+    P5_TRY(linear_wgrad<T>(s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
+    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.ca.o), e->dO, in, Md, d, in));
+    P5AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca; a.dO = e->dO;
+    a.dQ = e->dqkv; a.dK = e->dkv; a.dV = (T*)e->dkv + in; a.Dvec = e->Dvec;
+    a.kmask = e->mask; a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = 2 * in; a.ldo = in; a.lddo = in;
+    a.lddq = in; a.lddk = a.lddv = 2 * in; a.causal = 0; a.drop = mk_drop(e, 1, i, 3);
+    P5_TRY(launch_attn_bwd<T>(a, s));
+    P5_TRY(linear_wgrad<T>(s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
+    P5_TRY(linear_dgrad<T>(s, e->dqkv, in, Wc<T>(e, lo.ca.q), e->dn, d, Md, in, d));
+    P5_TRY(linear_wgrad<T>(s, e->dkv, 2 * in, e->enc_out, d, e->G + lo.ca.k, M, 2 * in, d));
+    P5_TRY(linear_dgrad<T>(s, e->dkv, 2 * in, Wc<T>(e, lo.ca.k), e->d_enc, d, M, 2 * in, d,
+                           e->d_enc_started ? P5_EPI_ACCUM : P5_EPI_STORE, nullptr, 0, 1.f, 1));
+    e->d_enc_started = true;
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
+    // self attention
+    P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
+    return 0;
+  }
+  if (stage == nd + 1) {
+    P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, e->G + e->off_E, (float*)nullptr, (const float*)e->dres_cur,
+              (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
+    return P5_KCHECK();
+  }
+  if (stage == nd + 2) {
+    const size_t n = (size_t)M * d;
+    P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
+              (const float*)e->d_enc, n, no_drop());
+    P5_TRY(P5_KCHECK());
+    e->dres_cur = e->dres_a;
+    P5_TRY(swap_norm_bwd<T>(e, s, e->enc_xf, e->off_enc_fln, e->enc_rstd_f, M, mk_drop(e, 0, 0, 7), mk_drop(e, 0, ne - 1, 6), false));
+    return 0;
+  }
+  if (stage >= nd + 3 && stage <= nd + 2 + ne) {
+    const int i = ne - (stage - (nd + 2));
+    const LayerOff& lo = e->enc[i];
+    LayerSave& l = e->es[i];
+    P5_TRY(ffn_bwd<T>(e, s, lo, l, M, 0, i));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2)));
+    P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
+    return 0;
+  }
+  if (stage == nd + ne + 3) {
+    P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, e->G + e->off_E, e->G + e->off_WW, (const float*)e->dres_cur,
+              e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
+    return P5_KCHECK();
+  }
+  return fail("backward: bad stage");
+}
+
+// ---- generation ------------------------------------------------------------------------------------------
+struct GenWs {
+  void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
+  void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
+  void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
+  float *logits, *cand; int* n_cand;
+  P5BeamState st;
+};
+
+static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_len, int max_c, GenWs* g) {
+  const P5Config& c = e->c;
+  const size_t sz = c.dtype == 1 ? 2 : 4;
+  const int d = c.d_model, in = e->inner, F = c.d_ff;
+  const size_t R = (size_t)B * K;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  const int64_t enc_bytes = layout_ws(e, base, B, L, 0, false);
+  Bump b{base, (size_t)enc_bytes};
+  GenWs tmp;
+  GenWs& w = g ? *g : tmp;
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    w.kv_cross[i] = b.take((size_t)B * L * 2 * in * sz);
+    w.cache[i] = b.take((size_t)max_len * R * 2 * in * sz);
+  }
+  w.xa = b.take(R * d * sz); w.xb = b.take(R * d * sz); w.n = b.take(R * d * sz);
+  w.qkv = b.take(R * 3 * in * sz); w.q = b.take(R * in * sz); w.o = b.take(R * in * sz);
+  w.h = b.take(R * (c.gated_gelu ? 3 : 1) * F * sz); w.hn = b.take(R * d * sz);
+  w.logits = (float*)b.take(R * Vp * 4);
+  w.cand = (float*)b.take(R * (size_t)max_c * 4);
+  w.n_cand = (int*)b.take(R * 4);
+  P5BeamState& st = w.st;
+  st.run_seq = (int*)b.take(R * max_len * 4); st.run_seq_next = (int*)b.take(R * max_len * 4);
+  st.fin_seq = (int*)b.take(R * max_len * 4); st.fin_seq_next = (int*)b.take(R * max_len * 4);
+  st.anc = (int*)b.take(R * max_len * 4); st.anc_next = (int*)b.take(R * max_len * 4);
+  st.run_score = (float*)b.take(R * 4); st.run_node = (int*)b.take(R * 4);
+  st.fin_score = (float*)b.take(R * 4); st.fin_flag = (int*)b.take(R * 4); st.fin_len = (int*)b.take(R * 4);
+  st.unsat = (int*)b.take((size_t)B * 4);
+  st.last_tok = (int64_t*)b.take(R * 8);
+  st.flags = (int*)b.take(64);
+  return (int64_t)((b.off + 255) & ~(size_t)255);
+}
+
+template <class T>
+static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int pos, int max_len, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, R = B * K;
+  P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.xa, Wc<T>(e, e->off_E), (const T*)nullptr,
+            (const int64_t*)w.st.last_tok, (const int64_t*)nullptr, R, d, no_drop());
+  P5_TRY(P5_KCHECK());
+  void* x = w.xa; void* y = w.xb;
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const LayerOff& lo = e->dec[i];
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.sa.ln, R, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.sa.q), w.qkv, 3 * in, R, 3 * in, d));
+    P5_LAUNCH((p5_dec_self_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i],
+              (const int*)w.st.anc, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, pos, max_len);
+    P5_TRY(P5_KCHECK());
+    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.sa.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ca.ln, R, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.ca.q), w.q, in, R, in, d));
+    P5_LAUNCH((p5_dec_cross_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.q, (const T*)w.kv_cross[i],
+              e->mask, R, H, K, L);
+    P5_TRY(P5_KCHECK());
+    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.ca.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ff_ln, R, d, c.eps, no_drop()));
+    if (c.gated_gelu) {
+      T* u = (T*)w.h + (size_t)R * F;
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), u, 2 * F, R, 2 * F, d));
+      const size_t n = (size_t)R * F;
+      P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (T*)w.h, (const T*)u, R, F, no_drop());
+      P5_TRY(P5_KCHECK());
+    } else {
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), w.h, F, R, F, d, P5_EPI_RELU_DROP));
+    }
+    P5_TRY(linear_fwd<T>(s, w.h, F, Wc<T>(e, lo.wo), y, d, R, d, F, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+  }
+  P5_TRY(rmsnorm_fwd<T>(s, w.hn, nullptr, x, e->P + e->off_dec_fln, R, d, c.eps, no_drop()));
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, 1.0f / sqrtf((float)d), 1);
+}
+
+template <class T>
+static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                         const int* roots, int max_c, int* out_seq, float* out_score, int* out_len, char* ws, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, R = B * K;
+  GenWs w;
+  layout_gen(e, ws, B, L, K, max_len, max_c, &w);
+  e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
+  P5_TRY(encoder_fwd<T>(e, s));
+  for (int i = 0; i < c.n_dec_layers; ++i)
+    P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, e->dec[i].ca.k), w.kv_cross[i], 2 * in, B * L, 2 * in, d));
+  P5_LAUNCH(p5_beam_init_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, child_off, child_tok, child_node, roots, B, K, max_len,
+            c.pad_id);
+  P5_TRY(P5_KCHECK());
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
+    P5_TRY(decode_step<T>(e, w, B, L, K, cur_len - 1, max_len, s));
+    P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.n_cand, (const float*)w.logits, Vp, c.vocab_size,
+              (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, max_c);
+    P5_TRY(P5_KCHECK());
+    hipMemsetAsync(w.st.flags, 0, 8, s);
+    P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, w.cand, (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K,
+              max_len, cur_len, c.eos_id, R);
+    P5_TRY(P5_KCHECK());
+    std::swap(w.st.run_seq, w.st.run_seq_next);
+    std::swap(w.st.fin_seq, w.st.fin_seq_next);
+    std::swap(w.st.anc, w.st.anc_next);
+    int flags[2] = {1, 1};
+    hipMemcpyAsync(flags, w.st.flags, 8, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    if (!(flags[0] > 0 && flags[1] > 0)) break;   // HF utils.py:3055-3075
+  }
+  hipMemcpyAsync(out_seq, w.st.fin_seq, (size_t)R * max_len * 4, hipMemcpyDeviceToDevice, s);
+  hipMemcpyAsync(out_score, w.st.fin_score, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
+  hipMemcpyAsync(out_len, w.st.fin_len, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
+  return 0;
+}
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* p5_last_error(void) { return g_err.c_str(); }
+int p5_abi_version(void) { return 1; }
+int p5_is_emulator(void) {
+#ifdef P5_EMU
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int p5_engine_create(const P5Config* cfg, P5Engine** out) {
+  P5_REQUIRE(cfg && out, "null argument");
+  P5_REQUIRE(cfg->d_kv == 64, "d_kv must be 64 (every T5 checkpoint)");
+  P5_REQUIRE(cfg->d_model % 64 == 0 && cfg->d_model <= 1024, "d_model must be a multiple of 64, <= 1024");
+  P5_REQUIRE(cfg->d_ff % 64 == 0, "d_ff must be a multiple of 64");
+  P5_REQUIRE(cfg->n_enc_layers >= 1 && cfg->n_enc_layers <= 64 && cfg->n_dec_layers >= 1 && cfg->n_dec_layers <= 64, "layer count");
+  P5_REQUIRE(cfg->dtype == 0 || cfg->dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  P5Engine* e = new P5Engine();
+  e->c = *cfg;
+  e->inner = cfg->n_heads * cfg->d_kv;
+  build_layout(e);
+  *out = e;
+  return 0;
+}
+int p5_engine_destroy(P5Engine* e) { delete e; return 0; }
+int64_t p5_param_count(const P5Engine* e) { return e->n_params; }
+int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols) {
+  if (idx < 0 || idx >= (int)e->table.size()) return 1;
+  const ParamInfo& p = e->table[idx];
+  snprintf(name, name_cap, "%s", p.name.c_str());
+  *offset = p.off; *rows = p.rows; *cols = p.cols;
+  return 0;
+}
+int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const int* lut_enc, const int* lut_dec, int lut_half,
+                   uint32_t* rng_state) {
+  P5_REQUIRE(params && lut_enc && lut_dec, "null argument");
+  P5_REQUIRE(e->c.dtype == 0 || shadow, "bf16 mode needs a shadow arena");
+  P5_REQUIRE(lut_half >= 511, "bucket LUT must cover |rel| <= 511");
+  e->P = params; e->G = grads; e->S = shadow; e->lut_enc = lut_enc; e->lut_dec = lut_dec; e->lut_half = lut_half; e->rng = rng_state;
+  return 0;
+}
+int p5_refresh_shadow(P5Engine* e, void* stream) {
+  if (e->c.dtype != 1) return 0;
+  const size_t n = (size_t)e->n_params;
+  P5_LAUNCH((p5_cast_kernel<bf16>), dim3(2048), dim3(256), 0, (hipStream_t)stream, (bf16*)e->S, (const float*)e->P, n);
+  return P5_KCHECK();
+}
+
+int64_t p5_train_workspace_bytes(const P5Engine* e, int B, int L, int T) {
+  P5Engine tmp = *e;
+  return layout_ws(&tmp, nullptr, B, L, T, true);
+}
+
+int p5_forward(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, const int64_t* labels,
+               int B, int L, int T, int training, float* nll_out, void* ws, int64_t ws_bytes, void* stream) {
+  P5_REQUIRE(e->P, "engine not bound");
+  P5_REQUIRE(B >= 1 && L >= 1 && L <= 512 && T >= 1 && T <= 512, "shape limits: 1 <= L,T <= 512");
+  const int64_t need = layout_ws(e, (char*)ws, B, L, T, true);
+  P5_REQUIRE(ws_bytes >= need, "workspace too small");
+  P5_REQUIRE(((uintptr_t)ws % 256) == 0, "workspace must be 256-byte aligned");
+  e->B = B; e->L = L; e->T = T; e->M = B * L; e->Md = B * T; e->training = training;
+  e->Vp = (e->c.vocab_size + 63) / 64 * 64;
+  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = labels;
+  if (training && e->c.dropout > 0.f) P5_REQUIRE(e->rng, "training with dropout needs rng_state");
+  return e->c.dtype == 1 ? forward_impl<bf16>(e, nll_out, (hipStream_t)stream) : forward_impl<float>(e, nll_out, (hipStream_t)stream);
+}
+int p5_backward_num_stages(const P5Engine* e) { return e->c.n_dec_layers + e->c.n_enc_layers + 4; }
+int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
+  P5_REQUIRE(e->G, "no gradient arena bound");
+  P5_REQUIRE(e->Md > 0, "p5_forward must run first");
+  return e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
+                         : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream);
+}
+int p5_backward(P5Engine* e, const float* dnll, void* stream) {
+  const int n = p5_backward_num_stages(e);
+  for (int s = 0; s < n; ++s) P5_TRY(p5_backward_stage(e, dnll, s, stream));
+  return 0;
+}
+int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end) {
+  const int nd = e->c.n_dec_layers, ne = e->c.n_enc_layers;
+  *begin = *end = 0;
+  if (stage == 0) { *begin = e->off_dec_fln; *end = e->n_params; }
+  else if (stage >= 1 && stage <= nd) { *begin = e->dec[nd - stage].begin; *end = e->dec[nd - stage].end; }
+  else if (stage == nd + 2) { *begin = e->off_enc_fln; *end = e->dec[0].begin; }
+  else if (stage >= nd + 3 && stage <= nd + 2 + ne) { const int i = ne - (stage - (nd + 2)); *begin = e->enc[i].begin; *end = e->enc[i].end; }
+  else if (stage == nd + ne + 3) { *begin = 0; *end = e->off_small_end; }
+  return 0;
+}
+
+int p5_grad_sumsq(const float* grads, int64_t n, float* out_scalar, void* stream) {
+  P5_LAUNCH(p5_sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out_scalar, grads, (size_t)n);
+  return P5_KCHECK();
+}
+int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq, float max_norm,
+                  float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step_t, void* stream) {
+  P5AdamArgs a;
+  a.p = params; a.g = grads; a.m = m; a.v = v; a.shadow = shadow_bf16; a.sumsq = sumsq; a.n = (size_t)n;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm; a.grad_scale = grad_scale;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step_t));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step_t));
+  P5_LAUNCH(p5_adamw_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
+  return P5_KCHECK();
+}
+
+int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children) {
+  P5Engine tmp = *e;
+  return layout_gen(&tmp, nullptr, B, L, K, max_len, max_children, nullptr);
+}
+int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
+                int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots, int max_children,
+                int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
+  P5_REQUIRE(e->P, "engine not bound");
+  P5_REQUIRE(K >= 1 && K <= 64, "1 <= num_beams <= 64");
+  P5_REQUIRE(max_len >= 2 && max_len <= 64, "2 <= max_length <= 64");
+  P5_REQUIRE(L >= 1 && L <= 512, "1 <= L <= 512");
+  P5_REQUIRE(max_children >= 1, "max_children");
+  P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");
+  const int64_t need = layout_gen(e, nullptr, B, L, K, max_len, max_children, nullptr);
+  P5_REQUIRE(ws_bytes >= need, "workspace too small");
+  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
+  return e->c.dtype == 1
+             ? generate_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, max_children, out_seq, out_score, out_len, (char*)ws,
+                                   (hipStream_t)stream)
+             : generate_impl<float>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, max_children, out_seq, out_score, out_len,
+                                    (char*)ws, (hipStream_t)stream);
+}
+int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L,
+              void* enc_out, void* ws, int64_t ws_bytes, void* stream) {
+  P5_REQUIRE(e->P, "engine not bound");
+  const int64_t need = layout_ws(e, (char*)ws, B, L, 0, false);
+  P5_REQUIRE(ws_bytes >= need, "workspace too small");
+  e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
+  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask;
+  P5_TRY(e->c.dtype == 1 ? encoder_fwd<bf16>(e, (hipStream_t)stream) : encoder_fwd<float>(e, (hipStream_t)stream));
+  const size_t bytes = (size_t)B * L * e->c.d_model * (e->c.dtype == 1 ? 2 : 4);
+  hipMemcpyAsync(enc_out, e->enc_out, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return 0;
+}
+
+// ---- per-kernel entry points ---------------------------------------------------------------------------
+static P5Drop op_drop(const uint32_t* state, uint32_t site, float p) {
+  P5Drop d = no_drop();
+  if (state && p > 0.f) { d.state = state; d.site_key = p5_site_key(site); d.thr = p5_drop_thr(p); d.scale = 1.f / (1.f - p); }
+  return d;
+}
+int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+               int a_ks, int b_ks, int epi, int c_f32, int splitk, float alpha, const uint32_t* rng_state, uint32_t site, float drop_p,
+               void* stream) {
+  P5GemmArgs g;
+  g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+  g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
+  return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
+}
+int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream) {
+  return dtype == 1 ? rmsnorm_fwd<bf16>((hipStream_t)stream, y, rstd, x, w, rows, d, eps, no_drop())
+                    : rmsnorm_fwd<float>((hipStream_t)stream, y, rstd, x, w, rows, d, eps, no_drop());
+}
+int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w, const float* rstd,
+                      const float* dres_in, int rows, int d, void* stream) {
+  return dtype == 1 ? rmsnorm_bwd<bf16>((hipStream_t)stream, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop())
+                    : rmsnorm_bwd<float>((hipStream_t)stream, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop());
+}
+int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table, const int* lut,
+                   int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int causal,
+                   const uint32_t* rng_state, uint32_t site, float drop_p, void* stream) {
+  P5AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.lse = lse; a.rel_table = rel_table; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.causal = causal;
+  a.drop = op_drop(rng_state, site, drop_p);
+  return dtype == 1 ? launch_attn_fwd<bf16>(a, (hipStream_t)stream) : launch_attn_fwd<float>(a, (hipStream_t)stream);
+}
+int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, float* Dvec,
+                   void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, const int* lut, int lut_half,
+                   const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                   int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream) {
+  P5AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = Q; a.K = K; a.V = V; a.O = (void*)O; a.dO = dO; a.lse = (float*)lse; a.Dvec = Dvec; a.dQ = dQ; a.dK = dK; a.dV = dV;
+  a.rel_table = rel_table; a.d_rel_table = d_rel_table; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
+  a.lddv = lddv; a.causal = causal; a.drop = op_drop(rng_state, site, drop_p);
+  return dtype == 1 ? launch_attn_bwd<bf16>(a, (hipStream_t)stream) : launch_attn_bwd<float>(a, (hipStream_t)stream);
+}
+int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream) {
+  P5_LAUNCH(p5_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, nll, lse, logits, labels, V, ldl);
+  return P5_KCHECK();
+}
+int p5_op_tr_probe(void* out, const void* in, void* stream) {
+  P5_LAUNCH(p5_tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned short*)out, (const unsigned short*)in);
+  return P5_KCHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+"""`P5T5Native` -- drop-in for OpenP5's `P5_T5` model object (/root/reference/src/src_t5/model/P5_T5.py:207)
+backed by the HIP engine in libp5hip.so.
+
+It satisfies exactly the uses the reference's launcher/runner make of the model:
+  * `forward(input_ids, whole_word_ids, attention_mask, labels, alpha=..., return_dict=True)["loss"]` is the flat
+    [B*T] fp32 per-token NLL (P5_T5.py:368-369, consumed at DistributedRunner.py:63-77), differentiable;
+  * `generate(input_ids, attention_mask, whole_word_ids, max_length, prefix_allowed_tokens_fn, num_beams,
+    num_return_sequences, output_scores, return_dict_in_generate)` -> {"sequences", "sequences_scores"}
+    (DistributedRunner.py:361-374);
+  * `nn.Module` protocol with HF T5 state-dict keys incl. the duplicated tied keys;
+    `shared.weight` is the single tied [V, d] tensor, writable in place (utils/initialization.py:27-29);
+  * `resize_token_embeddings(n)` (main.py:193), `.train()/.eval()/.zero_grad()/.parameters()`.
+
+All parameters are views into ONE flat fp32 arena (and all gradients views into a second arena of the same
+layout), which is what lets clip + AdamW be two flat kernels and the data-parallel all-reduce a handful of
+contiguous buckets issued while the backward is still running.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .trie import CompiledTrie, Trie, find_trie
+
+
+@dataclass
+class P5ModelConfig:
+    """The T5Config fields the path reads (HF configuration_t5.py:44-62 defaults = t5-small)."""
+    vocab_size: int = 32128
+    d_model: int = 512
+    d_kv: int = 64
+    d_ff: int = 2048
+    num_layers: int = 6
+    num_decoder_layers: Optional[int] = None
+    num_heads: int = 8
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    dropout_rate: float = 0.1
+    layer_norm_epsilon: float = 1e-6
+    feed_forward_proj: str = "relu"
+    whole_word_size: int = 512           # P5_T5.py:64
+    pad_token_id: int = 0
+    eos_token_id: int = 1
+    decoder_start_token_id: int = 0
+
+    @staticmethod
+    def from_backbone(name: str, **kw) -> "P5ModelConfig":
+        presets = {
+            "t5-small": dict(d_model=512, d_ff=2048, num_heads=8, num_layers=6),
+            "t5-base": dict(d_model=768, d_ff=3072, num_heads=12, num_layers=12),
+            "t5-large": dict(d_model=1024, d_ff=4096, num_heads=16, num_layers=24),
+        }
+        key = name.split("/")[-1]
+        if key not in presets:
+            raise ValueError(f"unknown backbone {name!r} (known: {sorted(presets)})")
+        d = dict(presets[key])
+        d.update(kw)
+        return P5ModelConfig(**d)
+
+    @staticmethod
+    def from_hf(cfg) -> "P5ModelConfig":
+        g = lambda k, dflt=None: getattr(cfg, k, dflt)
+        return P5ModelConfig(
+            vocab_size=g("vocab_size"), d_model=g("d_model"), d_kv=g("d_kv"), d_ff=g("d_ff"), num_layers=g("num_layers"),
+            num_decoder_layers=g("num_decoder_layers"), num_heads=g("num_heads"),
+            relative_attention_num_buckets=g("relative_attention_num_buckets", 32),
+            relative_attention_max_distance=g("relative_attention_max_distance", 128),
+            dropout_rate=g("dropout_rate", 0.1), layer_norm_epsilon=g("layer_norm_epsilon", 1e-6),
+            feed_forward_proj=g("feed_forward_proj", "relu"), pad_token_id=g("pad_token_id", 0) or 0,
+            eos_token_id=g("eos_token_id", 1), decoder_start_token_id=g("decoder_start_token_id", 0) or 0)
+
+
+def relative_position_bucket_lut(half: int, bidirectional: bool, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """bucket(rel) for rel = key_pos - query_pos in [-half, half]; same op sequence (fp32 log, truncation) as
+    HF modeling_t5.py:217-262 so the table is bit-identical to what T5Attention.compute_bias indexes with."""
+    rel = torch.arange(-half, half + 1, dtype=torch.long)
+    ret = torch.zeros_like(rel)
+    nb = num_buckets
+    if bidirectional:
+        nb //= 2
+        ret = ret + (rel > 0).to(torch.long) * nb
+        rel = torch.abs(rel)
+    else:
+        rel = -torch.min(rel, torch.zeros_like(rel))
+    max_exact = nb // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return (ret + torch.where(is_small, rel, large)).to(torch.int32)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _P5LossFn(torch.autograd.Function):
+    """autograd seam: forward = p5_forward (activations stay in the engine workspace), backward = p5_backward
+    writing straight into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, whole_word_ids, attention_mask, labels):
+        ctx.model = model
+        return model._engine_forward(input_ids, whole_word_ids, attention_mask, labels)
+
+    @staticmethod
+    def backward(ctx, dnll):
+        ctx.model._engine_backward(dnll)
+        return None, None, None, None, None, None
+
+
+class P5T5Native(nn.Module):
+    LUT_HALF = 512
+
+    def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
+        super().__init__()
+        if not isinstance(config, P5ModelConfig):
+            config = P5ModelConfig.from_hf(config)
+        if config.num_decoder_layers is None:
+            config.num_decoder_layers = config.num_layers
+        self.config = config
+        if backend is None:
+            from ._lib import hip_backend
+            backend = hip_backend(device)
+        self._be = backend
+        self._lib = backend.lib
+        self.compute_dtype = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0}[str(dtype).replace("torch.", "")]
+        self._engine = ctypes.c_void_p()
+        self._ws = None
+        self._gen_ws = None
+        self._anchor = torch.zeros(1, device=backend.device, requires_grad=True)
+        self.ddp_world = 1          # set by the runner: gradient all-reduce across ranks during backward
+        self.ddp_group = None
+        self._pending = []
+        self._build(seed)
+
+    # ------------------------------------------------------------------ engine / arena plumbing
+    def _cfg_struct(self):
+        c = self.config
+        ff = c.feed_forward_proj
+        if ff not in ("relu", "gated-gelu"):
+            raise ValueError(f"feed_forward_proj={ff!r} not supported (relu | gated-gelu)")
+        return _abi.P5Config(
+            vocab_size=c.vocab_size, d_model=c.d_model, d_kv=c.d_kv, d_ff=c.d_ff, n_enc_layers=c.num_layers,
+            n_dec_layers=c.num_decoder_layers, n_heads=c.num_heads, rel_buckets=c.relative_attention_num_buckets,
+            rel_max_distance=c.relative_attention_max_distance, whole_word_size=c.whole_word_size,
+            gated_gelu=1 if ff == "gated-gelu" else 0, dtype=self.compute_dtype, eps=c.layer_norm_epsilon,
+            dropout=c.dropout_rate, pad_id=c.pad_token_id, eos_id=c.eos_token_id)
+
+    def _create_engine(self):
+        if self._engine:
+            self._lib.p5_engine_destroy(self._engine)
+        self._engine = ctypes.c_void_p()
+        cfg = self._cfg_struct()
+        self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine)), "p5_engine_create")
+        table = []
+        name = ctypes.create_string_buffer(256)
+        off, rows, cols = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+        i = 0
+        while self._lib.p5_param_table(self._engine, i, name, 256, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols)) == 0:
+            table.append((name.value.decode(), off.value, rows.value, cols.value))
+            i += 1
+        self._table = table
+        self._n = int(self._lib.p5_param_count(self._engine))
+
+    def _build(self, seed, old_state: Optional[Dict[str, torch.Tensor]] = None):
+        dev = self._be.device
+        self._create_engine()
+        self._flat = torch.zeros(self._n, dtype=torch.float32, device=dev)
+        self._grads = torch.zeros(self._n, dtype=torch.float32, device=dev)
+        self._shadow = torch.zeros(self._n, dtype=torch.bfloat16, device=dev) if self.compute_dtype == 1 else None
+        c = self.config
+        self._lut_enc = relative_position_bucket_lut(self.LUT_HALF, True, c.relative_attention_num_buckets, c.relative_attention_max_distance).to(dev)
+        self._lut_dec = relative_position_bucket_lut(self.LUT_HALF, False, c.relative_attention_num_buckets, c.relative_attention_max_distance).to(dev)
+        self._rng_cpu = [int(seed) & 0xFFFFFFFF, 0]
+        self._rng = torch.tensor(self._rng_cpu, dtype=torch.int64, device=dev).to(torch.int32)
+        # drop any previous parameter modules, then (re)register views with HF names
+        for k in list(self._modules.keys()):
+            del self._modules[k]
+        self._views = {}
+        for name, off, rows, cols in self._table:
+            shape = (cols,) if name.endswith("layer_norm.weight") else (rows, cols)
+            view = self._flat[off:off + rows * cols].view(shape)
+            p = nn.Parameter(view, requires_grad=True)
+            self._register_dotted(name, p)
+            self._views[name] = (off, rows * cols, shape)
+        self._init_weights(seed)
+        if old_state is not None:
+            self._copy_in(old_state, strict=False)
+        self._bind()
+        self._shadow_dirty = True
+
+    def _register_dotted(self, name, p):
+        parts = name.split(".")
+        mod = self
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, nn.Module())
+            mod = mod._modules[part]
+        mod.register_parameter(parts[-1], p)
+
+    def _bind(self):
+        self._be.check(self._lib.p5_engine_bind(self._engine, _ptr(self._flat), _ptr(self._grads), _ptr(self._shadow), _ptr(self._lut_enc),
+                                                 _ptr(self._lut_dec), self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind")
+
+    @torch.no_grad()
+    def _init_weights(self, seed):
+        """HF `_init_weights` std's (modeling_t5.py:563-616, factor 1.0); whole-word table N(0,1) (P5_T5.py:64-67)."""
+        g = torch.Generator().manual_seed(int(seed))
+        c = self.config
+        d, dk, H, F = c.d_model, c.d_kv, c.num_heads, c.d_ff
+        for name, p in self.named_parameters():
+            if name.endswith("layer_norm.weight"):
+                p.fill_(1.0)
+                continue
+            if name in ("shared.weight", "encoder.whole_word_embeddings.weight"):
+                std = 1.0
+            elif name.endswith(".q.weight"):
+                std = (d * dk) ** -0.5
+            elif name.endswith(".k.weight") or name.endswith(".v.weight"):
+                std = d ** -0.5
+            elif name.endswith(".o.weight"):
+                std = (H * dk) ** -0.5
+            elif ".wi" in name:
+                std = d ** -0.5
+            elif name.endswith(".wo.weight"):
+                std = F ** -0.5
+            else:
+                std = d ** -0.5
+            p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+
+    def _sync_shadow(self):
+        if self.compute_dtype == 1 and self._shadow_dirty:
+            self._be.check(self._lib.p5_refresh_shadow(self._engine, self._be.stream_ptr()), "p5_refresh_shadow")
+        self._shadow_dirty = False
+
+    def mark_params_updated(self, shadow_fresh: bool = False):
+        """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
+        self._shadow_dirty = not shadow_fresh
+
+    # ------------------------------------------------------------------ nn.Module protocol
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self._flat.device))
+        if probe.device != self._flat.device:
+            if not self._be.is_emulator and probe.device.type != "cuda":
+                raise RuntimeError("P5T5Native lives on the HIP device; there is no CPU path")
+            if probe.device != self._be.device:
+                raise RuntimeError(f"P5T5Native was built for {self._be.device}; build it with device={probe.device} instead")
+        if probe.dtype != torch.float32:
+            raise RuntimeError("master parameters are fp32; choose the compute dtype with dtype='bf16'|'fp32'")
+        return self
+
+    TIED = ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight")
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        shared = sd[prefix + "shared.weight"]
+        for k in self.TIED:
+            sd[prefix + k] = shared
+        return sd
+
+    @torch.no_grad()
+    def _copy_in(self, state_dict, strict):
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in state_dict]
+        unexpected = []
+        for k, v in state_dict.items():
+            if k in own:
+                if tuple(own[k].shape) != tuple(v.shape):
+                    if k in ("shared.weight",) and v.shape[1] == own[k].shape[1]:
+                        n = min(v.shape[0], own[k].shape[0])
+                        own[k][:n].copy_(v[:n].to(own[k].device, torch.float32))
+                        continue
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(own[k].shape)}")
+                own[k].copy_(v.to(own[k].device, torch.float32))
+            elif k in self.TIED or k == "decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight":
+                continue   # tied duplicates / key ignored on load (P5_T5.py:213-215)
+            else:
+                unexpected.append(k)
+        if "shared.weight" not in state_dict:
+            for k in self.TIED:
+                if k in state_dict:
+                    own["shared.weight"].copy_(state_dict[k].to(own["shared.weight"].device, torch.float32))
+                    missing = [m for m in missing if m != "shared.weight"]
+                    break
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing={missing} unexpected={unexpected}")
+        self._shadow_dirty = True
+        return missing, unexpected
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        missing, unexpected = self._copy_in(state_dict, strict)
+        from torch.nn.modules.module import _IncompatibleKeys
+        return _IncompatibleKeys(missing, unexpected)
+
+    @classmethod
+    def from_pretrained(cls, backbone, config=None, state_dict=None, **kw):
+        """`P5_T5.from_pretrained(args.backbone, config=config)` (main.py:176,184).  Weights come from `state_dict`
+        or from a local HF checkpoint directory/file (`pytorch_model.bin` / `model.safetensors`); with neither (no
+        network in this environment) the HF `_init_weights` distribution is used.  A missing
+        `encoder.whole_word_embeddings.weight` keeps its fresh N(0,1) init, as in the reference."""
+        import os
+        if config is None:
+            config = P5ModelConfig.from_backbone(str(backbone))
+        model = cls(config, **kw)
+        sd = state_dict
+        if sd is None and isinstance(backbone, str) and os.path.exists(backbone):
+            path = backbone
+            if os.path.isdir(path):
+                for cand in ("model.safetensors", "pytorch_model.bin"):
+                    if os.path.exists(os.path.join(path, cand)):
+                        path = os.path.join(path, cand)
+                        break
+            if path.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd = load_file(path)
+            elif os.path.isfile(path):
+                sd = torch.load(path, map_location="cpu")
+        if sd is not None:
+            model.load_state_dict(sd, strict=False)
+        return model
+
+    @torch.no_grad()
+    def resize_token_embeddings(self, new_num_tokens: int):
+        """main.py:193: keep the old rows, new rows ~ N(0, 1) (HF `_init_weights` for the shared table)."""
+        old = self.config.vocab_size
+        if new_num_tokens == old:
+            return self.shared
+        state = {k: v.detach().clone() for k, v in super().state_dict().items()}
+        old_E = state.pop("shared.weight")
+        self.config.vocab_size = int(new_num_tokens)
+        seed = self._rng_cpu[0]
+        self._build(seed)
+        self._copy_in(state, strict=False)
+        n = min(old, new_num_tokens)
+        self.shared.weight[:n].copy_(old_E[:n])
+        self._shadow_dirty = True
+        return self.shared
+
+    def get_input_embeddings(self):
+        return self.shared
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def zero_grad(self, set_to_none: bool = True):
+        # the engine zeroes the gradient arena at the start of every backward; keep the views attached
+        self._grads.zero_()
+
+    def tie_weights(self):
+        return None
+
+    # ------------------------------------------------------------------ RNG for dropout
+    def set_dropout_seed(self, seed: int, step: int = 0):
+        self._rng_cpu = [int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF]
+        self._rng.copy_(torch.tensor(self._rng_cpu, dtype=torch.int64).to(torch.int32))
+
+    # ------------------------------------------------------------------ forward / backward
+    def _workspace(self, nbytes, which="_ws"):
+        cur = getattr(self, which)
+        if cur is None or cur.numel() < nbytes:
+            raw = torch.empty(int(nbytes * 1.05) + 512, dtype=torch.uint8, device=self._be.device)
+            skew = (-raw.data_ptr()) % 256          # the engine wants a 256-byte aligned base
+            cur = raw[skew:skew + int(nbytes * 1.05) + 255]
+            setattr(self, which, cur)
+        return cur
+
+    @staticmethod
+    def _i64(t, device):
+        return t.to(device=device, dtype=torch.int64).contiguous()
+
+    def _engine_forward(self, input_ids, whole_word_ids, attention_mask, labels):
+        dev = self._be.device
+        B, L = input_ids.shape
+        T = labels.shape[1]
+        self._sync_shadow()
+        ws = self._workspace(self._lib.p5_train_workspace_bytes(self._engine, B, L, T))
+        nll = torch.empty(B * T, dtype=torch.float32, device=dev)
+        training = 1 if (self.training and self.config.dropout_rate > 0) else 0
+        if training:
+            self._rng_cpu[1] = (self._rng_cpu[1] + 1) & 0xFFFFFFFF
+            self._rng[1] = self._rng_cpu[1] if self._rng_cpu[1] < 2 ** 31 else self._rng_cpu[1] - 2 ** 32
+        self._saved_inputs = (input_ids, whole_word_ids, attention_mask, labels)   # keep device buffers alive
+        self._be.check(self._lib.p5_forward(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), _ptr(labels), B, L, T,
+                                            training, _ptr(nll), _ptr(ws), ws.numel(), self._be.stream_ptr()), "p5_forward")
+        return nll
+
+    def _engine_backward(self, dnll):
+        dnll = dnll.to(torch.float32).contiguous()
+        lib, eng, sp = self._lib, self._engine, self._be.stream_ptr()
+        if self.ddp_world > 1:
+            import torch.distributed as dist
+            nst = lib.p5_backward_num_stages(eng)
+            b, e = ctypes.c_int64(), ctypes.c_int64()
+            self._pending = []
+            for st in range(nst):
+                self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
+                lib.p5_backward_stage_range(eng, st, ctypes.byref(b), ctypes.byref(e))
+                if e.value > b.value:
+                    self._pending.append(dist.all_reduce(self._grads[b.value:e.value], op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True))
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+        else:
+            self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
+        for name, p in self.named_parameters():
+            if p.grad is None:
+                off, n, shape = self._views[name]
+                p.grad = self._grads[off:off + n].view(shape)
+
+    def forward(self, input_ids=None, whole_word_ids=None, attention_mask=None, labels=None, alpha=None, return_dict=True, **unused):
+        """P5_T5.forward (P5_T5.py:275-386): returns {"loss": flat [B*T] per-token NLL}; `alpha` is accepted and ignored
+        exactly as in the reference (P5_T5.py:294)."""
+        if labels is None:
+            raise ValueError("P5T5Native.forward needs labels (the runner always passes them)")
+        dev = self._be.device
+        input_ids = self._i64(input_ids, dev)
+        if whole_word_ids is None:
+            whole_word_ids = torch.zeros_like(input_ids)
+        whole_word_ids = self._i64(whole_word_ids, dev)
+        if attention_mask is None:
+            attention_mask = (input_ids != self.config.pad_token_id).long()
+        attention_mask = self._i64(attention_mask, dev)
+        labels = self._i64(labels, dev)
+        nll = _P5LossFn.apply(self._anchor, self, input_ids, whole_word_ids, attention_mask, labels)
+        out = {"loss": nll}
+        return out if return_dict else (nll,)
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, whole_word_ids=None, max_length: int = 20,
+                 prefix_allowed_tokens_fn: Optional[Callable] = None, num_beams: int = 1, num_return_sequences: Optional[int] = None,
+                 output_scores: bool = False, return_dict_in_generate: bool = False, trie=None, roots=None, **unused):
+        """Constrained beam search (DistributedRunner.py:361-371).  `prefix_allowed_tokens_fn` made by
+        `openp5_amd.trie.prefix_allowed_tokens_fn` -- or by the reference's own generation_trie.prefix_allowed_tokens_fn,
+        whose closure holds the Trie -- runs fully on the device.  `trie` may be passed directly (Trie / CompiledTrie)."""
+        dev = self._be.device
+        K = int(num_beams)
+        nret = int(num_return_sequences or K)
+        if trie is None and prefix_allowed_tokens_fn is not None:
+            trie = find_trie(prefix_allowed_tokens_fn)
+            if trie is None:
+                trie = self._explore_callable(prefix_allowed_tokens_fn, input_ids.shape[0], max_length)
+                roots = trie._roots
+        if trie is None:
+            raise ValueError("generate() needs a trie / prefix_allowed_tokens_fn (OpenP5 always decodes under the item trie)")
+        if isinstance(trie, Trie) or (hasattr(trie, "trie_dict") and not isinstance(trie, CompiledTrie)):
+            cache = getattr(trie, "_p5_compiled", None)
+            if cache is None or cache[0] != getattr(trie, "len", None):
+                cache = (getattr(trie, "len", None), CompiledTrie.from_dict(trie.trie_dict))
+                try:
+                    trie._p5_compiled = cache
+                except Exception:
+                    pass
+            trie = cache[1]
+        off, tok, nxt = trie.device_arrays(dev)
+        input_ids = self._i64(input_ids, dev)
+        B, L = input_ids.shape
+        if whole_word_ids is None:
+            whole_word_ids = torch.zeros_like(input_ids)
+        whole_word_ids = self._i64(whole_word_ids, dev)
+        if attention_mask is None:
+            attention_mask = (input_ids != self.config.pad_token_id).long()
+        attention_mask = self._i64(attention_mask, dev)
+        roots_t = None
+        if roots is not None:
+            roots_t = torch.as_tensor(roots, dtype=torch.int32, device=dev).contiguous()
+        self._sync_shadow()
+        maxc = max(1, trie.max_children)
+        ws = self._workspace(self._lib.p5_generate_workspace_bytes(self._engine, B, L, K, max_length, maxc), "_gen_ws")
+        seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
+        score = torch.zeros(B, K, dtype=torch.float32, device=dev)
+        ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        self._be.check(self._lib.p5_generate(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), B, L, K, max_length,
+                                             _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, _ptr(seq), _ptr(score), _ptr(ln), _ptr(ws),
+                                             ws.numel(), self._be.stream_ptr()), "p5_generate")
+        out_len = 1 + int(ln[:, :nret].max().item())
+        sequences = seq[:, :nret, :out_len].reshape(B * nret, out_len).to(torch.int64)
+        scores = score[:, :nret].reshape(B * nret)
+        if return_dict_in_generate:
+            return {"sequences": sequences, "sequences_scores": scores if output_scores else None}
+        return sequences
+
+    def _explore_callable(self, fn, B, max_length):
+        """Compat path for an arbitrary prefix_allowed_tokens_fn(batch_id, prefix): enumerate it breadth-first into one
+        CSR trie per batch item (as many Python calls as trie nodes, once per generate call)."""
+        off, tok, nxt, roots = [0], [], [], []
+        queue = []
+        for b in range(B):
+            roots.append(len(queue) + 0)
+            queue.append((b, []))
+        next_id = len(queue)
+        qi = 0
+        while qi < len(queue):
+            b, prefix = queue[qi]
+            qi += 1
+            kids = [] if (len(prefix) >= max_length or (prefix and prefix[-1] == self.config.eos_token_id)) else \
+                (sorted(set(int(t) for t in fn(b, torch.tensor(prefix, dtype=torch.long)))) if prefix else [self.config.decoder_start_token_id])
+            for t in kids:
+                tok.append(t)
+                nxt.append(next_id)
+                next_id += 1
+                queue.append((b, prefix + [t]))
+            off.append(len(tok))
+        ct = CompiledTrie(np.asarray(off), np.asarray(tok), np.asarray(nxt))
+        ct._roots = roots
+        return ct
+
+    def __del__(self):
+        try:
+            if self._engine:
+                self._lib.p5_engine_destroy(self._engine)
+        except Exception:
+            pass

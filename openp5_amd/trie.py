@@ -1,0 +1,154 @@
+"""Item-ID prefix trie (host side) and its CSR compilation for the device beam search.
+
+`Trie` mirrors /root/reference/src/src_t5/utils/generation_trie.py:7-88 (same constructor, `add`, `get`,
+`__len__`, `__iter__`, `trie_dict`; the `append_trie` hook of the reference is kept).  `prefix_allowed_tokens_fn`
+mirrors generation_trie.py:91-97 and additionally exposes `.candidate_trie`, which `P5T5Native.generate` uses to
+run the constraint on the device instead of calling back into Python per (batch x beam) row per step.
+"""
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+
+class Trie(object):
+    def __init__(self, sequences: Optional[Iterable[Sequence[int]]] = None):
+        self.trie_dict: Dict[int, dict] = {}
+        self.len = 0
+        if sequences:
+            for sequence in sequences:
+                self.add(sequence)
+        self.append_trie = None
+        self.bos_token_id = None
+
+    def append(self, trie, bos_token_id):
+        self.append_trie = trie
+        self.bos_token_id = bos_token_id
+
+    def add(self, sequence: Sequence[int]):
+        node = self.trie_dict
+        for tok in sequence:
+            node = node.setdefault(int(tok), {})
+        self.len += 1
+
+    def get(self, prefix_sequence: Sequence[int]) -> List[int]:
+        node = self.trie_dict
+        for i, tok in enumerate(prefix_sequence):
+            if tok in node:
+                node = node[tok]
+            elif self.append_trie is not None:
+                return self.append_trie.get(list(prefix_sequence[i:]))
+            else:
+                return []
+        out = list(node.keys())
+        if self.append_trie is not None and self.bos_token_id in out:
+            out.remove(self.bos_token_id)
+            out += list(self.append_trie.trie_dict.keys())
+        return out
+
+    @staticmethod
+    def load_from_dict(trie_dict):
+        trie = Trie()
+        trie.trie_dict = trie_dict
+        trie.len = sum(1 for _ in trie)
+        return trie
+
+    def __iter__(self):
+        def _traverse(prefix, node):
+            if node:
+                for tok in node:
+                    yield from _traverse(prefix + [tok], node[tok])
+            else:
+                yield prefix
+        return _traverse([], self.trie_dict)
+
+    def __len__(self):
+        return self.len
+
+    def __getitem__(self, value):
+        return self.get(value)
+
+
+def prefix_allowed_tokens_fn(candidate_trie):
+    def prefix_allowed_tokens(batch_id, sentence):
+        sentence = sentence.tolist() if hasattr(sentence, "tolist") else list(sentence)
+        return candidate_trie.get(sentence)
+
+    prefix_allowed_tokens.candidate_trie = candidate_trie
+    return prefix_allowed_tokens
+
+
+def exact_match(predictions, targets, k):
+    """generation_trie.py:99-109."""
+    correct = 0
+    for b, t in enumerate(targets):
+        if t in predictions[b * k:(b + 1) * k]:
+            correct += 1
+    return correct
+
+
+class CompiledTrie:
+    """CSR form: node 0 is the empty prefix; children of node n are edges child_off[n]..child_off[n+1] with token
+    `child_tok` (sorted ascending, matching HF's flat beam*V+token tie order) leading to node `child_node`."""
+
+    def __init__(self, child_off: np.ndarray, child_tok: np.ndarray, child_node: np.ndarray):
+        self.child_off = np.ascontiguousarray(child_off, dtype=np.int32)
+        self.child_tok = np.ascontiguousarray(child_tok, dtype=np.int32)
+        self.child_node = np.ascontiguousarray(child_node, dtype=np.int32)
+        self.n_nodes = len(self.child_off) - 1
+        self.max_children = int(np.max(np.diff(self.child_off))) if self.n_nodes > 0 else 0
+        self._dev = {}
+
+    @staticmethod
+    def from_dict(trie_dict: Dict[int, dict]) -> "CompiledTrie":
+        off, tok, nxt = [0], [], []
+        # breadth-first so that siblings are contiguous
+        queue = [trie_dict]
+        next_id = 1
+        qi = 0
+        while qi < len(queue):
+            node = queue[qi]
+            qi += 1
+            for t in sorted(node.keys()):
+                tok.append(int(t))
+                nxt.append(next_id)
+                next_id += 1
+                queue.append(node[t])
+            off.append(len(tok))
+        return CompiledTrie(np.asarray(off), np.asarray(tok), np.asarray(nxt))
+
+    @staticmethod
+    def from_trie(trie: Trie) -> "CompiledTrie":
+        if getattr(trie, "append_trie", None) is not None:
+            raise NotImplementedError("append_trie tries are not supported by the device path")
+        return CompiledTrie.from_dict(trie.trie_dict)
+
+    @staticmethod
+    def from_sequences(seqs: Iterable[Sequence[int]]) -> "CompiledTrie":
+        return CompiledTrie.from_trie(Trie(seqs))
+
+    def children(self, node: int):
+        a, b = self.child_off[node], self.child_off[node + 1]
+        return self.child_tok[a:b], self.child_node[a:b]
+
+    def device_arrays(self, device):
+        import torch
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in (self.child_off, self.child_tok, self.child_node))
+        return self._dev[key]
+
+
+def find_trie(fn):
+    """Recover the Trie behind a prefix_allowed_tokens_fn: ours (`.candidate_trie`) or the reference's closure
+    (generation_trie.py:91-97 closes over `candidate_trie`)."""
+    t = getattr(fn, "candidate_trie", None)
+    if t is not None:
+        return t
+    for cell in (getattr(fn, "__closure__", None) or ()):
+        try:
+            obj = cell.cell_contents
+        except ValueError:
+            continue
+        if hasattr(obj, "trie_dict") and hasattr(obj, "get"):
+            return obj
+    return None

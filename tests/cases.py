@@ -1,0 +1,353 @@
+"""Parity cases shared by the not-gpu suite (host emulation backend) and the -m gpu suite (libp5hip.so on the MI355X).
+Every case drives the C ABI of include/p5hip.h and checks against plain torch math or the oracle / golden fixtures."""
+import ctypes
+import os
+import random
+
+import torch
+
+from oracle import t5_oracle as O
+from openp5_amd.model import P5ModelConfig, P5T5Native, relative_position_bucket_lut
+from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TT = {0: torch.float32, 1: torch.bfloat16}
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def sync(be):
+    if not be.is_emulator:
+        torch.cuda.synchronize()
+
+
+def dev(be, t):
+    return t.to(be.device).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def tr_probe(be):
+    """ds_read_b64_tr_b16: lane i of a 16-lane group must receive column i of the group's [4][16] block."""
+    x = torch.arange(256, dtype=torch.int16)
+    out = torch.zeros(256, dtype=torch.int16)
+    xd, od = dev(be, x), dev(be, out)
+    be.check(be.lib.p5_op_tr_probe(P(od), P(xd), be.stream_ptr()), "tr_probe")
+    sync(be)
+    got = od.cpu().view(64, 4)
+    exp = torch.zeros(64, 4, dtype=torch.int16)
+    for l in range(64):
+        for j in range(4):
+            exp[l, j] = (l >> 4) * 64 + j * 16 + (l & 15)
+    assert torch.equal(got, exp), f"tr16 semantics differ:\n{got[:20]}\nexpected\n{exp[:20]}"
+
+
+def gemm_case(be, dtype, M, N, K, a_ks, b_ks, epi=0, c_f32=0, splitk=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tt = TT[dtype]
+    A = torch.randn(M, K, generator=g).to(tt)
+    Bm = torch.randn(N, K, generator=g).to(tt)
+    ref = A.float() @ Bm.float().t()
+    A_ = A.t().contiguous() if a_ks else A
+    B_ = Bm.t().contiguous() if b_ks else Bm
+    out_f32 = bool(c_f32) or dtype == 0
+    C = torch.zeros(M, N, dtype=torch.float32 if out_f32 else tt)
+    aux = None
+    if epi == 1:
+        ref = torch.relu(ref)
+    elif epi == 2:
+        aux = torch.randn(M, N, generator=g).to(tt)
+        ref = ref + aux.float()
+    elif epi == 3:
+        aux = torch.randn(M, N, generator=g).to(tt)
+        ref = torch.where(aux.float() > 0, ref, torch.zeros_like(ref))
+    Ad, Bd, Cd = dev(be, A_), dev(be, B_), dev(be, C)
+    auxd = dev(be, aux) if aux is not None else None
+    be.check(be.lib.p5_op_gemm(dtype, P(Ad), P(Bd), P(Cd), P(auxd), M, N, K, A_.shape[1], B_.shape[1], N, N, a_ks, b_ks, epi, c_f32, splitk,
+                               1.0, None, 0, 0.0, be.stream_ptr()), "gemm")
+    sync(be)
+    got = Cd.cpu().float()
+    tol = 1e-4 * max(1.0, K ** 0.5) if out_f32 else 2e-2 * max(1.0, float(ref.abs().max()))
+    if dtype == 1 and out_f32:
+        tol = 1e-3 * max(1.0, K ** 0.5)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"gemm dtype={dtype} M={M} N={N} K={K} aks={a_ks} bks={b_ks} epi={epi}: err {err} > {tol}"
+    return err
+
+
+def rmsnorm_case(be, dtype, rows, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tt = TT[dtype]
+    x = torch.randn(rows, d, generator=g).to(tt)
+    w = (1.0 + 0.1 * torch.randn(d, generator=g))
+    dy = torch.randn(rows, d, generator=g).to(tt)
+    dres = torch.randn(rows, d, generator=g)
+    xr = x.float().clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = O.rmsnorm(xr, wr, 1e-6)
+    yr.backward(dy.float())
+    y = torch.zeros(rows, d, dtype=tt)
+    rstd = torch.zeros(rows)
+    xd, wd, yd, rd = dev(be, x), dev(be, w), dev(be, y), dev(be, rstd)
+    be.check(be.lib.p5_op_rmsnorm_fwd(dtype, P(yd), P(rd), P(xd), P(wd), rows, d, 1e-6, be.stream_ptr()), "rmsnorm_fwd")
+    dres_out = dev(be, torch.zeros(rows, d))
+    dy_next = dev(be, torch.zeros(rows, d, dtype=tt))
+    dw = dev(be, torch.zeros(d))
+    be.check(be.lib.p5_op_rmsnorm_bwd(dtype, P(dres_out), P(dy_next), P(dw), P(dev(be, dy)), P(xd), P(wd), P(rd), P(dev(be, dres)), rows, d,
+                                      be.stream_ptr()), "rmsnorm_bwd")
+    sync(be)
+    tol = 1e-5 if dtype == 0 else 3e-2
+    assert (yd.cpu().float() - yr.detach()).abs().max() <= tol * 4
+    assert (dres_out.cpu() - (xr.grad + dres)).abs().max() <= tol * 8
+    assert (dw.cpu() - wr.grad).abs().max() <= tol * 8 * max(1.0, rows ** 0.5)
+    assert (dy_next.cpu().float() - dres_out.cpu()).abs().max() <= (1e-6 if dtype == 0 else 5e-2)
+
+
+def attn_ref(q, k, v, bias, mask_add, causal):
+    s = q @ k.transpose(2, 3)
+    if bias is not None:
+        s = s + bias
+    if mask_add is not None:
+        s = s + mask_add
+    if causal:
+        Lq, Lk = s.shape[-2:]
+        cm = torch.ones(Lq, Lk, dtype=torch.bool).tril()
+        s = s.masked_fill(~cm, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return p @ v
+
+
+def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
+    """mode: 'enc' (bidirectional bias + key mask, self), 'dec' (causal + unidirectional bias, self), 'cross' (mask only)."""
+    g = torch.Generator().manual_seed(seed)
+    tt = TT[dtype]
+    inner = H * 64
+    self_attn = mode != "cross"
+    if self_attn:
+        assert Lq == Lk
+        qkv = (0.5 * torch.randn(B * Lq, 3 * inner, generator=g)).to(tt)
+        Qs, Ks, Vs = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+        ldq = ldk = ldv = 3 * inner
+    else:
+        qb = (0.5 * torch.randn(B * Lq, inner, generator=g)).to(tt)
+        kvb = (0.5 * torch.randn(B * Lk, 2 * inner, generator=g)).to(tt)
+        Qs, Ks, Vs = qb, kvb[:, :inner], kvb[:, inner:]
+        ldq, ldk, ldv = inner, 2 * inner, 2 * inner
+    table = 0.5 * torch.randn(32, H, generator=g)
+    kmask = torch.ones(B, Lk, dtype=torch.long)
+    if mode != "dec":
+        for b in range(B):
+            n = int(torch.randint(max(1, Lk // 2), Lk + 1, (1,), generator=g))
+            kmask[b, n:] = 0
+    dO = torch.randn(B * Lq, inner, generator=g).to(tt)
+
+    def heads(x, Ln):
+        return x.float().reshape(B, Ln, H, 64).transpose(1, 2)
+
+    qr = heads(Qs, Lq).clone().requires_grad_(True)
+    kr = heads(Ks, Lk).clone().requires_grad_(True)
+    vr = heads(Vs, Lk).clone().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    lut_half = 512
+    bias = None
+    lut = None
+    if mode in ("enc", "dec"):
+        lut = relative_position_bucket_lut(lut_half, mode == "enc", 32, 128)
+        rel = torch.arange(Lk)[None, :] - torch.arange(Lq)[:, None]
+        bias = tr[lut[rel + lut_half].long()].permute(2, 0, 1).unsqueeze(0)
+    mask_add = None
+    if mode != "dec":
+        mask_add = torch.where(kmask[:, None, None, :] != 0, 0.0, float("-inf"))
+    out_r = attn_ref(qr, kr, vr, bias, mask_add, mode == "dec")
+    out_r.backward(heads(dO, Lq))
+    O_r = out_r.detach().transpose(1, 2).reshape(B * Lq, inner)
+
+    Od = dev(be, torch.zeros(B * Lq, inner, dtype=tt))
+    lse = dev(be, torch.zeros(B * H * Lq))
+    if self_attn:
+        qkv_d = dev(be, qkv)
+        Qd, Kd, Vd = qkv_d, qkv_d[:, inner:], qkv_d[:, 2 * inner:]
+    else:
+        q_d, kv_d = dev(be, qb), dev(be, kvb)
+        Qd, Kd, Vd = q_d, kv_d, kv_d[:, inner:]
+    table_d = dev(be, table) if mode != "cross" else None
+    lut_d = dev(be, lut) if lut is not None else None
+    km_d = dev(be, kmask) if mode != "dec" else None
+    causal = 1 if mode == "dec" else 0
+    be.check(be.lib.p5_op_attn_fwd(dtype, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq,
+                                   ldk, ldv, inner, causal, None, 0, 0.0, be.stream_ptr()), "attn_fwd")
+    if self_attn:
+        dqkv = dev(be, torch.zeros(B * Lq, 3 * inner, dtype=tt))
+        dQd, dKd, dVd = dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:]
+        lddq = lddk = lddv = 3 * inner
+    else:
+        dq_d = dev(be, torch.zeros(B * Lq, inner, dtype=tt))
+        dkv_d = dev(be, torch.zeros(B * Lk, 2 * inner, dtype=tt))
+        dQd, dKd, dVd = dq_d, dkv_d, dkv_d[:, inner:]
+        lddq, lddk, lddv = inner, 2 * inner, 2 * inner
+    dtab = dev(be, torch.zeros(32, H)) if mode != "cross" else None
+    Dv = dev(be, torch.zeros(B * H * Lq))
+    be.check(be.lib.p5_op_attn_bwd(dtype, P(Qd), P(Kd), P(Vd), P(Od), P(dev(be, dO)), P(lse), P(Dv), P(dQd), P(dKd), P(dVd), P(table_d),
+                                   P(dtab), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk, ldv, inner, lddq, lddk, lddv, causal, None,
+                                   0, 0.0, be.stream_ptr()), "attn_bwd")
+    sync(be)
+    tol = 2e-5 if dtype == 0 else 4e-2
+    scale = max(1.0, Lk ** 0.5)
+
+    def unheads(x, Ln):
+        return x.transpose(1, 2).reshape(B * Ln, inner)
+
+    errs = {"O": (Od.cpu().float() - O_r).abs().max().item()}
+    if self_attn:
+        g_all = dqkv.cpu().float()
+        gq, gk, gv = g_all[:, :inner], g_all[:, inner:2 * inner], g_all[:, 2 * inner:]
+    else:
+        gq = dq_d.cpu().float()
+        gk, gv = dkv_d.cpu().float()[:, :inner], dkv_d.cpu().float()[:, inner:]
+    errs["dQ"] = (gq - unheads(qr.grad, Lq)).abs().max().item()
+    errs["dK"] = (gk - unheads(kr.grad, Lk)).abs().max().item()
+    errs["dV"] = (gv - unheads(vr.grad, Lk)).abs().max().item()
+    if mode != "cross":
+        errs["dT"] = (dtab.cpu() - tr.grad).abs().max().item() / max(1.0, float(tr.grad.abs().max()))
+    for k_, e_ in errs.items():
+        assert e_ <= tol * scale * (4 if k_ != "O" else 1), f"attention {mode} dtype={dtype} Lq={Lq} Lk={Lk}: {k_} err {e_} (all: {errs})"
+    return errs
+
+
+# ---------------------------------------------------------------------------------------------------------
+def build_model(be, ocfg, params, dtype, dropout=0.0, seed=1):
+    cfg = P5ModelConfig(vocab_size=ocfg.vocab_size, d_model=ocfg.d_model, d_ff=ocfg.d_ff, num_layers=ocfg.num_layers,
+                        num_decoder_layers=ocfg.num_decoder_layers, num_heads=ocfg.num_heads, dropout_rate=dropout,
+                        feed_forward_proj="relu" if ocfg.ff_act == "relu" else "gated-gelu")
+    m = P5T5Native(cfg, dtype=dtype, backend=be, seed=seed)
+    m.load_state_dict(params, strict=True)
+    return m
+
+
+def synth_batch(cfg, B, L, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, cfg.vocab_size, (B, L), generator=g)
+    mask = torch.ones(B, L, dtype=torch.long)
+    for b in range(1, B):
+        n = int(torch.randint(L // 2, L + 1, (1,), generator=g))
+        mask[b, n:] = 0
+        ids[b, n:] = 0
+    ww = torch.cumsum((torch.rand(B, L, generator=g) < 0.4).long(), 1) * mask
+    labels = torch.randint(3, cfg.vocab_size, (B, T), generator=g)
+    out_attn = torch.ones(B, T, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(2, T + 1, (1,), generator=g))
+        labels[b, n - 1] = cfg.eos_id
+        labels[b, n:] = 0
+        out_attn[b, n:] = 0
+    return ids, ww, mask, labels, out_attn
+
+
+def model_train_case(be, ocfg, B, L, T, dtype="fp32", dropout=0.0, seed=3, nll_tol=2e-5, grad_tol=2e-4):
+    """forward NLL + every parameter gradient against the oracle (autograd on the CPU restatement)."""
+    ocfg = O.T5Cfg(**{**ocfg.__dict__, "dropout": dropout})
+    params = O.init_params(ocfg, 7)
+    m = build_model(be, ocfg, params, dtype, dropout)
+    ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, seed)
+    dp = None
+    if dropout > 0:
+        m.train()
+        m.set_dropout_seed(1234, 0)
+        dp = O.DropoutPlan((1234 + 1 * 0x632BE5AB) & 0xFFFFFFFF, dropout)
+    else:
+        m.eval()
+    nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels, alpha=2, return_dict=True)["loss"]
+    assert nll.shape == (B * T,)
+    loss = O.runner_loss(nll, out_attn.to(nll.device))
+    loss.backward()
+    sync(be)
+    Pq = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    nll_o = O.p5_forward_nll(Pq, ocfg, ids, ww, mask, labels, dp)
+    O.runner_loss(nll_o, out_attn).backward()
+    err = (nll.detach().cpu() - nll_o.detach()).abs().max().item()
+    assert err <= nll_tol, f"nll err {err}"
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        g_, go = p.grad.detach().cpu(), Pq[name].grad
+        rel = (g_ - go).abs().max().item() / (go.abs().max().item() + 1e-8)
+        if rel > worst[0]:
+            worst = (rel, name)
+    assert worst[0] <= grad_tol, f"gradient mismatch {worst}"
+    return err, worst
+
+
+def golden_case(be, name, dtype="fp32", nll_tol=3e-5, grad_tol=3e-4, score_tol=2e-5):
+    """HIP path vs fixtures produced by stock HF T5 (tests/golden/make_golden.py)."""
+    fx = torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+    ocfg = O.T5Cfg(**fx["cfg"])
+    params = O.init_params(ocfg, fx["params_seed"])
+    m = build_model(be, ocfg, params, dtype)
+    m.eval()
+    nll = m(input_ids=fx["input_ids"], whole_word_ids=fx["whole_word_ids"], attention_mask=fx["attention_mask"], labels=fx["labels"])["loss"]
+    loss = O.runner_loss(nll, fx["output_attention"].to(nll.device))
+    loss.backward()
+    sync(be)
+    assert (nll.detach().cpu() - fx["nll"]).abs().max().item() <= nll_tol
+    assert abs(float(loss) - float(fx["loss"])) <= nll_tol
+    tied = {"shared.weight"}
+    for k, p in m.named_parameters():
+        ref = fx["grad_norms"].get(k)
+        if ref is None:
+            continue
+        got = float(p.grad.norm())
+        assert abs(got - ref) <= grad_tol * max(1.0, ref) + 1e-7, f"grad norm {k}: {got} vs {ref}"
+    assert (m.shared.weight.grad[:16].cpu() - fx["grad_shared"]).abs().max() <= grad_tol
+    rel = dict(m.named_parameters())["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].grad.cpu()
+    assert (rel - fx["grad_enc_rel"]).abs().max() <= grad_tol
+    fn = prefix_allowed_tokens_fn(Trie(fx["items"]))
+    out = m.generate(input_ids=fx["input_ids"], attention_mask=fx["attention_mask"], whole_word_ids=fx["whole_word_ids"],
+                     max_length=fx["max_length"], prefix_allowed_tokens_fn=fn, num_beams=fx["num_beams"],
+                     num_return_sequences=fx["num_beams"], output_scores=True, return_dict_in_generate=True)
+    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), fx["sequences"], fx["sequences_scores"], score_tol)
+
+
+def compare_generation(seq, score, seq_ref, score_ref, score_tol, eos=1):
+    """Token-exact up to and including the first EOS (HF 5.15 pads with eos, HF 4.26 / this path with pad=0)."""
+    assert seq.shape[0] == seq_ref.shape[0]
+    assert (score - score_ref).abs().max().item() <= score_tol, (score, score_ref)
+    for r in range(seq.shape[0]):
+        a, b = seq[r].tolist(), seq_ref[r].tolist()
+        ea = a.index(eos) if eos in a else len(a) - 1
+        eb = b.index(eos) if eos in b else len(b) - 1
+        assert a[:ea + 1] == b[:eb + 1], f"row {r}: {a} vs {b}"
+        assert all(t == 0 for t in a[ea + 1:]), f"row {r} not pad-filled: {a}"
+
+
+def make_items(n_items, seed, lo=7, hi=40, prefix=(0, 5, 6), minlen=2, maxlen=4):
+    rnd = random.Random(seed)
+    items = set()
+    while len(items) < n_items:
+        n = rnd.randint(minlen, maxlen)
+        items.add(tuple(list(prefix) + [rnd.randint(lo, hi) for _ in range(n)] + [1]))
+    return sorted(list(x) for x in items)
+
+
+def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours"):
+    params = O.init_params(ocfg, 7)
+    m = build_model(be, ocfg, params, dtype)
+    m.eval()
+    ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
+    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
+    trie = Trie(items)
+    if via == "ours":
+        fn = prefix_allowed_tokens_fn(trie)
+    elif via == "closure":          # the reference's closure style (generation_trie.py:91-97)
+        def make(candidate_trie):
+            def prefix_allowed_tokens(batch_id, sentence):
+                return candidate_trie.get(sentence.tolist())
+            return prefix_allowed_tokens
+        fn = make(trie)
+    else:                           # opaque callable -> host exploration path
+        fn = lambda b, s: trie.get(s.tolist())   # noqa: E731
+    out = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=max_len, prefix_allowed_tokens_fn=fn,
+                     num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True)
+    with torch.no_grad():
+        s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, max_len)
+    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
+    return out

@@ -1,0 +1,81 @@
+"""-m gpu: the parity tests proper -- libp5hip.so on the MI355X through the C ABI, against torch math, the oracle and
+the HF-generated golden fixtures."""
+import pytest
+import torch
+
+from oracle import t5_oracle as O
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_loaded(hip):
+    assert hip.lib.p5_is_emulator() == 0
+    assert hip.lib.p5_abi_version() == 1
+
+
+def test_tr_probe(hip):
+    cases.tr_probe(hip)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(70, 50, 48, 0, 0, 0), (70, 56, 64, 0, 1, 0), (72, 56, 50, 1, 1, 4), (130, 200, 96, 0, 0, 1),
+                                   (66, 72, 40, 0, 0, 2), (64, 64, 136, 0, 1, 3), (1024, 512, 512, 0, 0, 0), (2048, 512, 2048, 0, 1, 0),
+                                   (512, 2048, 4096, 1, 1, 4), (300, 32100, 512, 0, 0, 0)])
+def test_gemm(hip, dtype, shape):
+    M, N, K, aks, bks, epi = shape
+    cases.gemm_case(hip, dtype, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=0 if epi == 4 else 1)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_rmsnorm(hip, dtype):
+    cases.rmsnorm_case(hip, dtype, 37, 128)
+    cases.rmsnorm_case(hip, dtype, 1000, 512)
+    cases.rmsnorm_case(hip, dtype, 300, 1024)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 20, 20), ("enc", 70, 70), ("enc", 128, 128), ("enc", 200, 200), ("enc", 512, 512),
+                                        ("dec", 6, 6), ("dec", 18, 18), ("cross", 7, 33), ("cross", 9, 130), ("cross", 17, 300)])
+def test_attention(hip, dtype, mode, Lq, Lk):
+    cases.attn_case(hip, dtype, 2, 3, Lq, Lk, mode)
+
+
+def test_model_fp32(hip):
+    cases.model_train_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6, "fp32", 0.0)
+
+
+def test_model_fp32_dropout(hip):
+    cases.model_train_case(hip, O.T5Cfg.named("tiny"), 2, 17, 5, "fp32", 0.1)
+
+
+def test_model_gated(hip):
+    cases.model_train_case(hip, O.T5Cfg.named("tiny", ff_act="gated-gelu"), 2, 12, 4, "fp32", 0.0)
+
+
+def test_model_bf16(hip):
+    cases.model_train_case(hip, O.T5Cfg.named("tiny"), 2, 16, 5, "bf16", 0.0, nll_tol=0.08, grad_tol=0.5)
+
+
+def test_model_t5_small_fp32(hip):
+    """BASELINE.json configs[0] shape (B=4, L=128) at full T5-small dims, V=32100, fp32 parity mode."""
+    cases.model_train_case(hip, O.T5Cfg.named("t5-small"), 4, 128, 8, "fp32", 0.0, nll_tol=1e-4, grad_tol=1e-3)
+
+
+def test_model_t5_small_fp32_dropout(hip):
+    cases.model_train_case(hip, O.T5Cfg.named("t5-small"), 2, 40, 8, "fp32", 0.1, nll_tol=1e-4, grad_tol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["tiny_relu", "tiny_gated"])
+def test_golden(hip, name):
+    cases.golden_case(hip, name)
+
+
+@pytest.mark.parametrize("via", ["ours", "closure", "opaque"])
+def test_generate(hip, via):
+    cases.generate_case(hip, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
+
+
+def test_generate_t5_small(hip):
+    """beam-10 over a 300-item trie at T5-small dims: ranked item sequences identical to the CPU oracle."""
+    cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4)
