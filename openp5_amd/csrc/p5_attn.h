@@ -35,6 +35,8 @@ struct P5AttnArgs {
   int B, H, Lq, Lk;
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int causal;
+  int rel_copies;        // d_rel_table holds this many partial copies (stride rel_stride floats) to spread atomics; 0/1 = one
+  int rel_stride;
   P5Drop drop;
 };
 
@@ -337,12 +339,25 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
             dp = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? dp * a.drop.scale : 0.f;
           }
           ds = p * (dp - D_r[r]);
-          if (a.d_rel_table) atomicAdd(&sdb[kj - qi + a.Lq - 1], ds);
         }
         *(T*)(pw + (g * 4 + r) * C::TS + (t * 16 + li) * C::SZ) = from_f<T>(ds);
       }
     }
     __syncthreads();
+    if (a.d_rel_table) {
+      // d(rel-bias): sum dS along the diagonals (constant key - query) of this wave's [16 q][64 keys] tile held in
+      // LDS -- one LDS atomic per diagonal per wave instead of one per score element
+      for (int dd = lane; dd < 79; dd += 64) {
+        float sum = 0.f;
+#pragma unroll
+        for (int qr = 0; qr < 16; ++qr) {
+          const int kcol = dd - 15 + qr;
+          if (kcol >= 0 && kcol < 64) sum += to_f<T>(*(const T*)(pw + qr * C::TS + kcol * C::SZ));
+        }
+        const int idx = ch * 64 + dd - 15 - q0 + a.Lq - 1;
+        if (sum != 0.f && idx >= 0 && idx < nrel) atomicAdd(&sdb[idx], sum);
+      }
+    }
 #pragma unroll
     for (int kc = 0; kc < C::NCK; ++kc) {
       const u32x4 dsa = ld16(pw + li * C::TS + kc * 64 + g * 16);
@@ -360,10 +375,20 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
       dQ[((size_t)b * a.Lq + qi) * a.lddq + h * 64 + dt * 16 + li] = from_f<T>(dq[dt][r]);
   }
   if (a.d_rel_table) {
+    // relative positions -> buckets inside the workgroup, then one global atomic per (bucket, head) into one of
+    // `rel_copies` partial tables (same-address atomics from ~B*Lq/64 workgroups serialise at L2 otherwise)
+    __syncthreads();
+    float* sbk = sbias;   // sbias is dead from here on
+    if (tid < 64) sbk[tid] = 0.f;
     __syncthreads();
     for (int i = tid; i < nrel; i += 256) {
       const float v = sdb[i];
-      if (v != 0.f) atomicAdd(&a.d_rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h], v);
+      if (v != 0.f) atomicAdd(&sbk[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] & 63], v);
+    }
+    __syncthreads();
+    if (tid < 64 && sbk[tid] != 0.f) {
+      const int copy = a.rel_copies > 1 ? (b % a.rel_copies) : 0;
+      atomicAdd(&a.d_rel_table[(size_t)copy * a.rel_stride + tid * a.H + h], sbk[tid]);
     }
   }
 }

@@ -140,6 +140,18 @@ __device__ static __forceinline__ u32x2 lds_tr16_b64(const void* p) {
 }
 #endif
 
+// ---- direct global -> LDS copy (gfx950 global_load_lds_dwordx4): lane l's 16 bytes land at lds_wave_base + 16*l.
+// The LDS base must be wave-uniform (it travels in M0); completion is tracked by vmcnt, and __syncthreads()
+// drains it before the barrier (cdna_hip_programming.md section 5).
+#ifdef P5_EMU
+static inline void glds16(const void* g, char* lds_wave_base) { memcpy(lds_wave_base + 16 * (int)emu::lane(), g, 16); }
+#else
+__device__ static __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll

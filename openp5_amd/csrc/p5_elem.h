@@ -193,6 +193,15 @@ __global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, 
   }
 }
 
+// dst[i] += sum_c partial[c][i]   (partial copies of the relative-bias gradient)
+__global__ __launch_bounds__(256) void p5_reduce_copies_kernel(float* __restrict__ dst, const float* __restrict__ partial, int n, int copies) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < copies; ++c) s += partial[(size_t)c * n + i];
+  dst[i] += s;
+}
+
 // fp32 master -> compute-dtype shadow (bf16 fast mode)
 template <class T>
 __global__ __launch_bounds__(256) void p5_cast_kernel(T* __restrict__ out, const float* __restrict__ in, size_t n) {

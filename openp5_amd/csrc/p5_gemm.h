@@ -13,8 +13,9 @@
 //   wgrad    dW = dy^T x     : A = dy KS,  B = x  KS   (split-K over the token dim, fp32 atomics)
 // KS fragments come out of LDS through ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32).
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves as 2x2), one 64-byte K-chunk per step, double-buffered
-// in LDS with the next chunk's global loads in flight during the MFMAs.
+// Tile: BM x BN per 256-thread workgroup (4 waves as 2x2), NCK 64-byte K-chunks per step, double-buffered in
+// LDS with the next step's global loads in flight during the MFMAs.  bf16 results leave through an LDS-staged
+// epilogue so that residual reads and C writes are 16 bytes per lane.
 #pragma once
 #include "p5_device.h"
 #include "p5_rng.h"
@@ -44,19 +45,19 @@ struct P5GemmArgs {
   P5Drop drop;
 };
 
-template <class T, bool KS> struct LdsTile {
-  // byte layout of one operand tile of R rows x 64B of K
-  template <int R> static constexpr int bytes() {
-    return KS ? TT<T>::KCH * (R * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16)) : R * 64;
-  }
+// byte size of ONE 64-byte-K chunk of an operand tile of R rows
+template <class T, int R, bool KS> struct LdsChunk {
+  static constexpr int KS_STRIDE = R * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+  static constexpr int BYTES = KS ? TT<T>::KCH * KS_STRIDE : R * 64;
 };
 
 __device__ static __forceinline__ int kc_off(int row, int kc) {
-  // XOR swizzle that makes every ds_read_b128 lane group hit 16 distinct 16-byte slots (see DESIGN.md)
+  // XOR swizzle that makes every ds_read_b128 lane group hit 16 distinct 16-byte slots (DESIGN.md)
   const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;  // h = [0,3,2,1]
   return row * 64 + ((kc ^ h) << 4);
 }
 
+// loads ONE chunk (KCH elements of K starting at k0) of an R-row operand tile into registers
 template <class T, int R, bool KS>
 __device__ static __forceinline__ void stage_load(u32x4* regs, const T* __restrict__ p, int ld, int r0, int k0, int nrows,
                                                   int K, int tid) {
@@ -96,12 +97,30 @@ __device__ static __forceinline__ void stage_store(const u32x4* regs, char* lds,
   } else {
     constexpr int CPR = R / EPF;
     constexpr int NCH = TT<T>::KCH * CPR / 256;
-    constexpr int STRIDE = R * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int STRIDE = LdsChunk<T, R, true>::KS_STRIDE;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * 256;
       st16(lds + (c / CPR) * STRIDE + (c % CPR) * 16, regs[i]);
     }
+  }
+}
+
+// KC chunk straight from HBM into LDS (no VGPR round trip, no ds_write): each wave instruction fills 16 rows x 64 B.
+// The XOR swizzle of kc_off() is applied on the SOURCE address (the LDS image of a wave instruction is linear).
+// Rows past the matrix edge are clamped: they only feed C rows/cols that are never stored.  Needs K % KCH == 0.
+template <class T, int R>
+__device__ static __forceinline__ void stage_dma(char* lds, const T* __restrict__ p, int ld, int r0, int k0, int nrows, int tid) {
+  constexpr int NI = R / 64;
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int rbase = (wave * NI + i) * 16;
+    const int row = rbase + (lane >> 2), slot = lane & 3;
+    int gr = r0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;
+    glds16(p + (size_t)gr * ld + k0 + ((slot ^ h) * TT<T>::EPF), lds + rbase * 64);
   }
 }
 
@@ -111,7 +130,7 @@ __device__ static __forceinline__ u32x4 frag_load(const char* lds, int t0, int l
   if constexpr (!KS) {
     return ld16(lds + kc_off(t0 + (lane & 15), lane >> 4));
   } else {
-    constexpr int STRIDE = R * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int STRIDE = LdsChunk<T, R, true>::KS_STRIDE;
     const int g = lane >> 4, i = lane & 15;
     u32x4 r;
     if constexpr (sizeof(T) == 2) {
@@ -137,25 +156,52 @@ __device__ static __forceinline__ u32x4 frag_load(const char* lds, int t0, int l
   }
 }
 
-template <class T, int BM, int BN, bool AKS, bool BKS>
+__device__ static __forceinline__ float gemm_epi_apply(const P5GemmArgs& g, float v, float auxv, uint32_t seed, bool do_drop, int row,
+                                                       int col) {
+  if (g.epi == P5_EPI_RELU_DROP) {
+    v = v > 0.f ? v : 0.f;
+    if (do_drop) v = p5_keep(seed, g.drop.site_key, (uint32_t)(row * g.N + col), g.drop.thr) ? v * g.drop.scale : 0.f;
+  } else if (g.epi == P5_EPI_RESID_DROP) {
+    if (do_drop) v = p5_keep(seed, g.drop.site_key, (uint32_t)(row * g.N + col), g.drop.thr) ? v * g.drop.scale : 0.f;
+    v += auxv;
+  } else if (g.epi == P5_EPI_MASK_POS) {
+    v = auxv > 0.f ? v : 0.f;
+  }
+  return v;
+}
+
+template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool BDMA>
 __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int KCH = TT<T>::KCH;
-  constexpr int ABYTES = LdsTile<T, AKS>::template bytes<BM>();
-  constexpr int BBYTES = LdsTile<T, BKS>::template bytes<BN>();
+  constexpr int ACH = LdsChunk<T, BM, AKS>::BYTES, BCH = LdsChunk<T, BN, BKS>::BYTES;
+  constexpr int STAGE = NCK * (ACH + BCH);
   constexpr int NA = AKS ? (KCH * (BM / TT<T>::EPF) / 256) : (BM * 4 / 256);
   constexpr int NB = BKS ? (KCH * (BN / TT<T>::EPF) / 256) : (BN * 4 / 256);
-  __shared__ __attribute__((aligned(16))) char lds[2 * (ABYTES + BBYTES)];
+  constexpr int CST = BN * 2 + 16;                    // LDS row stride of the staged bf16 C tile
+  constexpr int LDS_BYTES = (2 * STAGE > BM * CST) ? 2 * STAGE : BM * CST;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  // split-K range (in K-chunks)
-  const int nkc = (g.K + KCH - 1) / KCH;
-  const int per = (nkc + g.splitk - 1) / g.splitk;
-  const int kc_begin = blockIdx.z * per;
-  const int kc_end = (kc_begin + per < nkc) ? kc_begin + per : nkc;
-  if (kc_begin >= kc_end) return;
+  // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2): give every XCD a
+  // contiguous run of tiles -- n fastest inside an m row -- so the A panel of a row and the B panels are fetched from
+  // HBM once per XCD and then hit in its L2, instead of every workgroup streaming its own 2 x (tile x K) bytes.
+  int m0, n0;
+  {
+    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.x + blockIdx.y * gx;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (lid / gx) * BM;
+    n0 = (lid % gx) * BN;
+  }
+  // split-K range (in steps of NCK chunks)
+  const int nst = (g.K + KCH * NCK - 1) / (KCH * NCK);
+  const int per = (nst + g.splitk - 1) / g.splitk;
+  const int st_begin = blockIdx.z * per;
+  const int st_end = (st_begin + per < nst) ? st_begin + per : nst;
+  if (st_begin >= st_end) return;
 
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bp = (const T*)g.B;
@@ -166,42 +212,105 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[NA], rb[NB];
-  stage_load<T, BM, AKS>(ra, A, g.lda, m0, kc_begin * KCH, g.M, g.K, tid);
-  stage_load<T, BN, BKS>(rb, Bp, g.ldb, n0, kc_begin * KCH, g.N, g.K, tid);
-  stage_store<T, BM, AKS>(ra, lds, tid);
-  stage_store<T, BN, BKS>(rb, lds + ABYTES, tid);
+  static_assert(!(ADMA && AKS) && !(BDMA && BKS), "direct-to-LDS staging is for K-contiguous operands");
+  u32x4 ra[NCK][ADMA ? 1 : NA], rb[NCK][BDMA ? 1 : NB];
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    const int k0 = (st_begin * NCK + c) * KCH;
+    if constexpr (ADMA) stage_dma<T, BM>(lds + c * (ACH + BCH), A, g.lda, m0, k0, g.M, tid);
+    else stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
+    if constexpr (BDMA) stage_dma<T, BN>(lds + c * (ACH + BCH) + ACH, Bp, g.ldb, n0, k0, g.N, tid);
+    else stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
+  }
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * (ACH + BCH), tid);
+    if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], lds + c * (ACH + BCH) + ACH, tid);
+  }
   __syncthreads();
 
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const int cur = (kc - kc_begin) & 1;
-    char* la = lds + cur * (ABYTES + BBYTES);
-    char* lb = la + ABYTES;
-    const bool more = (kc + 1 < kc_end);
+  for (int st = st_begin; st < st_end; ++st) {
+    const int cur = (st - st_begin) & 1;
+    const char* base = lds + cur * STAGE;
+    const bool more = (st + 1 < st_end);
     if (more) {
-      stage_load<T, BM, AKS>(ra, A, g.lda, m0, (kc + 1) * KCH, g.M, g.K, tid);
-      stage_load<T, BN, BKS>(rb, Bp, g.ldb, n0, (kc + 1) * KCH, g.N, g.K, tid);
+      char* nb = lds + (cur ^ 1) * STAGE;   // last read in step st-1, which ended with a barrier
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        const int k0 = ((st + 1) * NCK + c) * KCH;
+        if constexpr (ADMA) stage_dma<T, BM>(nb + c * (ACH + BCH), A, g.lda, m0, k0, g.M, tid);
+        else stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
+        if constexpr (BDMA) stage_dma<T, BN>(nb + c * (ACH + BCH) + ACH, Bp, g.ldb, n0, k0, g.N, tid);
+        else stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
+      }
     }
-    u32x4 fa[TM], fb[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
+    for (int c = 0; c < NCK; ++c) {
+      const char* la = base + c * (ACH + BCH);
+      const char* lb = la + ACH;
+      u32x4 fa[TM], fb[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) fb[j] = frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+    }
     if (more) {
-      char* na = lds + (cur ^ 1) * (ABYTES + BBYTES);
-      stage_store<T, BM, AKS>(ra, na, tid);
-      stage_store<T, BN, BKS>(rb, na + ABYTES, tid);
+      char* nb = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], nb + c * (ACH + BCH), tid);
+        if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], nb + c * (ACH + BCH) + ACH, tid);
+      }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns C[row = (lane>>4)*4 + r][col = lane & 15] of every 16x16 tile ----
   const uint32_t seed = p5_seed(g.drop);
   const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
+
+  if constexpr (sizeof(T) == 2) {
+    if (!g.c_f32 && (g.N % 8) == 0 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0 &&
+        (g.aux == nullptr || ((g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0))) {
+      // ---- LDS-staged epilogue: accumulators -> bf16 tile in LDS -> 16-byte rows (aux reads + C writes) ----
+      // (the K loop ended with a barrier, so the staging buffers are free)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+            const int lc = wn * (BN / 2) + j * 16 + (lane & 15);
+            *(bf16*)(lds + lr * CST + lc * 2) = f2bf(acc[i][j][r] * g.alpha);
+          }
+      __syncthreads();
+      constexpr int PPR = BN / 8;                 // 16-byte pieces per tile row
+      constexpr int NPIECE = BM * PPR / 256;
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i) {
+        const int p = tid + i * 256;
+        const int lr = p / PPR, pc = p % PPR;
+        const int row = m0 + lr, col = n0 + pc * 8;
+        if (row >= g.M || col >= g.N) continue;
+        float v[8];
+        unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
+        if (g.epi != P5_EPI_STORE) {
+          float av[8];
+          if (g.aux) unpack16<bf16>(ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], g.aux ? av[e] : 0.f, seed, do_drop, row, col + e);
+        }
+        st16((bf16*)g.C + (size_t)row * g.ldc + col, pack16<bf16>(v));
+      }
+      return;
+    }
+  }
+
+  // ---- direct epilogue: lane owns C[row = (lane>>4)*4 + r][col = lane & 15] of every 16x16 tile ----
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -211,17 +320,10 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
         if (row >= g.M || col >= g.N) continue;
-        float v = acc[i][j][r] * g.alpha;
         const size_t ci = (size_t)row * g.ldc + col;
-        if (g.epi == P5_EPI_RELU_DROP) {
-          v = v > 0.f ? v : 0.f;
-          if (do_drop) v = p5_keep(seed, g.drop.site_key, (uint32_t)(row * g.N + col), g.drop.thr) ? v * g.drop.scale : 0.f;
-        } else if (g.epi == P5_EPI_RESID_DROP) {
-          if (do_drop) v = p5_keep(seed, g.drop.site_key, (uint32_t)(row * g.N + col), g.drop.thr) ? v * g.drop.scale : 0.f;
-          v += to_f<T>(((const T*)g.aux)[(size_t)row * g.ldaux + col]);
-        } else if (g.epi == P5_EPI_MASK_POS) {
-          v = to_f<T>(((const T*)g.aux)[(size_t)row * g.ldaux + col]) > 0.f ? v : 0.f;
-        }
+        float auxv = 0.f;
+        if (g.aux) auxv = to_f<T>(((const T*)g.aux)[(size_t)row * g.ldaux + col]);
+        const float v = gemm_epi_apply(g, acc[i][j][r] * g.alpha, auxv, seed, do_drop, row, col);
         if (g.epi == P5_EPI_ATOMIC) {
           atomicAdd(((float*)g.C) + ci, v);
         } else if (g.epi == P5_EPI_ACCUM) {

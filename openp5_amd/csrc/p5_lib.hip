@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 
 #include "p5_device.h"
 #include "p5_rng.h"
@@ -41,9 +42,13 @@ template <class T, int BM, int BN>
 static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
   const int mode = g.a_ks * 2 + g.b_ks;
-  if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false>), grid, block, 0, s, g);
-  else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true>), grid, block, 0, s, g);
-  else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true>), grid, block, 0, s, g);
+  // direct-to-LDS staging for K-contiguous operands whenever every K-step is full (fast-mode dtype only)
+  const bool dma = sizeof(T) == 2 && (g.K % (TT<T>::KCH * 2)) == 0;
+  if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
+  else if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false>), grid, block, 0, s, g);
+  else if (mode == 1 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, false>), grid, block, 0, s, g);
+  else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, false, false>), grid, block, 0, s, g);
+  else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, false, false>), grid, block, 0, s, g);
   else return fail("gemm: (A strided, B contiguous) is not instantiated");
   return P5_KCHECK();
 }
@@ -60,14 +65,17 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   if (g.b_ks) P5_REQUIRE(g.N % EPF == 0 || g.ldb >= ((g.N + EPF - 1) / EPF) * EPF, "gemm: B N-extent (KS)");
   if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm: accumulate epilogues need fp32 C");
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  const bool big = t128 >= 160;
+  static const int force_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;       // dev knobs
+  static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
+  // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
+  const bool big = force_tile ? force_tile == 128 : t128 >= 512;
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   if (g.splitk <= 0) {
     g.splitk = 1;
     if (g.epi == P5_EPI_ATOMIC) {
       const int nkc = (g.K + TT<T>::KCH - 1) / TT<T>::KCH;
-      int want = (int)((768 + tiles - 1) / tiles);
-      int maxs = nkc / 4 > 0 ? nkc / 4 : 1;
+      int want = (int)((split_target + tiles - 1) / tiles);
+      int maxs = nkc / 8 > 0 ? nkc / 8 : 1;
       g.splitk = want < maxs ? want : maxs;
       if (g.splitk < 1) g.splitk = 1;
     }
@@ -157,7 +165,7 @@ struct P5Engine {
   void *enc_x0 = nullptr, *enc_xf = nullptr, *enc_out = nullptr; float* enc_rstd_f = nullptr;
   int64_t* dec_ids = nullptr; void *dec_x0 = nullptr, *dec_xf = nullptr, *dec_hn = nullptr; float* dec_rstd_f = nullptr;
   float *logits = nullptr, *lse_tok = nullptr;
-  float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr;
+  float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr, *rel_partial = nullptr;
   void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
   bool d_enc_started = false;
 };
@@ -292,6 +300,8 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
   return P5_KCHECK();
 }
 
+static constexpr int REL_COPIES = 16;
+
 static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with_bwd) {
   const P5Config& c = e->c;
   const size_t sz = c.dtype == 1 ? 2 : 4;
@@ -346,6 +356,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->dres_b = (float*)b.take(Mx * d * 4);
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
+    e->rel_partial = (float*)b.take((size_t)2 * REL_COPIES * c.rel_buckets * H * 4);
     e->dy = b.take(Mx * d * sz);
     e->dn = b.take(Mx * d * sz);
     e->dqkv = b.take(Mx * 3 * in * sz);
@@ -499,7 +510,9 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa; a.dO = e->dO;
   a.dQ = e->dqkv; a.dK = (T*)e->dqkv + in; a.dV = (T*)e->dqkv + 2 * in; a.Dvec = e->Dvec;
   a.rel_table = e->P + (is_dec ? e->off_dec_rel : e->off_enc_rel);
-  a.d_rel_table = e->G + (is_dec ? e->off_dec_rel : e->off_enc_rel);
+  a.rel_stride = c.rel_buckets * H;
+  a.rel_copies = REL_COPIES;
+  a.d_rel_table = e->rel_partial + (is_dec ? (size_t)REL_COPIES * a.rel_stride : 0);
   a.bucket_lut = is_dec ? e->lut_dec : e->lut_enc; a.lut_half = e->lut_half; a.kmask = is_dec ? nullptr : e->mask;
   a.B = e->B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.lddo = in;
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
@@ -517,6 +530,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   const int nd = c.n_dec_layers, ne = c.n_enc_layers;
   if (stage == 0) {
     hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);
+    hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
               e->labels, dnll, c.vocab_size, e->Vp, e->Vp);
@@ -524,7 +538,15 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const float alpha = 1.0f / sqrtf((float)d);
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
     P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 1, e->dec_hn, d, 1, e->G + e->off_E, d, c.vocab_size, d, Md, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
-    P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dn, d, Md, d, c.vocab_size, P5_EPI_STORE, nullptr, 0, alpha, 0, no_drop()));
+    {
+      // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
+      hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
+      P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dres_b, d, Md, d, c.vocab_size, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+      const size_t n = (size_t)Md * d;
+      P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
+                (const float*)e->dres_b, n, no_drop());
+      P5_TRY(P5_KCHECK());
+    }
     e->dres_cur = e->dres_a;
     P5_TRY(swap_norm_bwd<T>(e, s, e->dec_xf, e->off_dec_fln, e->dec_rstd_f, Md, mk_drop(e, 1, 0, 7), mk_drop(e, 1, nd - 1, 6), false));
     return 0;
@@ -558,6 +580,9 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     return 0;
   }
   if (stage == nd + 1) {
+    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
+              (const float*)(e->rel_partial + (size_t)REL_COPIES * c.rel_buckets * H), c.rel_buckets * H, REL_COPIES);
+    P5_TRY(P5_KCHECK());
     P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, e->G + e->off_E, (float*)nullptr, (const float*)e->dres_cur,
               (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
     return P5_KCHECK();
@@ -582,6 +607,9 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     return 0;
   }
   if (stage == nd + ne + 3) {
+    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_enc_rel,
+              (const float*)e->rel_partial, c.rel_buckets * H, REL_COPIES);
+    P5_TRY(P5_KCHECK());
     P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, e->G + e->off_E, e->G + e->off_WW, (const float*)e->dres_cur,
               e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
     return P5_KCHECK();
@@ -732,6 +760,7 @@ int p5_engine_create(const P5Config* cfg, P5Engine** out) {
   P5_REQUIRE(cfg->d_ff % 64 == 0, "d_ff must be a multiple of 64");
   P5_REQUIRE(cfg->n_enc_layers >= 1 && cfg->n_enc_layers <= 64 && cfg->n_dec_layers >= 1 && cfg->n_dec_layers <= 64, "layer count");
   P5_REQUIRE(cfg->dtype == 0 || cfg->dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  P5_REQUIRE(cfg->rel_buckets >= 2 && cfg->rel_buckets <= 64, "relative_attention_num_buckets must be <= 64");
   P5Engine* e = new P5Engine();
   e->c = *cfg;
   e->inner = cfg->n_heads * cfg->d_kv;
@@ -896,7 +925,7 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
   a.Q = Q; a.K = K; a.V = V; a.O = (void*)O; a.dO = dO; a.lse = (float*)lse; a.Dvec = Dvec; a.dQ = dQ; a.dK = dK; a.dV = dV;
   a.rel_table = rel_table; a.d_rel_table = d_rel_table; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
-  a.lddv = lddv; a.causal = causal; a.drop = op_drop(rng_state, site, drop_p);
+  a.lddv = lddv; a.causal = causal; a.rel_copies = 1; a.rel_stride = 0; a.drop = op_drop(rng_state, site, drop_p);
   return dtype == 1 ? launch_attn_bwd<bf16>(a, (hipStream_t)stream) : launch_attn_bwd<float>(a, (hipStream_t)stream);
 }
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream) {

@@ -94,14 +94,20 @@ def rmsnorm_case(be, dtype, rows, d, seed=0):
     dres_out = dev(be, torch.zeros(rows, d))
     dy_next = dev(be, torch.zeros(rows, d, dtype=tt))
     dw = dev(be, torch.zeros(d))
-    be.check(be.lib.p5_op_rmsnorm_bwd(dtype, P(dres_out), P(dy_next), P(dw), P(dev(be, dy)), P(xd), P(wd), P(rd), P(dev(be, dres)), rows, d,
+    dyd, dresd = dev(be, dy), dev(be, dres)      # keep the device buffers alive across the launch
+    be.check(be.lib.p5_op_rmsnorm_bwd(dtype, P(dres_out), P(dy_next), P(dw), P(dyd), P(xd), P(wd), P(rd), P(dresd), rows, d,
                                       be.stream_ptr()), "rmsnorm_bwd")
     sync(be)
     tol = 1e-5 if dtype == 0 else 3e-2
-    assert (yd.cpu().float() - yr.detach()).abs().max() <= tol * 4
-    assert (dres_out.cpu() - (xr.grad + dres)).abs().max() <= tol * 8
-    assert (dw.cpu() - wr.grad).abs().max() <= tol * 8 * max(1.0, rows ** 0.5)
-    assert (dy_next.cpu().float() - dres_out.cpu()).abs().max() <= (1e-6 if dtype == 0 else 5e-2)
+    e_y = (yd.cpu().float() - yr.detach()).abs().max().item()
+    e_dx = (dres_out.cpu() - (xr.grad + dres)).abs().max().item()
+    e_dw = (dw.cpu() - wr.grad).abs().max().item()
+    e_nx = (dy_next.cpu().float() - dres_out.cpu()).abs().max().item()
+    msg = f"rmsnorm dtype={dtype} rows={rows} d={d}: y {e_y:.3e} dx {e_dx:.3e} dw {e_dw:.3e} next {e_nx:.3e}"
+    assert e_y <= tol * 4, msg
+    assert e_dx <= tol * 8, msg
+    assert e_dw <= tol * 8 * max(1.0, rows ** 0.5), msg
+    assert e_nx <= (1e-6 if dtype == 0 else 5e-2), msg
 
 
 def attn_ref(q, k, v, bias, mask_add, causal):
@@ -188,7 +194,8 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
         lddq, lddk, lddv = inner, 2 * inner, 2 * inner
     dtab = dev(be, torch.zeros(32, H)) if mode != "cross" else None
     Dv = dev(be, torch.zeros(B * H * Lq))
-    be.check(be.lib.p5_op_attn_bwd(dtype, P(Qd), P(Kd), P(Vd), P(Od), P(dev(be, dO)), P(lse), P(Dv), P(dQd), P(dKd), P(dVd), P(table_d),
+    dOd = dev(be, dO)
+    be.check(be.lib.p5_op_attn_bwd(dtype, P(Qd), P(Kd), P(Vd), P(Od), P(dOd), P(lse), P(Dv), P(dQd), P(dKd), P(dVd), P(table_d),
                                    P(dtab), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk, ldv, inner, lddq, lddk, lddv, causal, None,
                                    0, 0.0, be.stream_ptr()), "attn_bwd")
     sync(be)
