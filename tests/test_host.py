@@ -1,0 +1,216 @@
+"""not-gpu: host-side logic of the path (collator, trie, metrics, prompts, samplers, datasets) -- known-answer values
+from SURVEY.md App. D and, when /root/reference is present (build container only), equality with the reference's own
+modules run on the same inputs."""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from openp5_amd import evaluate
+from openp5_amd.collator import Collator, TestCollator, calculate_whole_word_ids
+from openp5_amd.data import MultiTaskDataset, TestDataset
+from openp5_amd.sampler import DistMultiDataTaskSampler, SingleMultiDataTaskSampler, parse_sampler_args
+from openp5_amd.synth import write_dataset, write_prompt_file
+from openp5_amd.tokenizer import build_offline_tokenizer
+from openp5_amd.trie import CompiledTrie, Trie, find_trie, prefix_allowed_tokens_fn
+from openp5_amd.utils import utils
+from openp5_amd.utils.prompt import get_info_from_prompt, load_prompt_template
+
+REF = "/root/reference/src/src_t5"
+HAVE_REF = os.path.isdir(REF)
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return build_offline_tokenizer()
+
+
+def ref_module(name):
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.append(REF)
+    import importlib
+    return importlib.import_module(name)
+
+
+def test_whole_word_ids_kat():
+    p1 = ['▁ML', '1', 'M', '▁user', '_', '12', '▁item', '_', '100', '1', '</s>', '<pad>', '<pad>']
+    assert calculate_whole_word_ids(p1, list(range(13))) == [1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 3, 0, 0]
+    p2 = ['▁ML', '1', 'M', '▁user', '_', '12', '▁item', '_', '100', '1', '▁,', '▁x', '</s>']
+    assert calculate_whole_word_ids(p2, list(range(13))) == [1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 5, 0]
+
+
+def test_collator_matches_scalar_definition(tok):
+    batch = [{"input": "What would ML1M user_12 be likely to purchase next after buying ML1M items item_1001 , item_1002 ?", "output": "ML1M item_1038"},
+             {"input": "What should we recommend for ML1M user_7 ?", "output": "ML1M item_2"},
+             {"input": "ML1M user_3 has purchased ML1M items item_5 , item_77 , item_1234", "output": "ML1M item_999", "user_idx": 3}]
+    ids, attn, ww, out_ids, out_attn = Collator(tok)(batch)
+    assert ids.dtype == torch.int64 and ids.shape == attn.shape == ww.shape
+    for r in range(ids.shape[0]):
+        pieces = tok.convert_ids_to_tokens(ids[r].tolist())
+        assert ww[r].tolist() == calculate_whole_word_ids(pieces, ids[r].tolist())
+    assert out_ids[0].tolist()[-1] in (0, 1) and out_attn.sum() > 0
+    for b in batch:
+        b.setdefault("user_idx", 0)
+    assert TestCollator(tok)(batch)[5].tolist() == [0, 0, 3]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present")
+def test_whole_word_ids_equals_reference(tok):
+    ref = ref_module("processor.Collator")
+    rnd = random.Random(0)
+    for _ in range(50):
+        n = rnd.randint(2, 30)
+        ids = [rnd.randint(3, 400) for _ in range(n)] + [1] + [0] * rnd.randint(0, 5)
+        pieces = tok.convert_ids_to_tokens(ids)
+        assert calculate_whole_word_ids(pieces, ids) == ref.calculate_whole_word_ids(pieces, ids)
+        got = Collator(tok).whole_word_ids(np.asarray([ids]))[0].tolist()
+        assert got == ref.calculate_whole_word_ids(pieces, ids)
+
+
+def test_trie_kat_and_csr():
+    t = Trie([[0, 5, 6, 1], [0, 5, 7, 1]])
+    assert t.get([0]) == [5] and sorted(t.get([0, 5])) == [6, 7] and t.get([0, 5, 6]) == [1]
+    assert t.get([0, 5, 6, 1]) == [] and t.get([0, 9]) == [] and len(t) == 2
+    ct = CompiledTrie.from_trie(t)
+    toks, nodes = ct.children(0)
+    assert toks.tolist() == [0]
+    toks, nodes = ct.children(int(nodes[0]))
+    assert toks.tolist() == [5]
+    toks, nodes = ct.children(int(nodes[0]))
+    assert toks.tolist() == [6, 7] and ct.max_children == 2
+    fn = prefix_allowed_tokens_fn(t)
+    assert fn(0, torch.tensor([0, 5])) == t.get([0, 5]) and find_trie(fn) is t
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present")
+def test_trie_equals_reference():
+    gt = ref_module("utils.generation_trie")
+    rnd = random.Random(1)
+    seqs = [[0] + [rnd.randint(2, 9) for _ in range(rnd.randint(1, 5))] + [1] for _ in range(200)]
+    a, b = Trie(seqs), gt.Trie(seqs)
+    assert len(a) == len(b)
+    for _ in range(500):
+        pre = rnd.choice(seqs)[: rnd.randint(0, 6)]
+        assert sorted(a.get(pre)) == sorted(b.get(pre))
+    assert find_trie(gt.prefix_allowed_tokens_fn(b)) is b      # the reference's closure is recognised -> device path
+
+
+def test_metrics_kat():
+    rel = evaluate.rel_results(['a', 'b', 'c', 'd'], ['b', 'x'], [-1, -2, -1.5, -3], 2)
+    assert rel == [[0, 1], [0, 0]]
+    res = evaluate.get_metrics_results(rel, ['hit@1', 'hit@2', 'ndcg@2'])
+    assert np.allclose(res, [0.0, 1.0, 0.63092975])
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present")
+def test_metrics_equal_reference():
+    ref = ref_module("utils.evaluate")
+    rnd = random.Random(2)
+    k, B = 10, 30
+    preds = [f"i{rnd.randint(0, 40)}" for _ in range(B * k)]
+    gold = [f"i{rnd.randint(0, 40)}" for _ in range(B)]
+    scores = [rnd.random() for _ in range(B * k)]
+    assert evaluate.rel_results(preds, gold, scores, k) == ref.rel_results(preds, gold, scores, k)
+    ms = ['hit@5', 'hit@10', 'ndcg@5', 'ndcg@10']
+    rel = evaluate.rel_results(preds, gold, scores, k)
+    assert np.allclose(evaluate.get_metrics_results(rel, ms), ref.get_metrics_results(rel, ms))
+    pos = {f"u{b}": set(rnd.sample(preds, 5)) for b in range(B)}
+    id2user = {b: f"u{b}" for b in range(B)}
+    a = evaluate.rel_results_filtered(pos, id2user, list(range(B)), k, preds, gold, scores, 5)
+    b_ = ref.rel_results_filtered(pos, id2user, list(range(B)), k, preds, gold, scores, 5)
+    assert a == b_
+
+
+def make_args(tmp, extra=()):
+    parser = argparse.ArgumentParser()
+    utils.parse_global_args(parser)
+    MultiTaskDataset.parse_dataset_args(parser)
+    parse_sampler_args(parser)
+    from openp5_amd.runner import parse_runner_args
+    parse_runner_args(parser)
+    prompt = write_prompt_file(os.path.join(tmp, "prompt.txt"))
+    write_dataset(os.path.join(tmp, "data"), "Toy")
+    args = parser.parse_args(["--data_path", os.path.join(tmp, "data"), "--datasets", "Toy", "--tasks", "sequential,straightforward",
+                              "--item_indexing", "sequential", "--prompt_file", prompt, "--sample_prompt", "1", "--sample_num", "3,3",
+                              "--max_his", "20", "--distributed", "0", "--batch_size", "4", "--eval_batch_size", "5"] + list(extra))
+    args.rank = 0
+    return args
+
+
+def test_prompt_and_dataset(tmp_path):
+    args = make_args(str(tmp_path))
+    tpl = load_prompt_template(args.prompt_file, ["sequential", "straightforward"])
+    assert set(tpl) == {"sequential", "straightforward"} and "0" in tpl["sequential"]["seen"] and "0" in tpl["sequential"]["unseen"]
+    assert set(get_info_from_prompt(tpl)) == {"dataset", "user_id", "history", "target"}
+    random.seed(0)
+    ds = MultiTaskDataset(args, "Toy", "train")
+    n = len(ds.data_samples)
+    assert len(ds) == 6 * n and ds.task_index == [3 * n, 6 * n]
+    assert sorted(ds.item_map.values())[0] == "1001"
+    s = ds[0]
+    assert s["output"].startswith("Toy item_") and "Toy user_1 " in s["input"]
+    td = TestDataset(argparse.Namespace(**{**vars(args), "test_filtered": 0}), "Toy", "sequential")
+    assert len(td) == 30 and td[0]["output"].startswith("Toy item_")
+    # leave-one-out: the test target is the user's last item, validation target the one before
+    last = ds.reindex_user_seq_dict["1"][-1]
+    assert td[0]["output"] == f"Toy item_{last}"
+    assert os.path.exists(os.path.join(args.data_path, "Toy", "user_sequence_sequential_indexing_original.txt"))
+
+
+def test_samplers(tmp_path):
+    from torch.utils.data import ConcatDataset
+    args = make_args(str(tmp_path))
+    random.seed(0)
+    ds = MultiTaskDataset(args, "Toy", "train")
+    cat = ConcatDataset([ds])
+    n = len(ds.data_samples)
+    s = SingleMultiDataTaskSampler(cat, 4, seed=2023)
+    s.set_epoch(0)
+    idx = list(iter(s))
+    assert len(idx) == len(s)
+    for i in range(0, len(idx), 4):             # task-homogeneous batches, alternating tasks
+        grp = idx[i:i + 4]
+        assert all(g < 3 * n for g in grp) or all(g >= 3 * n for g in grp)
+        assert (grp[0] >= 3 * n) == ((i // 4) % 2 == 1)
+    # disjoint strided shards over two ranks (separate dataset copies, as in real multi-process runs)
+    shards = []
+    for r in range(2):
+        random.seed(0)
+        d = MultiTaskDataset(args, "Toy", "train")
+        sm = DistMultiDataTaskSampler(ConcatDataset([d]), 4, 2, r, seed=2023)
+        sm.set_epoch(0)
+        shards.append(list(iter(sm)))
+    assert len(shards[0]) == len(shards[1])
+    assert set(shards[0]) | set(shards[1]) == set(range(6 * n))
+    assert len(set(shards[0]) & set(shards[1])) == 0
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not present")
+def test_dataset_and_sampler_equal_reference(tmp_path):
+    """Same toy data + flags through the reference's own MultiTaskDataset / TestDataset / samplers."""
+    from torch.utils.data import ConcatDataset
+    RD = ref_module("data.MultiTaskDataset")
+    RT = ref_module("data.TestDataset")
+    RS = ref_module("processor.DistMultiDataTaskSampler")
+    a1 = make_args(str(tmp_path / "a"))
+    a2 = make_args(str(tmp_path / "b"))
+    for a in (a1, a2):
+        a.test_filtered = 0
+    random.seed(5)
+    mine = MultiTaskDataset(a1, "Toy", "train")
+    random.seed(5)
+    ref = RD.MultiTaskDataset(a2, "Toy", "train")
+    assert mine.data["input"] == ref.data["input"] and mine.data["output"] == ref.data["output"]
+    assert mine.task_index == ref.task_index and mine.item_map == ref.item_map
+    tm, tr = TestDataset(a1, "Toy", "straightforward"), RT.TestDataset(a2, "Toy", "straightforward")
+    assert tm.data == tr.data and tm.all_items == tr.all_items
+    for epoch in (0, 1):
+        sm = DistMultiDataTaskSampler(ConcatDataset([mine]), 4, 2, 1, seed=2023)
+        sr = RS.DistMultiDataTaskSampler(ConcatDataset([ref]), 4, 2, 1, seed=2023)
+        sm.set_epoch(epoch); sr.set_epoch(epoch)
+        assert list(iter(sm)) == list(iter(sr)) and len(sm) == len(sr)
