@@ -56,6 +56,8 @@ int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t
 int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const int* lut_enc, const int* lut_dec,
                    int lut_half, uint32_t* rng_state);
 int p5_refresh_shadow(P5Engine* e, void* stream);
+/* optional second stream: weight-gradient GEMMs run on it, one sub-layer behind the dgrad chain (NULL = single stream) */
+int p5_engine_set_side_stream(P5Engine* e, void* side_stream);
 
 /* ---- training step pieces ---- */
 int64_t p5_train_workspace_bytes(const P5Engine* e, int B, int L, int T);

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "p5_param_table": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "p5_engine_bind": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "p5_refresh_shadow": (i32, [vp, vp]),
+    "p5_engine_set_side_stream": (i32, [vp, vp]),
     "p5_train_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "p5_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp]),
     "p5_backward_num_stages": (i32, [vp]),

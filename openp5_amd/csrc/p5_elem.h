@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < d; j += 256) {
+  // every workgroup starts its flush at a different column so that concurrent workgroups hit different addresses
+  for (int j0 = threadIdx.x; j0 < d; j0 += 256) {
+    const int j = (j0 + (int)(blockIdx.x % 8u) * 64) % d;
     const float v = sdw[0][j] + sdw[1][j] + sdw[2][j] + sdw[3][j];
     if (v != 0.f) atomicAdd(dw + j, v);
   }

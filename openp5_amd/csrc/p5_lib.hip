@@ -167,8 +167,61 @@ struct P5Engine {
   float *logits = nullptr, *lse_tok = nullptr;
   float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr, *rel_partial = nullptr;
   void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
+  // two sets of the temporaries the wgrad GEMMs read, alternated per sub-layer, so the side stream can run one
+  // sub-layer behind the dgrad chain without a write-after-read hazard
+  void *dy2[2] = {nullptr, nullptr}, *dh2[2] = {nullptr, nullptr}, *du2[2] = {nullptr, nullptr}, *dqkv2[2] = {nullptr, nullptr},
+       *dkv2[2] = {nullptr, nullptr};
+  void* dy_next = nullptr;
+  int sub = -1;
   bool d_enc_started = false;
+  // optional second stream for the weight-gradient GEMMs (off the critical dgrad chain)
+  hipStream_t side = nullptr;
+#ifndef P5_EMU
+  hipEvent_t ev_pool[32];
+  hipEvent_t side_done[2];
+  bool side_done_valid[2] = {false, false};
+  int ev_next = 0;
+#endif
 };
+
+static void begin_sublayer(P5Engine* e) {
+  e->sub++;
+  const int p = e->sub & 1;
+  e->dy = e->dy2[p]; e->dy_next = e->dy2[1 - p];
+  e->dh = e->dh2[p]; e->du = e->du2[p]; e->dqkv = e->dqkv2[p]; e->dkv = e->dkv2[p];
+}
+// side stream waits for everything enqueued on `main` so far
+static void fork_to_side(P5Engine* e, hipStream_t main) {
+#ifndef P5_EMU
+  if (!e->side) return;
+  hipEvent_t ev = e->ev_pool[e->ev_next++ & 31];
+  hipEventRecord(ev, main);
+  hipStreamWaitEvent(e->side, ev, 0);
+#endif
+}
+static void join_side(P5Engine* e, hipStream_t main) {
+#ifndef P5_EMU
+  if (!e->side) return;
+  hipEvent_t ev = e->ev_pool[e->ev_next++ & 31];
+  hipEventRecord(ev, e->side);
+  hipStreamWaitEvent(main, ev, 0);
+#endif
+}
+// called right before the norm backward that ends sub-layer `sub` (and overwrites the other dy set)
+static void end_sublayer_sync(P5Engine* e, hipStream_t main) {
+#ifndef P5_EMU
+  if (!e->side) return;
+  const int p = e->sub & 1;
+  hipEventRecord(e->side_done[p], e->side);          // all wgrads of this sub-layer are enqueued
+  e->side_done_valid[p] = true;
+  if (e->side_done_valid[1 - p]) hipStreamWaitEvent(main, e->side_done[1 - p], 0);   // wgrads of the previous sub-layer
+#endif
+}
+static hipStream_t wgrad_stream(P5Engine* e, hipStream_t main) {
+  if (!e->side) return main;
+  fork_to_side(e, main);
+  return e->side;
+}
 
 static void add_param(P5Engine* e, const std::string& name, int rows, int cols, int64_t& off_out) {
   // every tensor starts on a 64-element boundary so 16-byte vector accesses stay aligned in both dtypes
@@ -278,9 +331,15 @@ static int linear_dgrad(hipStream_t s, const void* dy, int lddy, const T* W, voi
 }
 // dW += dy^T x   (fp32 atomics into the grad arena)
 template <class T>
-static int linear_wgrad(hipStream_t s, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
+static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
                         float alpha = 1.f) {
   return gemm<T>(s, dy, lddy, 1, x, ldx, 1, dW, K_in, N_out, K_in, M, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop());
+}
+
+template <class T>
+static int linear_wgrad(P5Engine* e, hipStream_t main, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
+                        float alpha = 1.f) {
+  return linear_wgrad_on<T>(wgrad_stream(e, main), dy, lddy, x, ldx, dW, M, N_out, K_in, alpha);
 }
 
 template <class T>
@@ -294,7 +353,7 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
                        const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext) {
   P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
   int blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;
   P5_LAUNCH((p5_rmsnorm_bwd_kernel<T>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd,
             dres_in, rows, d, din, dnext);
   return P5_KCHECK();
@@ -357,13 +416,16 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
     e->rel_partial = (float*)b.take((size_t)2 * REL_COPIES * c.rel_buckets * H * 4);
-    e->dy = b.take(Mx * d * sz);
     e->dn = b.take(Mx * d * sz);
-    e->dqkv = b.take(Mx * 3 * in * sz);
-    e->dkv = b.take(M * 2 * in * sz);
     e->dO = b.take(Mx * in * sz);
-    e->dh = b.take(Mx * F * sz);
-    e->du = c.gated_gelu ? b.take(Mx * 2 * F * sz) : nullptr;
+    for (int p = 0; p < 2; ++p) {
+      e->dy2[p] = b.take(Mx * d * sz);
+      e->dqkv2[p] = b.take(Mx * 3 * in * sz);
+      e->dkv2[p] = b.take(M * 2 * in * sz);
+      e->dh2[p] = b.take(Mx * F * sz);
+      e->du2[p] = c.gated_gelu ? b.take(Mx * 2 * F * sz) : nullptr;
+    }
+    e->dy = e->dy2[0]; e->dqkv = e->dqkv2[0]; e->dkv = e->dkv2[0]; e->dh = e->dh2[0]; e->du = e->du2[0];
     e->dlogits = b.take(Md * Vp * sz);
   }
   return (int64_t)((b.off + 255) & ~(size_t)255);
@@ -472,18 +534,18 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
   const P5Config& c = e->c;
   const int d = c.d_model, F = c.d_ff;
   const float hscale = (e->training && c.dropout > 0.f) ? 1.f / (1.f - c.dropout) : 1.f;
-  P5_TRY(linear_wgrad<T>(s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
+  P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
   if (c.gated_gelu) {
     P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F));
     const size_t n = (size_t)rows * F;
     P5_LAUNCH((p5_gated_gelu_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
               (T*)e->du, (const T*)e->dh, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
     P5_TRY(P5_KCHECK());
-    P5_TRY(linear_wgrad<T>(s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
+    P5_TRY(linear_wgrad<T>(e, s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
     P5_TRY(linear_dgrad<T>(s, e->du, 2 * F, Wc<T>(e, lo.wi), e->dn, d, rows, 2 * F, d));
   } else {
     P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F, P5_EPI_MASK_POS, l.h_ff, F, hscale));
-    P5_TRY(linear_wgrad<T>(s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
+    P5_TRY(linear_wgrad<T>(e, s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
     P5_TRY(linear_dgrad<T>(s, e->dh, F, Wc<T>(e, lo.wi), e->dn, d, rows, F, d));
   }
   return 0;
@@ -493,7 +555,8 @@ template <class T>
 static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_off, const float* rstd, int rows, P5Drop din, P5Drop dnext,
                          bool has_res_in = true) {
   float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
-  P5_TRY(rmsnorm_bwd<T>(s, out, e->dy, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows,
+  end_sublayer_sync(e, s);
+  P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows,
                         e->c.d_model, din, dnext));
   e->dres_cur = out;
   return 0;
@@ -503,7 +566,7 @@ template <class T>
 static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int Lq, bool is_dec, int li) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads;
-  P5_TRY(linear_wgrad<T>(s, e->dy, d, l.o_sa, in, e->G + lo.sa.o, rows, d, in));
+  P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_sa, in, e->G + lo.sa.o, rows, d, in));
   P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.sa.o), e->dO, in, rows, d, in));
   P5AttnArgs a;
   memset(&a, 0, sizeof(a));
@@ -518,7 +581,7 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
   a.drop = mk_drop(e, is_dec ? 1 : 0, li, 1);
   P5_TRY(launch_attn_bwd<T>(a, s));
-  P5_TRY(linear_wgrad<T>(s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
+  P5_TRY(linear_wgrad<T>(e, s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
   P5_TRY(linear_dgrad<T>(s, e->dqkv, 3 * in, Wc<T>(e, lo.sa.q), e->dn, d, rows, 3 * in, d));
   return 0;
 }
@@ -532,12 +595,17 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);
     hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
+    e->sub = -1;
+#ifndef P5_EMU
+    e->side_done_valid[0] = e->side_done_valid[1] = false;
+#endif
+    begin_sublayer(e);
     P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
               e->labels, dnll, c.vocab_size, e->Vp, e->Vp);
     P5_TRY(P5_KCHECK());
     const float alpha = 1.0f / sqrtf((float)d);
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
-    P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 1, e->dec_hn, d, 1, e->G + e->off_E, d, c.vocab_size, d, Md, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+    P5_TRY(gemm<T>(wgrad_stream(e, s), e->dlogits, e->Vp, 1, e->dec_hn, d, 1, e->G + e->off_E, d, c.vocab_size, d, Md, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
     {
       // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
       hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
@@ -555,10 +623,12 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const int i = nd - stage;
     const LayerOff& lo = e->dec[i];
     LayerSave& l = e->ds[i];
+    begin_sublayer(e);
     P5_TRY(ffn_bwd<T>(e, s, lo, l, Md, 1, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4)));
     // cross attention
-    P5_TRY(linear_wgrad<T>(s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
+    begin_sublayer(e);
+    P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
     P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.ca.o), e->dO, in, Md, d, in));
     P5AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -567,14 +637,15 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     a.kmask = e->mask; a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = 2 * in; a.ldo = in; a.lddo = in;
     a.lddq = in; a.lddk = a.lddv = 2 * in; a.causal = 0; a.drop = mk_drop(e, 1, i, 3);
     P5_TRY(launch_attn_bwd<T>(a, s));
-    P5_TRY(linear_wgrad<T>(s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
+    P5_TRY(linear_wgrad<T>(e, s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
     P5_TRY(linear_dgrad<T>(s, e->dqkv, in, Wc<T>(e, lo.ca.q), e->dn, d, Md, in, d));
-    P5_TRY(linear_wgrad<T>(s, e->dkv, 2 * in, e->enc_out, d, e->G + lo.ca.k, M, 2 * in, d));
+    P5_TRY(linear_wgrad<T>(e, s, e->dkv, 2 * in, e->enc_out, d, e->G + lo.ca.k, M, 2 * in, d));
     P5_TRY(linear_dgrad<T>(s, e->dkv, 2 * in, Wc<T>(e, lo.ca.k), e->d_enc, d, M, 2 * in, d,
                            e->d_enc_started ? P5_EPI_ACCUM : P5_EPI_STORE, nullptr, 0, 1.f, 1));
     e->d_enc_started = true;
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
     // self attention
+    begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
     return 0;
@@ -593,6 +664,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
               (const float*)e->d_enc, n, no_drop());
     P5_TRY(P5_KCHECK());
     e->dres_cur = e->dres_a;
+    begin_sublayer(e);
     P5_TRY(swap_norm_bwd<T>(e, s, e->enc_xf, e->off_enc_fln, e->enc_rstd_f, M, mk_drop(e, 0, 0, 7), mk_drop(e, 0, ne - 1, 6), false));
     return 0;
   }
@@ -600,8 +672,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const int i = ne - (stage - (nd + 2));
     const LayerOff& lo = e->enc[i];
     LayerSave& l = e->es[i];
+    begin_sublayer(e);
     P5_TRY(ffn_bwd<T>(e, s, lo, l, M, 0, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2)));
+    begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
     return 0;
@@ -814,8 +888,25 @@ int p5_backward_num_stages(const P5Engine* e) { return e->c.n_dec_layers + e->c.
 int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   P5_REQUIRE(e->G, "no gradient arena bound");
   P5_REQUIRE(e->Md > 0, "p5_forward must run first");
-  return e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
-                         : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream);
+  P5_TRY(e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
+                         : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream));
+  // the side stream is now ordered after this stage's main-stream work (a bucket all-reduce enqueued behind the side
+  // stream sees every gradient of the stage); after the last stage the main stream waits for the side stream
+  fork_to_side(e, (hipStream_t)stream);
+  if (stage == p5_backward_num_stages(e) - 1) join_side(e, (hipStream_t)stream);
+  return 0;
+}
+int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
+#ifndef P5_EMU
+  if (side_stream && !e->side) {
+    for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming);
+    for (int i = 0; i < 2; ++i) hipEventCreateWithFlags(&e->side_done[i], hipEventDisableTiming);
+  }
+  e->side = (hipStream_t)side_stream;
+#else
+  (void)e; (void)side_stream;
+#endif
+  return 0;
 }
 int p5_backward(P5Engine* e, const float* dnll, void* stream) {
   const int n = p5_backward_num_stages(e);

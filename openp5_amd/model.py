@@ -17,6 +17,7 @@ contiguous buckets issued while the backward is still running.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 from dataclasses import dataclass
@@ -117,6 +118,7 @@ class _P5LossFn(torch.autograd.Function):
 
 class P5T5Native(nn.Module):
     LUT_HALF = 512
+    use_side_stream = True
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
         super().__init__()
@@ -138,6 +140,7 @@ class P5T5Native(nn.Module):
         self.ddp_world = 1          # set by the runner: gradient all-reduce across ranks during backward
         self.ddp_group = None
         self._pending = []
+        self._side = None
         self._build(seed)
 
     # ------------------------------------------------------------------ engine / arena plumbing
@@ -208,6 +211,11 @@ class P5T5Native(nn.Module):
     def _bind(self):
         self._be.check(self._lib.p5_engine_bind(self._engine, _ptr(self._flat), _ptr(self._grads), _ptr(self._shadow), _ptr(self._lut_enc),
                                                  _ptr(self._lut_dec), self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind")
+        if not self._be.is_emulator and self.use_side_stream:
+            # weight-gradient GEMMs run on a second HIP stream, off the dgrad critical path
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self._be.device)
+            self._lib.p5_engine_set_side_stream(self._engine, ctypes.c_void_p(self._side.cuda_stream))
 
     @torch.no_grad()
     def _init_weights(self, seed):
@@ -404,7 +412,11 @@ class P5T5Native(nn.Module):
                 self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
                 lib.p5_backward_stage_range(eng, st, ctypes.byref(b), ctypes.byref(e))
                 if e.value > b.value:
-                    self._pending.append(dist.all_reduce(self._grads[b.value:e.value], op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True))
+                    # enqueue behind the side stream when there is one: it is ordered after this stage's main-stream work
+                    # AND carries the stage's weight-gradient GEMMs
+                    ctx = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
+                    with ctx:
+                        self._pending.append(dist.all_reduce(self._grads[b.value:e.value], op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True))
             for w in self._pending:
                 w.wait()
             self._pending = []
