@@ -152,6 +152,14 @@ __device__ static __forceinline__ void glds16(const void* g, char* lds_wave_base
 }
 #endif
 
+// compiler scheduling fence: nothing is moved across it (used to keep an end-of-step barrier BELOW the MFMAs it follows
+// in program order -- hipcc otherwise hoists "s_waitcnt vmcnt(0); s_barrier" above them and serialises copy and math)
+#ifdef P5_EMU
+#define P5_SCHED_FENCE() ((void)0)
+#else
+#define P5_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll

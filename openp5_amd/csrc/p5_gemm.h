@@ -106,22 +106,30 @@ __device__ static __forceinline__ void stage_store(const u32x4* regs, char* lds,
   }
 }
 
-// KC chunk straight from HBM into LDS (no VGPR round trip, no ds_write): each wave instruction fills 16 rows x 64 B.
-// The XOR swizzle of kc_off() is applied on the SOURCE address (the LDS image of a wave instruction is linear).
-// Rows past the matrix edge are clamped: they only feed C rows/cols that are never stored.  Needs K % KCH == 0.
+// K-contiguous operand straight from HBM into LDS (no VGPR round trip, no ds_write).  One K-step = 128 bytes per row
+// (two 64-byte chunks), so every wave instruction copies 8 rows x 128 B = whole cache lines; with 64-byte row
+// segments each 128-byte line would be requested twice through the per-CU vector-memory path, which is the limiter of
+// these GEMMs.  LDS image = [R][128 B]; the 16-byte slot index is XOR-ed with (row & 7) -- applied on the
+// SOURCE address, since a wave instruction's LDS image is linear -- which makes every ds_read_b128 lane group
+// conflict-free.  Rows past the matrix edge are clamped (they only feed C rows/cols that are never stored).
+// Needs K % (2*KCH) == 0.
 template <class T, int R>
-__device__ static __forceinline__ void stage_dma(char* lds, const T* __restrict__ p, int ld, int r0, int k0, int nrows, int tid) {
-  constexpr int NI = R / 64;
+__device__ static __forceinline__ void stage_dma128(char* lds, const T* __restrict__ p, int ld, int r0, int k0, int nrows, int tid) {
+  constexpr int NI = R / 32;                       // wave instructions per wave: R*128 B / (4 waves * 1 KiB)
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int rbase = (wave * NI + i) * 16;
-    const int row = rbase + (lane >> 2), slot = lane & 3;
+    const int rbase = (wave * NI + i) * 8;
+    const int row = rbase + (lane >> 3), slot = lane & 7;
     int gr = r0 + row;
     gr = gr < nrows ? gr : nrows - 1;
-    const int h = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;
-    glds16(p + (size_t)gr * ld + k0 + ((slot ^ h) * TT<T>::EPF), lds + rbase * 64);
+    glds16(p + (size_t)gr * ld + k0 + ((slot ^ (row & 7)) * TT<T>::EPF), lds + rbase * 128);
   }
+}
+template <class T>
+__device__ static __forceinline__ u32x4 frag_load_kc128(const char* lds, int t0, int c, int lane) {
+  const int row = t0 + (lane & 15);
+  return ld16(lds + row * 128 + ((((c << 2) | (lane >> 4)) ^ (row & 7)) << 4));
 }
 
 // one 16-row fragment (rows t0..t0+15 of the tile) for this lane
@@ -170,105 +178,13 @@ __device__ static __forceinline__ float gemm_epi_apply(const P5GemmArgs& g, floa
   return v;
 }
 
-template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool BDMA>
-__global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
+template <class T, int BM, int BN, int LDSB>
+__device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* lds, int m0, int n0, int tid) {
   constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int KCH = TT<T>::KCH;
-  constexpr int ACH = LdsChunk<T, BM, AKS>::BYTES, BCH = LdsChunk<T, BN, BKS>::BYTES;
-  constexpr int STAGE = NCK * (ACH + BCH);
-  constexpr int NA = AKS ? (KCH * (BM / TT<T>::EPF) / 256) : (BM * 4 / 256);
-  constexpr int NB = BKS ? (KCH * (BN / TT<T>::EPF) / 256) : (BN * 4 / 256);
   constexpr int CST = BN * 2 + 16;                    // LDS row stride of the staged bf16 C tile
-  constexpr int LDS_BYTES = (2 * STAGE > BM * CST) ? 2 * STAGE : BM * CST;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(LDSB >= BM * CST, "LDS buffer too small for the staged C tile");
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2): give every XCD a
-  // contiguous run of tiles -- n fastest inside an m row -- so the A panel of a row and the B panels are fetched from
-  // HBM once per XCD and then hit in its L2, instead of every workgroup streaming its own 2 x (tile x K) bytes.
-  int m0, n0;
-  {
-    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
-    const int bid = blockIdx.x + blockIdx.y * gx;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    m0 = (lid / gx) * BM;
-    n0 = (lid % gx) * BN;
-  }
-  // split-K range (in steps of NCK chunks)
-  const int nst = (g.K + KCH * NCK - 1) / (KCH * NCK);
-  const int per = (nst + g.splitk - 1) / g.splitk;
-  const int st_begin = blockIdx.z * per;
-  const int st_end = (st_begin + per < nst) ? st_begin + per : nst;
-  if (st_begin >= st_end) return;
-
-  const T* __restrict__ A = (const T*)g.A;
-  const T* __restrict__ Bp = (const T*)g.B;
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  static_assert(!(ADMA && AKS) && !(BDMA && BKS), "direct-to-LDS staging is for K-contiguous operands");
-  u32x4 ra[NCK][ADMA ? 1 : NA], rb[NCK][BDMA ? 1 : NB];
-#pragma unroll
-  for (int c = 0; c < NCK; ++c) {
-    const int k0 = (st_begin * NCK + c) * KCH;
-    if constexpr (ADMA) stage_dma<T, BM>(lds + c * (ACH + BCH), A, g.lda, m0, k0, g.M, tid);
-    else stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
-    if constexpr (BDMA) stage_dma<T, BN>(lds + c * (ACH + BCH) + ACH, Bp, g.ldb, n0, k0, g.N, tid);
-    else stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
-  }
-#pragma unroll
-  for (int c = 0; c < NCK; ++c) {
-    if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * (ACH + BCH), tid);
-    if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], lds + c * (ACH + BCH) + ACH, tid);
-  }
-  __syncthreads();
-
-  for (int st = st_begin; st < st_end; ++st) {
-    const int cur = (st - st_begin) & 1;
-    const char* base = lds + cur * STAGE;
-    const bool more = (st + 1 < st_end);
-    if (more) {
-      char* nb = lds + (cur ^ 1) * STAGE;   // last read in step st-1, which ended with a barrier
-#pragma unroll
-      for (int c = 0; c < NCK; ++c) {
-        const int k0 = ((st + 1) * NCK + c) * KCH;
-        if constexpr (ADMA) stage_dma<T, BM>(nb + c * (ACH + BCH), A, g.lda, m0, k0, g.M, tid);
-        else stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
-        if constexpr (BDMA) stage_dma<T, BN>(nb + c * (ACH + BCH) + ACH, Bp, g.ldb, n0, k0, g.N, tid);
-        else stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCK; ++c) {
-      const char* la = base + c * (ACH + BCH);
-      const char* lb = la + ACH;
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
-    }
-    if (more) {
-      char* nb = lds + (cur ^ 1) * STAGE;
-#pragma unroll
-      for (int c = 0; c < NCK; ++c) {
-        if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], nb + c * (ACH + BCH), tid);
-        if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], nb + c * (ACH + BCH) + ACH, tid);
-      }
-    }
-    __syncthreads();
-  }
-
   const uint32_t seed = p5_seed(g.drop);
   const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
 
@@ -337,3 +253,110 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
     }
   }
 }
+
+template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool BDMA>
+__global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int KCH = TT<T>::KCH;
+  constexpr int ACH = LdsChunk<T, BM, AKS>::BYTES, BCH = LdsChunk<T, BN, BKS>::BYTES;
+  constexpr int STAGE = NCK * (ACH + BCH);
+  constexpr int NA = AKS ? (KCH * (BM / TT<T>::EPF) / 256) : (BM * 4 / 256);
+  constexpr int NB = BKS ? (KCH * (BN / TT<T>::EPF) / 256) : (BN * 4 / 256);
+  constexpr int CST = BN * 2 + 16;                    // LDS row stride of the staged bf16 C tile
+  constexpr int LDS_BYTES = (2 * STAGE > BM * CST) ? 2 * STAGE : BM * CST;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2): give every XCD a
+  // contiguous run of tiles -- n fastest inside an m row -- so the A panel of a row and the B panels are fetched from
+  // HBM once per XCD and then hit in its L2, instead of every workgroup streaming its own 2 x (tile x K) bytes.
+  int m0, n0;
+  {
+    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.x + blockIdx.y * gx;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (lid / gx) * BM;
+    n0 = (lid % gx) * BN;
+  }
+  // split-K range (in steps of NCK chunks)
+  const int nst = (g.K + KCH * NCK - 1) / (KCH * NCK);
+  const int per = (nst + g.splitk - 1) / g.splitk;
+  const int st_begin = blockIdx.z * per;
+  const int st_end = (st_begin + per < nst) ? st_begin + per : nst;
+  if (st_begin >= st_end) return;
+
+  const T* __restrict__ A = (const T*)g.A;
+  const T* __restrict__ Bp = (const T*)g.B;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  static_assert(!(ADMA && AKS) && !(BDMA && BKS), "direct-to-LDS staging is for K-contiguous operands");
+  static_assert(!(ADMA || BDMA) || NCK == 2, "direct-to-LDS staging copies 128-byte rows = two K-chunks per step");
+  u32x4 ra[NCK][ADMA ? 1 : NA], rb[NCK][BDMA ? 1 : NB];
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    const int k0 = (st_begin * NCK + c) * KCH;
+    if constexpr (!ADMA) stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
+    if constexpr (!BDMA) stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
+  }
+  if constexpr (ADMA) stage_dma128<T, BM>(lds, A, g.lda, m0, st_begin * NCK * KCH, g.M, tid);
+  if constexpr (BDMA) stage_dma128<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
+#pragma unroll
+  for (int c = 0; c < NCK; ++c) {
+    if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * ACH, tid);
+    if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], lds + NCK * ACH + c * BCH, tid);
+  }
+  __syncthreads();
+
+  for (int st = st_begin; st < st_end; ++st) {
+    const int cur = (st - st_begin) & 1;
+    const char* base = lds + cur * STAGE;
+    const bool more = (st + 1 < st_end);
+    if (more) {
+      char* nb = lds + (cur ^ 1) * STAGE;   // last read in step st-1, which ended with a barrier
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        const int k0 = ((st + 1) * NCK + c) * KCH;
+        if constexpr (!ADMA) stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
+        if constexpr (!BDMA) stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
+      }
+      if constexpr (ADMA) stage_dma128<T, BM>(nb, A, g.lda, m0, (st + 1) * NCK * KCH, g.M, tid);
+      if constexpr (BDMA) stage_dma128<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
+    }
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+      const char* la = base + c * ACH;
+      const char* lb = base + NCK * ACH + c * BCH;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = ADMA ? frag_load_kc128<T>(base, wm * (BM / 2) + i * 16, c, lane) : frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = BDMA ? frag_load_kc128<T>(base + NCK * ACH, wn * (BN / 2) + j * 16, c, lane) : frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+    }
+    if (more) {
+      char* nb = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+        if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], nb + c * ACH, tid);
+        if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], nb + NCK * ACH + c * BCH, tid);
+      }
+    }
+    P5_SCHED_FENCE();     // the copies issued at the top of the step stay in flight under the MFMAs above
+    __syncthreads();
+  }
+
+  gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
+}
+

@@ -68,13 +68,13 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   static const int force_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;       // dev knobs
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
-  const bool big = force_tile ? force_tile == 128 : t128 >= 512;
+  const bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   if (g.splitk <= 0) {
     g.splitk = 1;
     if (g.epi == P5_EPI_ATOMIC) {
       const int nkc = (g.K + TT<T>::KCH - 1) / TT<T>::KCH;
-      int want = (int)((split_target + tiles - 1) / tiles);
+      int want = (int)(((g.K >= 16384 ? 384 : split_target) + tiles - 1) / tiles);
       int maxs = nkc / 8 > 0 ? nkc / 8 : 1;
       g.splitk = want < maxs ? want : maxs;
       if (g.splitk < 1) g.splitk = 1;
@@ -179,6 +179,7 @@ struct P5Engine {
 #ifndef P5_EMU
   hipEvent_t ev_pool[32];
   hipEvent_t side_done[2];
+  hipEvent_t kv_ev[64];
   bool side_done_valid[2] = {false, false};
   int ev_next = 0;
 #endif
@@ -479,6 +480,15 @@ template <class T>
 static int decoder_fwd(P5Engine* e, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
+  if (e->side) {
+    fork_to_side(e, s);      // enc_out is ready
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      P5_TRY(linear_fwd<T>(e->side, e->enc_out, d, Wc<T>(e, e->dec[i].ca.k), e->ds[i].kv_ca, 2 * in, M, 2 * in, d));
+#ifndef P5_EMU
+      hipEventRecord(e->kv_ev[i], e->side);
+#endif
+    }
+  }
   P5_LAUNCH(p5_shift_right_kernel, dim3((Md + 255) / 256), dim3(256), 0, s, e->dec_ids, e->labels, e->B, e->T, (int64_t)c.pad_id);
   P5_TRY(P5_KCHECK());
   P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, (T*)e->dec_x0, Wc<T>(e, e->off_E), (const T*)nullptr,
@@ -502,7 +512,10 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
     // cross attention (zero position bias + encoder padding mask)
     P5_TRY(rmsnorm_fwd<T>(s, l.n_ca, l.rstd_ca, l.x_ca, e->P + lo.ca.ln, Md, d, c.eps, no_drop()));
     P5_TRY(linear_fwd<T>(s, l.n_ca, d, Wc<T>(e, lo.ca.q), l.q_ca, in, Md, in, d));
-    P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, lo.ca.k), l.kv_ca, 2 * in, M, 2 * in, d));
+    if (!e->side) P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, lo.ca.k), l.kv_ca, 2 * in, M, 2 * in, d));
+#ifndef P5_EMU
+    else hipStreamWaitEvent(s, e->kv_ev[i], 0);      // layer i's K/V projection was issued on the side stream up front
+#endif
     memset(&a, 0, sizeof(a));
     a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca;
     a.rel_table = nullptr; a.bucket_lut = nullptr; a.kmask = e->mask;
@@ -640,7 +653,9 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_TRY(linear_wgrad<T>(e, s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
     P5_TRY(linear_dgrad<T>(s, e->dqkv, in, Wc<T>(e, lo.ca.q), e->dn, d, Md, in, d));
     P5_TRY(linear_wgrad<T>(e, s, e->dkv, 2 * in, e->enc_out, d, e->G + lo.ca.k, M, 2 * in, d));
-    P5_TRY(linear_dgrad<T>(s, e->dkv, 2 * in, Wc<T>(e, lo.ca.k), e->d_enc, d, M, 2 * in, d,
+    // d(enc_out) += dKV Wkv is only consumed by the encoder backward: keep it off the decoder's dependent chain
+    // (side-stream launches are ordered among themselves, so the accumulation across layers is race-free)
+    P5_TRY(linear_dgrad<T>(e->side ? e->side : s, e->dkv, 2 * in, Wc<T>(e, lo.ca.k), e->d_enc, d, M, 2 * in, d,
                            e->d_enc_started ? P5_EPI_ACCUM : P5_EPI_STORE, nullptr, 0, 1.f, 1));
     e->d_enc_started = true;
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
@@ -659,6 +674,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     return P5_KCHECK();
   }
   if (stage == nd + 2) {
+    join_side(e, s);      // d_enc is accumulated on the side stream
     const size_t n = (size_t)M * d;
     P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
               (const float*)e->d_enc, n, no_drop());
@@ -901,6 +917,7 @@ int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
   if (side_stream && !e->side) {
     for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming);
     for (int i = 0; i < 2; ++i) hipEventCreateWithFlags(&e->side_done[i], hipEventDisableTiming);
+    for (int i = 0; i < 64; ++i) hipEventCreateWithFlags(&e->kv_ev[i], hipEventDisableTiming);
   }
   e->side = (hipStream_t)side_stream;
 #else
