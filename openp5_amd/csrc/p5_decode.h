@@ -102,43 +102,123 @@ __global__ __launch_bounds__(256) void p5_dec_cross_attn_kernel(T* __restrict__ 
   l = wave_sum(l);
   __syncthreads();
   if (!active) return;
-  float o = 0.f;
-  for (int j = 0; j < L; ++j) o += sp[wave][j] * to_f<T>(kv[((size_t)b * L + j) * 2 * inner + inner + h * 64 + lane]);
-  out[(size_t)r * inner + h * 64 + lane] = from_f<T>(l > 0.f ? o / l : 0.f);
+  // P V: lane = (key group kg = lane / NDG, dim group dg = lane % NDG); each lane accumulates EPF dims over the keys
+  // j == kg (mod NKG) with one 16-byte load per key, then the key groups are summed with shuffles
+  constexpr int EPF = TT<T>::EPF, NDG = 64 / EPF, NKG = 64 / NDG;
+  const int kg = lane / NDG, dg = lane % NDG;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j = kg; j < L; j += NKG) {
+    float x[8];
+    unpack16<T>(ld16(kv + ((size_t)b * L + j) * 2 * inner + inner + h * 64 + dg * EPF), x);
+    const float pj = sp[wave][j];
+#pragma unroll
+    for (int e = 0; e < EPF; ++e) o[e] += pj * x[e];
+  }
+#pragma unroll
+  for (int e = 0; e < EPF; ++e) {
+#pragma unroll
+    for (int msk = NDG; msk < 64; msk <<= 1) o[e] += __shfl_xor(o[e], msk);
+  }
+  if (kg == 0) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPF; ++e) o[e] *= inv;
+    st16(out + (size_t)r * inner + h * 64 + dg * EPF, pack16<T>(o));
+  }
 }
 
-// ---- per row: full-vocab log-sum-exp, then gather only the trie children's log-probs (+ running score) ----
-__global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ cand_score, int* __restrict__ n_cand,
+// block-wide arg-max with deterministic tie-break (lowest index); every thread gets the winner
+__device__ static __forceinline__ void block_argmax(float& bv, int& bi, float* s_val, int* s_idx) {
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    const float ov = __shfl_xor(bv, msk);
+    const int oi = __shfl_xor(bi, msk);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = bv; s_idx[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  bv = s_val[0]; bi = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+}
+
+// ---- per row: full-vocab log-sum-exp in ONE pass (online max/sum, 16-byte loads), then gather only the trie
+// children's log-probs (+ running score) and keep the row's best K2 = 2K of them, sorted (score desc, child asc).
+// The global top-2K of a batch item is contained in the union of its rows' top-2K lists.
+#define P5_ROW_LDS_CAND 2048
+__global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ cand_score, float* __restrict__ top_score,
+                                                          int* __restrict__ top_c, int* __restrict__ n_top,
                                                           const float* __restrict__ logits, int ldl, int V,
                                                           const int* __restrict__ node, const float* __restrict__ run_score,
                                                           const int* __restrict__ child_off, const int* __restrict__ child_tok,
-                                                          int max_c) {
-  __shared__ float sred[4];
-  const int r = blockIdx.x;
+                                                          int max_c, int K2) {
+  __shared__ float sm[4], ss[4];
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float sc[P5_ROW_LDS_CAND];
+  const int r = blockIdx.x, tid = threadIdx.x;
   const int nd = node[r];
   if (nd < 0) {  // dead beam: no candidates (uniform per block)
-    if (threadIdx.x == 0) n_cand[r] = 0;
+    if (tid == 0) n_top[r] = 0;
     return;
   }
   const float* lr = logits + (size_t)r * ldl;
-  float m = P5_NEG_INF;
-  for (int j = threadIdx.x; j < V; j += 256) m = fmaxf(m, lr[j]);
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
-  __syncthreads();
-  float s = 0.f;
-  for (int j = threadIdx.x; j < V; j += 256) s += expf(lr[j] - m);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
-  __syncthreads();
-  s = sred[0] + sred[1] + sred[2] + sred[3];
-  const float lse = m + logf(s);
-  const int c0 = child_off[nd], nc = child_off[nd + 1] - c0;
+  float m = P5_NEG_INF, sum = 0.f;
+  const int V4 = V >> 2;
+  for (int j = tid; j < V4; j += 256) {
+    const f32x4 v = *(const f32x4*)(lr + 4 * j);
+    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (mx > m) { sum *= expf(m - mx); m = mx; }
+    sum += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+  }
+  for (int j = (V4 << 2) + tid; j < V; j += 256) {
+    const float v = lr[j];
+    if (v > m) { sum *= expf(m - v); m = v; }
+    sum += expf(v - m);
+  }
+  {
+    const float wm_ = wave_max(m);
+    sum = wave_sum(m == P5_NEG_INF ? 0.f : sum * expf(m - wm_));
+    if ((tid & 63) == 0) { sm[tid >> 6] = wm_; ss[tid >> 6] = sum; }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    sum = 0.f;
+    for (int w = 0; w < 4; ++w) sum += ss[w] * expf(sm[w] - m);
+  }
+  const float lse = m + logf(sum);
+  const int c0 = child_off[nd];
+  int nc = child_off[nd + 1] - c0;
+  if (nc > max_c) nc = max_c;
   const float rs = run_score[r];
-  for (int c = threadIdx.x; c < nc && c < max_c; c += 256) cand_score[(size_t)r * max_c + c] = (lr[child_tok[c0 + c]] - lse) + rs;
-  if (threadIdx.x == 0) n_cand[r] = nc < max_c ? nc : max_c;
+  const bool in_lds = nc <= P5_ROW_LDS_CAND;
+  float* cs = in_lds ? sc : cand_score + (size_t)r * max_c;
+  for (int c = tid; c < nc; c += 256) cs[c] = (lr[child_tok[c0 + c]] - lse) + rs;
+  __syncthreads();
+  const int want = K2 < nc ? K2 : nc;
+  for (int it = 0; it < want; ++it) {
+    float bv = P5_NEG_INF;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < nc; c += 256) {
+      const float v = cs[c];
+      if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+    block_argmax(bv, bi, s_val, s_idx);
+    if (bi == 0x7fffffff) {            // only -inf left (cannot happen for finite logits); stop early
+      if (tid == 0) n_top[r] = it;
+      return;
+    }
+    if (tid == 0) {
+      top_score[(size_t)r * K2 + it] = bv;
+      top_c[(size_t)r * K2 + it] = bi;
+      cs[bi] = P5_NEG_INF;   // taken (a genuine -inf candidate is never selected above)
+    }
+    __syncthreads();
+  }
+  if (tid == 0) n_top[r] = want;
 }
 
 struct P5BeamState {
@@ -155,116 +235,106 @@ struct P5BeamState {
   int* flags;                        // [0] any_unsat, [1] not_all_hits  (host zeroes before each step)
 };
 
-// ---- one workgroup per batch item: top-2K over the item's candidates, then HF steps d-g ----
-__global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, float* __restrict__ cand_score, const int* __restrict__ n_cand,
+// ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
+// (utils.py:3131-3204, 3008-3075) with rank-based stable selections done in parallel ----
+#define P5_MAX_K 64
+#define P5_MAX_K2 128
+__global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const float* __restrict__ row_top_score,
+                                                          const int* __restrict__ row_top_c, const int* __restrict__ row_n_top,
                                                           const int* __restrict__ child_off, const int* __restrict__ child_tok,
                                                           const int* __restrict__ child_node, int max_c, int Kb, int max_len,
                                                           int cur_len, int eos_id, int R) {
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
-  __shared__ float top_lp[128];
-  __shared__ int top_beam[128], top_tok[128], top_node[128];
-  __shared__ int sel_run[64];       // candidate index chosen for each new running beam
-  __shared__ int fin_src[64];       // >=0: old finished slot; <0: -(cand+1)
-  __shared__ float fin_sc[64];
-  __shared__ int fin_fl[64];
-  __shared__ int fin_ln[64];
-  __shared__ float run_sc[64];
+  __shared__ float cs[P5_MAX_K * P5_MAX_K2];
+  __shared__ float top_lp[P5_MAX_K2], run_lp[P5_MAX_K2], msc[P5_MAX_K + P5_MAX_K2];
+  __shared__ int top_beam[P5_MAX_K2], top_tok[P5_MAX_K2], top_node[P5_MAX_K2], hit[P5_MAX_K2];
+  __shared__ int sel_run[P5_MAX_K], fin_src[P5_MAX_K], fin_fl[P5_MAX_K], fin_ln[P5_MAX_K];
+  __shared__ float fin_sc[P5_MAX_K], run_sc[P5_MAX_K];
+  __shared__ int s_nothit;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int K2 = 2 * Kb;
-  // ---- top-2K by repeated block arg-max (ties -> lowest flat index = lowest beam, then lowest token) ----
+  // candidate pool: Kb rows x (<= K2) entries, flat index j*K2 + i
+  for (int t = tid; t < Kb * K2; t += 256) {
+    const int j = t / K2, i = t % K2;
+    cs[t] = i < row_n_top[b * Kb + j] ? row_top_score[(size_t)(b * Kb + j) * K2 + i] : P5_NEG_INF;
+  }
+  if (tid == 0) s_nothit = 0;
+  __syncthreads();
   for (int it = 0; it < K2; ++it) {
     float bv = P5_NEG_INF;
-    int bi = 0x7fffffff;
-    for (int j = 0; j < Kb; ++j) {
-      const int r = b * Kb + j, nc = n_cand[r];
-      for (int c = tid; c < nc; c += 256) {
-        const float v = cand_score[(size_t)r * max_c + c];
-        const int fi = j * max_c + c;
-        if (v > bv || (v == bv && fi < bi)) { bv = v; bi = fi; }
-      }
+    int bi = 0x7fffffff;          // tie-break key = beam * max_c + child  (== HF's flat beam*V + token order)
+    for (int t = tid; t < Kb * K2; t += 256) {
+      const float v = cs[t];
+      if (v == P5_NEG_INF) continue;
+      const int j = t / K2, i = t % K2;
+      const int key = j * max_c + row_top_c[(size_t)(b * Kb + j) * K2 + i];
+      if (v > bv || (v == bv && key < bi)) { bv = v; bi = key; }
     }
-    // wave arg-max
-    for (int msk = 32; msk >= 1; msk >>= 1) {
-      const float ov = __shfl_xor(bv, msk);
-      const int oi = __shfl_xor(bi, msk);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) { s_val[tid >> 6] = bv; s_idx[tid >> 6] = bi; }
-    __syncthreads();
+    block_argmax(bv, bi, s_val, s_idx);
     if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
-      if (bi != 0x7fffffff && bv > P5_NEG_INF) {
+      if (bi != 0x7fffffff) {
         const int j = bi / max_c, c = bi % max_c;
         const int nd = st.run_node[b * Kb + j];
         top_lp[it] = bv; top_beam[it] = j;
         top_tok[it] = child_tok[child_off[nd] + c];
         top_node[it] = child_node[child_off[nd] + c];
-        cand_score[(size_t)(b * Kb + j) * max_c + c] = P5_NEG_INF;   // taken
-      } else {  // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries
+        for (int i = 0; i < K2; ++i)        // mark taken (rows are short: <= K2 entries)
+          if (cs[j * K2 + i] != P5_NEG_INF && row_top_c[(size_t)(b * Kb + j) * K2 + i] == c) { cs[j * K2 + i] = P5_NEG_INF; break; }
+      } else {   // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries
         top_lp[it] = P5_NEG_INF; top_beam[it] = 0; top_tok[it] = 0; top_node[it] = -1;
       }
     }
     __syncthreads();
   }
-  // ---- sequential bookkeeping on <= 2K + K entries (HF utils.py:3131-3204, 3008-3075) ----
+  // ---- d/e: hits, running beams = stable top-K of run_lp ----
+  const bool at_max = (cur_len + 1 >= max_len);
+  if (tid < K2) {
+    const int h = (top_tok[tid] == eos_id) || at_max;
+    hit[tid] = h;
+    run_lp[tid] = top_lp[tid] + (h ? -1.0e9f : 0.f);
+    if (!h) atomicAdd(&s_nothit, 1);
+  }
+  __syncthreads();
+  if (tid < K2) {
+    int rank = 0;
+    const float v = run_lp[tid];
+    for (int j = 0; j < K2; ++j) rank += (run_lp[j] > v || (run_lp[j] == v && j < tid)) ? 1 : 0;
+    if (rank < Kb) { sel_run[rank] = tid; run_sc[rank] = v; }
+  }
+  // ---- f: finished beams = stable top-K over [old finished ; new candidates] ----
+  const bool uns = st.unsat[b] != 0;
+  if (tid < Kb) msc[tid] = st.fin_score[b * Kb + tid];
+  else if (tid < Kb + K2) {
+    const int i = tid - Kb;
+    float v = top_lp[i] / (float)cur_len;
+    if (!uns) v += -1.0e9f;
+    if (!(hit[i] && i < Kb)) v += -1.0e9f;
+    msc[tid] = v;
+  }
+  __syncthreads();
+  if (tid < Kb + K2) {
+    int rank = 0;
+    const float v = msc[tid];
+    for (int j = 0; j < Kb + K2; ++j) rank += (msc[j] > v || (msc[j] == v && j < tid)) ? 1 : 0;
+    if (rank < Kb) {
+      fin_sc[rank] = v;
+      if (tid < Kb) { fin_src[rank] = tid; fin_fl[rank] = st.fin_flag[b * Kb + tid]; fin_ln[rank] = st.fin_len[b * Kb + tid]; }
+      else { const int i = tid - Kb; fin_src[rank] = -(i + 1); fin_fl[rank] = (hit[i] && i < Kb) ? 1 : 0; fin_ln[rank] = cur_len; }
+    }
+  }
+  __syncthreads();
+  // ---- g: early-stop heuristic with the NEW running / finished sets ----
   if (tid == 0) {
-    const bool at_max = (cur_len + 1 >= max_len);
-    bool all_hits = true;
-    float run_lp[128];
-    bool hit[128];
-    for (int i = 0; i < K2; ++i) {
-      hit[i] = (top_tok[i] == eos_id) || at_max;
-      all_hits = all_hits && hit[i];
-      run_lp[i] = top_lp[i] + (hit[i] ? -1.0e9f : 0.f);
-    }
-    // e. next running beams: stable top-K of run_lp
-    bool used[128];
-    for (int i = 0; i < K2; ++i) used[i] = false;
-    for (int j = 0; j < Kb; ++j) {
-      int best = -1;
-      for (int i = 0; i < K2; ++i)
-        if (!used[i] && (best < 0 || run_lp[i] > run_lp[best])) best = i;
-      used[best] = true;
-      sel_run[j] = best;
-    }
-    // f. finished beams: stable top-K over [old finished ; new candidates]
-    const bool uns = st.unsat[b] != 0;
-    float msc[192];
-    for (int j = 0; j < Kb; ++j) msc[j] = st.fin_score[b * Kb + j];
-    for (int i = 0; i < K2; ++i) {
-      float v = top_lp[i] / (float)cur_len;
-      if (!uns) v += -1.0e9f;
-      if (!(hit[i] && i < Kb)) v += -1.0e9f;
-      msc[Kb + i] = v;
-    }
-    bool mused[192];
-    for (int i = 0; i < Kb + K2; ++i) mused[i] = false;
-    for (int j = 0; j < Kb; ++j) {
-      int best = -1;
-      for (int i = 0; i < Kb + K2; ++i)
-        if (!mused[i] && (best < 0 || msc[i] > msc[best])) best = i;
-      mused[best] = true;
-      fin_sc[j] = msc[best];
-      if (best < Kb) { fin_src[j] = best; fin_fl[j] = st.fin_flag[b * Kb + best]; fin_ln[j] = st.fin_len[b * Kb + best]; }
-      else { fin_src[j] = -(best - Kb + 1); fin_fl[j] = (hit[best - Kb] && (best - Kb) < Kb) ? 1 : 0; fin_ln[j] = cur_len; }
-    }
-    // g. early-stop heuristic with the NEW running / finished sets
-    const float best_possible = run_lp[sel_run[0]] / (float)cur_len;   // (cur_len+1) - prompt_len(1)
+    const float best_possible = run_sc[0] / (float)cur_len;   // (cur_len+1) - prompt_len(1)
     float mn = fin_sc[0];
     for (int j = 1; j < Kb; ++j) mn = fminf(mn, fin_sc[j]);
     bool any = false;
-    for (int j = 0; j < Kb; ++j) {
-      const float worst = fin_fl[j] ? mn : -1.0e9f;
-      any = any || (best_possible > worst);
-    }
+    for (int j = 0; j < Kb; ++j) any = any || (best_possible > (fin_fl[j] ? mn : -1.0e9f));
     const int new_unsat = (uns && any) ? 1 : 0;
     st.unsat[b] = new_unsat;
     if (new_unsat) atomicAdd(&st.flags[0], 1);
-    if (!all_hits) atomicAdd(&st.flags[1], 1);
-    for (int j = 0; j < Kb; ++j) run_sc[j] = run_lp[sel_run[j]];
+    if (s_nothit > 0) atomicAdd(&st.flags[1], 1);
   }
   __syncthreads();
   // ---- materialise the new finished set (reads OLD fin_seq / run_seq, writes fin_seq_next) ----

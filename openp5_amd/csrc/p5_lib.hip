@@ -712,7 +712,7 @@ struct GenWs {
   void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
   void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
-  float *logits, *cand; int* n_cand;
+  float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
   P5BeamState st;
 };
 
@@ -736,6 +736,8 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.logits = (float*)b.take(R * Vp * 4);
   w.cand = (float*)b.take(R * (size_t)max_c * 4);
   w.n_cand = (int*)b.take(R * 4);
+  w.row_top_score = (float*)b.take(R * (size_t)(2 * K) * 4);
+  w.row_top_c = (int*)b.take(R * (size_t)(2 * K) * 4);
   P5BeamState& st = w.st;
   st.run_seq = (int*)b.take(R * max_len * 4); st.run_seq_next = (int*)b.take(R * max_len * 4);
   st.fin_seq = (int*)b.take(R * max_len * 4); st.fin_seq_next = (int*)b.take(R * max_len * 4);
@@ -807,12 +809,12 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   const int Vp = (c.vocab_size + 63) / 64 * 64;
   for (int cur_len = 1; cur_len < max_len; ++cur_len) {
     P5_TRY(decode_step<T>(e, w, B, L, K, cur_len - 1, max_len, s));
-    P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.n_cand, (const float*)w.logits, Vp, c.vocab_size,
-              (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, max_c);
+    P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_cand, (const float*)w.logits, Vp,
+              c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, max_c, 2 * K);
     P5_TRY(P5_KCHECK());
     hipMemsetAsync(w.st.flags, 0, 8, s);
-    P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, w.cand, (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K,
-              max_len, cur_len, c.eos_id, R);
+    P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
+              (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, cur_len, c.eos_id, R);
     P5_TRY(P5_KCHECK());
     std::swap(w.st.run_seq, w.st.run_seq_next);
     std::swap(w.st.fin_seq, w.st.fin_seq_next);
