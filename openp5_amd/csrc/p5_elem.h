@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
                                                             float* __restrict__ dw, const T* __restrict__ dy,
                                                             const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
-                                                            int rows, int d, P5Drop drop_in, P5Drop drop_next) {
+                                                            int rows, int d, P5Drop drop_in, P5Drop drop_next, float* __restrict__ dw_partial) {
   constexpr int EPF = TT<T>::EPF;
   __shared__ float sdw[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
     }
   }
   __syncthreads();
+  if (dw_partial) {   // one row of partial sums per workgroup, reduced later by p5_reduce_rows_kernel (no atomics)
+    for (int j = threadIdx.x; j < d; j += 256) dw_partial[(size_t)blockIdx.x * d + j] = sdw[0][j] + sdw[1][j] + sdw[2][j] + sdw[3][j];
+    return;
+  }
   // every workgroup starts its flush at a different column so that concurrent workgroups hit different addresses
   for (int j0 = threadIdx.x; j0 < d; j0 += 256) {
     const int j = (j0 + (int)(blockIdx.x % 8u) * 64) % d;
@@ -193,6 +197,18 @@ __global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, 
     if (dd) v = p5_keep(seed, drop.site_key, (uint32_t)i, drop.thr) ? v * drop.scale : 0.f;
     out[i] = from_f<T>(v);
   }
+}
+
+// dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials)
+__global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ float sred[4][64];
+  float s = 0.f;
+  if (j < d)
+    for (int b = part; b < nrows; b += 4) s += partial[(size_t)b * d + j];
+  sred[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && j < d) dst[j] += sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
 }
 
 // dst[i] += sum_c partial[c][i]   (partial copies of the relative-bias gradient)
@@ -264,15 +280,32 @@ __device__ static __forceinline__ float block_reduce(float v, bool is_max, float
 __global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll, float* __restrict__ lse_out,
                                                        const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                        int V, int ldl) {
-  __shared__ float sred[4];
-  const int row = blockIdx.x;
+  __shared__ float sm[4], ss[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
   const float* lr = logits + (size_t)row * ldl;
-  float m = P5_NEG_INF;
-  for (int j = threadIdx.x; j < V; j += 256) m = fmaxf(m, lr[j]);
-  m = block_reduce(m, true, sred);
-  float s = 0.f;
-  for (int j = threadIdx.x; j < V; j += 256) s += expf(lr[j] - m);
-  s = block_reduce(s, false, sred);
+  // one pass: running (max, sum of exp) per thread with 16-byte loads, merged across the workgroup
+  float m = P5_NEG_INF, s = 0.f;
+  const int V4 = V >> 2;
+  for (int j = tid; j < V4; j += 256) {
+    const f32x4 v = *(const f32x4*)(lr + 4 * j);
+    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (mx > m) { s *= expf(m - mx); m = mx; }
+    s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+  }
+  for (int j = (V4 << 2) + tid; j < V; j += 256) {
+    const float v = lr[j];
+    if (v > m) { s *= expf(m - v); m = v; }
+    s += expf(v - m);
+  }
+  {
+    const float wm_ = wave_max(m);
+    s = wave_sum(m == P5_NEG_INF ? 0.f : s * expf(m - wm_));
+    if ((tid & 63) == 0) { sm[tid >> 6] = wm_; ss[tid >> 6] = s; }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    s = 0.f;
+    for (int w = 0; w < 4; ++w) s += ss[w] * expf(sm[w] - m);
+  }
   if (threadIdx.x == 0) {
     const float lse = m + logf(s);
     lse_out[row] = lse;

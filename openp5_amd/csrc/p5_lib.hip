@@ -172,6 +172,8 @@ struct P5Engine {
   void *dy2[2] = {nullptr, nullptr}, *dh2[2] = {nullptr, nullptr}, *du2[2] = {nullptr, nullptr}, *dqkv2[2] = {nullptr, nullptr},
        *dkv2[2] = {nullptr, nullptr};
   void* dy_next = nullptr;
+  float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
+  int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
   // optional second stream for the weight-gradient GEMMs (off the critical dgrad chain)
@@ -351,12 +353,14 @@ static int rmsnorm_fwd(hipStream_t s, void* y, float* rstd, const void* x, const
 }
 template <class T>
 static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
-                       const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext) {
+                       const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext, float* dw_partial = nullptr,
+                       int* nblocks_out = nullptr) {
   P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
+  if (nblocks_out) *nblocks_out = blocks;
   P5_LAUNCH((p5_rmsnorm_bwd_kernel<T>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd,
-            dres_in, rows, d, din, dnext);
+            dres_in, rows, d, din, dnext, dw_partial);
   return P5_KCHECK();
 }
 
@@ -417,6 +421,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
     e->rel_partial = (float*)b.take((size_t)2 * REL_COPIES * c.rel_buckets * H * 4);
+    e->dw_scratch = (float*)b.take((size_t)(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2) * 1024 * d * 4);
     e->dn = b.take(Mx * d * sz);
     e->dO = b.take(Mx * in * sz);
     for (int p = 0; p < 2; ++p) {
@@ -569,8 +574,14 @@ static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_o
                          bool has_res_in = true) {
   float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
   end_sublayer_sync(e, s);
-  P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows,
-                        e->c.d_model, din, dnext));
+  const int d = e->c.d_model;
+  float* part = e->dw_scratch + (size_t)(e->norm_slot++) * 1024 * d;
+  int nblk = 0;
+  P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows, d, din,
+                        dnext, part, &nblk));
+  // the per-workgroup partials are summed off the critical path
+  P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64), dim3(256), 0, wgrad_stream(e, s), e->G + ln_off, (const float*)part, nblk, d);
+  P5_TRY(P5_KCHECK());
   e->dres_cur = out;
   return 0;
 }
@@ -609,6 +620,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     e->sub = -1;
+    e->norm_slot = 0;
 #ifndef P5_EMU
     e->side_done_valid[0] = e->side_done_valid[1] = false;
 #endif
