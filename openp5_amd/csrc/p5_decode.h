@@ -18,9 +18,14 @@
 // ---- single-token self-attention over the ancestry-indexed cache: one wave per (row, head) ----
 template <class T>
 __global__ __launch_bounds__(256) void p5_dec_self_attn_kernel(T* __restrict__ out, const T* __restrict__ qkv, T* __restrict__ cache,
-                                                              const int* __restrict__ anc, const float* __restrict__ rel_table,
-                                                              const int* __restrict__ lut, int lut_half, int R, int H, int pos,
-                                                              int max_len) {
+                                                              const int* __restrict__ anc_odd, const int* __restrict__ anc_even,
+                                                              const float* __restrict__ rel_table, const int* __restrict__ lut,
+                                                              int lut_half, int R, int H, const int* __restrict__ step, int max_len) {
+  // the step counter lives in device memory (cur_len = tokens so far, incl. the start token) so that ONE captured
+  // hipGraph of the decode step can be replayed for every step; double-buffered state is selected by its parity
+  const int cur_len = *step;
+  const int pos = cur_len - 1;
+  const int* __restrict__ anc = (cur_len & 1) ? anc_odd : anc_even;
   const int lane = threadIdx.x & 63;
   const int rh = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rh >= R * H) return;
@@ -232,7 +237,7 @@ struct P5BeamState {
   int* unsat;                        // [B]
   int* anc; int* anc_next;           // [max_len, R]
   int64_t* last_tok;                 // [R] decoder input for the next step
-  int* flags;                        // [0] any_unsat, [1] not_all_hits  (host zeroes before each step)
+  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len
 };
 
 // ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
@@ -243,7 +248,14 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
                                                           const int* __restrict__ row_top_c, const int* __restrict__ row_n_top,
                                                           const int* __restrict__ child_off, const int* __restrict__ child_tok,
                                                           const int* __restrict__ child_node, int max_c, int Kb, int max_len,
-                                                          int cur_len, int eos_id, int R) {
+                                                          int eos_id, int R) {
+  const int cur_len = st.flags[2];
+  if ((cur_len & 1) == 0) {      // even step: the "next" buffers of the previous step are the current ones
+    int* t;
+    t = st.run_seq; st.run_seq = st.run_seq_next; st.run_seq_next = t;
+    t = st.fin_seq; st.fin_seq = st.fin_seq_next; st.fin_seq_next = t;
+    t = st.anc; st.anc = st.anc_next; st.anc_next = t;
+  }
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ float cs[P5_MAX_K * P5_MAX_K2];
@@ -374,6 +386,10 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   }
 }
 
+__global__ void p5_beam_tick_kernel(int* flags) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) flags[2] += 1;
+}
+
 // initial state: every beam at the trie node reached by the decoder start token, scores [0, -1e9, ...]
 __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const int* __restrict__ child_off, const int* __restrict__ child_tok,
                                                           const int* __restrict__ child_node, const int* __restrict__ roots, int B, int Kb, int max_len,
@@ -398,4 +414,5 @@ __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const
     st.last_tok[i] = start_id;
   }
   if (i < B) st.unsat[i] = 1;
+  if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; }
 }

@@ -149,6 +149,8 @@ struct Bump {
   }
 };
 
+struct GraphKey { int B, L, K, max_len, max_c; const void *ws, *trie, *roots, *P, *S; int sz; };
+
 struct P5Engine {
   P5Config c;
   int inner;
@@ -176,6 +178,11 @@ struct P5Engine {
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
+#ifndef P5_EMU
+  hipGraphExec_t gen_graph_exec = nullptr;
+  bool gen_graph_failed = false;
+  GraphKey gen_graph_key;
+#endif
   // optional second stream for the weight-gradient GEMMs (off the critical dgrad chain)
   hipStream_t side = nullptr;
 #ifndef P5_EMU
@@ -725,6 +732,7 @@ struct GenWs {
   void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
   float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
+  int64_t* mask_copy;
   P5BeamState st;
 };
 
@@ -750,6 +758,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.n_cand = (int*)b.take(R * 4);
   w.row_top_score = (float*)b.take(R * (size_t)(2 * K) * 4);
   w.row_top_c = (int*)b.take(R * (size_t)(2 * K) * 4);
+  w.mask_copy = (int64_t*)b.take((size_t)B * L * 8);
   P5BeamState& st = w.st;
   st.run_seq = (int*)b.take(R * max_len * 4); st.run_seq_next = (int*)b.take(R * max_len * 4);
   st.fin_seq = (int*)b.take(R * max_len * 4); st.fin_seq_next = (int*)b.take(R * max_len * 4);
@@ -763,7 +772,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
 }
 
 template <class T>
-static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int pos, int max_len, hipStream_t s) {
+static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, R = B * K;
   P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.xa, Wc<T>(e, e->off_E), (const T*)nullptr,
@@ -775,14 +784,15 @@ static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int pos, int 
     P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.sa.ln, R, d, c.eps, no_drop()));
     P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.sa.q), w.qkv, 3 * in, R, 3 * in, d));
     P5_LAUNCH((p5_dec_self_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i],
-              (const int*)w.st.anc, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, pos, max_len);
+              (const int*)w.st.anc, (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H,
+              (const int*)(w.st.flags + 2), max_len);
     P5_TRY(P5_KCHECK());
     P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.sa.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
     std::swap(x, y);
     P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ca.ln, R, d, c.eps, no_drop()));
     P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.ca.q), w.q, in, R, in, d));
     P5_LAUNCH((p5_dec_cross_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.q, (const T*)w.kv_cross[i],
-              e->mask, R, H, K, L);
+              (const int64_t*)w.mask_copy, R, H, K, L);
     P5_TRY(P5_KCHECK());
     P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.ca.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
     std::swap(x, y);
@@ -819,23 +829,67 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
             c.pad_id);
   P5_TRY(P5_KCHECK());
   const int Vp = (c.vocab_size + 63) / 64 * 64;
-  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
-    P5_TRY(decode_step<T>(e, w, B, L, K, cur_len - 1, max_len, s));
+  hipMemcpyAsync(w.mask_copy, e->mask, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s);
+  auto step_body = [&]() -> int {
+    hipMemsetAsync(w.st.flags, 0, 8, s);
+    P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
     P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_cand, (const float*)w.logits, Vp,
               c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, max_c, 2 * K);
     P5_TRY(P5_KCHECK());
-    hipMemsetAsync(w.st.flags, 0, 8, s);
     P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
-              (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, cur_len, c.eos_id, R);
+              (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, c.eos_id, R);
     P5_TRY(P5_KCHECK());
-    std::swap(w.st.run_seq, w.st.run_seq_next);
-    std::swap(w.st.fin_seq, w.st.fin_seq_next);
-    std::swap(w.st.anc, w.st.anc_next);
+    P5_LAUNCH(p5_beam_tick_kernel, dim3(1), dim3(64), 0, s, w.st.flags);
+    return P5_KCHECK();
+  };
+#ifndef P5_EMU
+  // one decode step = ~85 tiny dependent kernels: capture it once into a hipGraph and replay it per step
+  static const bool use_graph = !(getenv("P5_NO_GRAPH") && atoi(getenv("P5_NO_GRAPH")));
+  GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.ws = ws; key.trie = child_off; key.roots = roots;
+  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T);
+  bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
+  auto capture = [&]() {
+    // (never during the very first step: the first launch of a kernel loads its code object, which is not allowed
+    // while a stream is capturing)
+    if (e->gen_graph_exec) { hipGraphExecDestroy(e->gen_graph_exec); e->gen_graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int rc = step_body();
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc == 0 && ec == hipSuccess && graph && hipGraphInstantiate(&e->gen_graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+      e->gen_graph_key = key;
+      have_graph = true;
+    } else {
+      e->gen_graph_exec = nullptr;
+    }
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+  };
+#endif
+  int steps_run = 0;
+  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
+#ifndef P5_EMU
+    if (use_graph && !have_graph && steps_run >= 1 && !e->gen_graph_failed) {
+      capture();
+      if (!have_graph) e->gen_graph_failed = true;
+    }
+    if (have_graph) {
+      if (hipGraphLaunch(e->gen_graph_exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
+    } else
+#endif
+    {
+      P5_TRY(step_body());
+    }
+    steps_run++;
     int flags[2] = {1, 1};
     hipMemcpyAsync(flags, w.st.flags, 8, hipMemcpyDeviceToHost, s);
     hipStreamSynchronize(s);
     if (!(flags[0] > 0 && flags[1] > 0)) break;   // HF utils.py:3055-3075
   }
+  // the finished set written by the last step lives in the "next" buffer of that step's parity
+  if (steps_run & 1) std::swap(w.st.fin_seq, w.st.fin_seq_next);
   hipMemcpyAsync(out_seq, w.st.fin_seq, (size_t)R * max_len * 4, hipMemcpyDeviceToDevice, s);
   hipMemcpyAsync(out_score, w.st.fin_score, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
   hipMemcpyAsync(out_len, w.st.fin_len, (size_t)R * 4, hipMemcpyDeviceToDevice, s);

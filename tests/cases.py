@@ -358,3 +358,63 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
         s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, max_len)
     compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
     return out
+
+
+def train_trajectory_case(be, ocfg, B, L, T, steps=3, dtype="fp32", lr=1e-2, tol=2e-4):
+    """N fused steps (forward + backward + clip + HF-AdamW + linear warmup) against the oracle's restatement of the
+    reference step (DistributedRunner.py:63-87, SingleRunner.py:178-219): parameter trajectories must coincide."""
+    from openp5_amd.optim import FusedAdamW
+    ocfg = O.T5Cfg(**{**ocfg.__dict__, "dropout": 0.0})
+    params = O.init_params(ocfg, 7)
+    m = build_model(be, ocfg, params, dtype)
+    m.eval()
+    total, warm = 10, 2
+    opt = FusedAdamW(m, lr=lr, eps=1e-6, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=warm, total_steps=total)
+    Pq = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    M1 = {k: torch.zeros_like(v) for k, v in params.items()}
+    M2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    for step in range(1, steps + 1):
+        ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, 100 + step)
+        nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"]
+        O.runner_loss(nll, out_attn.to(nll.device)).backward()
+        opt.step()
+        m.zero_grad()
+        loss_o = O.runner_loss(O.p5_forward_nll(Pq, ocfg, ids, ww, mask, labels), out_attn)
+        grads = torch.autograd.grad(loss_o, list(Pq.values()))
+        _, coef = O.clip_coef(grads, 1.0)
+        lr_t = O.linear_schedule_lr(lr, step - 1, warm, total)       # lr in effect for this step (scheduler stepped after)
+        with torch.no_grad():
+            for (k, p), g in zip(Pq.items(), grads):
+                O.adamw_hf_step(p, g * coef, M1[k], M2[k], step, lr_t)
+    sync(be)
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        err = (p.detach().cpu() - Pq[name].detach()).abs().max().item()
+        if err > worst[0]:
+            worst = (err, name)
+    assert worst[0] <= tol, f"parameter trajectory diverged: {worst}"
+    return worst
+
+
+def bf16_training_converges_case(be, steps=40):
+    """fast mode sanity: fused bf16 training on one fixed batch drives the masked loss down (dropout on)."""
+    from openp5_amd.optim import FusedAdamW
+    ocfg = O.T5Cfg.named("tiny", dropout=0.1)
+    params = O.init_params(ocfg, 3)
+    m = build_model(be, ocfg, params, "bf16", dropout=0.1)
+    m.train()
+    m.set_dropout_seed(11, 0)
+    opt = FusedAdamW(m, lr=3e-3, max_grad_norm=1.0)
+    ids, ww, mask, labels, out_attn = synth_batch(ocfg, 8, 24, 6, 77)
+    first = last = None
+    for _ in range(steps):
+        nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"]
+        loss = O.runner_loss(nll, out_attn.to(nll.device))
+        loss.backward()
+        opt.step()
+        m.zero_grad()
+        v = float(loss.detach())
+        first = v if first is None else first
+        last = v
+    assert last < 0.6 * first, (first, last)
+    return first, last

@@ -65,3 +65,8 @@ def test_generate(emu, via):
 def test_generate_few_items(emu):
     """fewer items than beams: junk (-1e9) hypotheses appear exactly as in HF."""
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 11, 6, 9, 7, seed=9, score_tol=1e4)
+
+
+def test_train_trajectory_fp32(emu):
+    """3 fused optimizer steps == the oracle's clip + HF-AdamW + warmup trajectory."""
+    cases.train_trajectory_case(emu, O.T5Cfg.named("tiny"), 2, 12, 5)

@@ -79,3 +79,37 @@ def test_generate(hip, via):
 def test_generate_t5_small(hip):
     """beam-10 over a 300-item trie at T5-small dims: ranked item sequences identical to the CPU oracle."""
     cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4)
+
+
+def test_train_trajectory_fp32(hip):
+    cases.train_trajectory_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6)
+
+
+def test_bf16_training_converges(hip):
+    cases.bf16_training_converges_case(hip)
+
+
+def test_generate_bf16_ranked_set(hip):
+    """fast mode: bf16 logits may flip near-ties, but the ranked top-K item SET must agree with the fp32 oracle on
+    almost every user (SURVEY.md 0.7 measured 76/80 rank positions identical for end-to-end bf16)."""
+    import torch
+    from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+    ocfg = O.T5Cfg.named("t5-small", dropout=0.0)
+    params = O.init_params(ocfg, 7)
+    m = cases.build_model(hip, ocfg, params, "bf16")
+    m.eval()
+    ids, ww, mask, _, _ = cases.synth_batch(ocfg, 8, 64, 4, 5)
+    items = cases.make_items(300, 5, hi=60)
+    trie = Trie(items)
+    out = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=12, prefix_allowed_tokens_fn=prefix_allowed_tokens_fn(trie),
+                     num_beams=10, num_return_sequences=10, output_scores=True, return_dict_in_generate=True)
+    with torch.no_grad():
+        s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), 10, 12)
+    seq = out["sequences"].cpu()
+    same = 0
+    for b in range(8):
+        a = {tuple(t for t in r.tolist() if t > 1) for r in seq[b * 10:(b + 1) * 10]}
+        r_ = {tuple(t for t in r.tolist() if t > 1) for r in s_ref[b * 10:(b + 1) * 10]}
+        same += len(a & r_)
+    assert same >= 72, f"only {same}/80 top-10 items agree between bf16 and the fp32 oracle"
+    assert (out["sequences_scores"].cpu() - sc_ref).abs().max() < 0.3
