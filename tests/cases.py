@@ -237,14 +237,14 @@ def synth_batch(cfg, B, L, T, seed):
     ids = torch.randint(3, cfg.vocab_size, (B, L), generator=g)
     mask = torch.ones(B, L, dtype=torch.long)
     for b in range(1, B):
-        n = int(torch.randint(L // 2, L + 1, (1,), generator=g))
+        n = max(1, int(torch.randint(L // 2, L + 1, (1,), generator=g)))
         mask[b, n:] = 0
         ids[b, n:] = 0
     ww = torch.cumsum((torch.rand(B, L, generator=g) < 0.4).long(), 1) * mask
     labels = torch.randint(3, cfg.vocab_size, (B, T), generator=g)
     out_attn = torch.ones(B, T, dtype=torch.long)
     for b in range(B):
-        n = int(torch.randint(2, T + 1, (1,), generator=g))
+        n = int(torch.randint(2, T + 1, (1,), generator=g)) if T >= 2 else 1
         labels[b, n - 1] = cfg.eos_id
         labels[b, n:] = 0
         out_attn[b, n:] = 0
@@ -275,9 +275,12 @@ def model_train_case(be, ocfg, B, L, T, dtype="fp32", dropout=0.0, seed=3, nll_t
     err = (nll.detach().cpu() - nll_o.detach()).abs().max().item()
     assert err <= nll_tol, f"nll err {err}"
     worst = (0.0, "")
+    # error of each tensor relative to its own largest entry, with a floor of 1 % of the largest gradient entry overall
+    # (tensors whose gradient is analytically zero -- e.g. q/k of a 1-token self-attention -- only carry rounding noise)
+    gmax = max(float(v.grad.abs().max()) for v in Pq.values())
     for name, p in m.named_parameters():
         g_, go = p.grad.detach().cpu(), Pq[name].grad
-        rel = (g_ - go).abs().max().item() / (go.abs().max().item() + 1e-8)
+        rel = (g_ - go).abs().max().item() / (go.abs().max().item() + 1e-2 * gmax + 1e-12)
         if rel > worst[0]:
             worst = (rel, name)
     assert worst[0] <= grad_tol, f"gradient mismatch {worst}"

@@ -70,3 +70,13 @@ def test_generate_few_items(emu):
 def test_train_trajectory_fp32(emu):
     """3 fused optimizer steps == the oracle's clip + HF-AdamW + warmup trajectory."""
     cases.train_trajectory_case(emu, O.T5Cfg.named("tiny"), 2, 12, 5)
+
+
+@pytest.mark.parametrize("B,L,T", [(1, 1, 1), (2, 5, 1), (1, 3, 9)])
+def test_model_edge_shapes(emu, B, L, T):
+    cases.model_train_case(emu, O.T5Cfg.named("tiny"), B, L, T, "fp32", 0.0)
+
+
+def test_generate_truncated_by_max_length(emu):
+    """max_length shorter than the item ids: every beam 'finishes' by length, exactly as HF's MaxLengthCriteria."""
+    cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 9, 4, 5, 30, seed=13)

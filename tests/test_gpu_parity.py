@@ -113,3 +113,18 @@ def test_generate_bf16_ranked_set(hip):
         same += len(a & r_)
     assert same >= 72, f"only {same}/80 top-10 items agree between bf16 and the fp32 oracle"
     assert (out["sequences_scores"].cpu() - sc_ref).abs().max() < 0.3
+
+
+@pytest.mark.parametrize("B,L,T", [(1, 1, 1), (2, 5, 1), (1, 3, 9), (1, 512, 16), (3, 300, 33)])
+def test_model_edge_shapes(hip, B, L, T):
+    """ragged / minimum / maximum (L = 512 is the collator's truncation limit, Collator.py:13) shapes."""
+    cases.model_train_case(hip, O.T5Cfg.named("tiny"), B, L, T, "fp32", 0.0, nll_tol=5e-5, grad_tol=5e-4)
+
+
+def test_generate_truncated_by_max_length(hip):
+    cases.generate_case(hip, O.T5Cfg.named("tiny"), 2, 9, 4, 5, 30, seed=13)
+
+
+def test_generate_large_fanout_and_batch(hip):
+    """fan-out > 256 children at one trie node and 64 users x 10 beams."""
+    cases.generate_case(hip, O.T5Cfg.named("tiny", vocab_size=1200), 16, 24, 10, 10, 600, seed=21, score_tol=5e-5)
