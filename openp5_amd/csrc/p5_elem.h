@@ -199,16 +199,21 @@ __global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, 
   }
 }
 
-// dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials)
+// dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials); grid = (d/64, row slices)
 __global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d) {
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   __shared__ float sred[4][64];
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per < nrows) ? b0 + per : nrows;
   float s = 0.f;
   if (j < d)
-    for (int b = part; b < nrows; b += 4) s += partial[(size_t)b * d + j];
+    for (int b = b0 + part; b < b1; b += 4) s += partial[(size_t)b * d + j];
   sred[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && j < d) dst[j] += sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
+  if (part == 0 && j < d) {
+    const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
+    if (v != 0.f) atomicAdd(dst + j, v);
+  }
 }
 
 // dst[i] += sum_c partial[c][i]   (partial copies of the relative-bias gradient)

@@ -587,7 +587,8 @@ static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_o
   P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows, d, din,
                         dnext, part, &nblk));
   // the per-workgroup partials are summed off the critical path
-  P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64), dim3(256), 0, wgrad_stream(e, s), e->G + ln_off, (const float*)part, nblk, d);
+  P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64, nblk >= 64 ? 16 : 1), dim3(256), 0, wgrad_stream(e, s), e->G + ln_off, (const float*)part,
+            nblk, d);
   P5_TRY(P5_KCHECK());
   e->dres_cur = out;
   return 0;

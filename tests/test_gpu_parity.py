@@ -128,3 +128,49 @@ def test_generate_truncated_by_max_length(hip):
 def test_generate_large_fanout_and_batch(hip):
     """fan-out > 256 children at one trie node and 64 users x 10 beams."""
     cases.generate_case(hip, O.T5Cfg.named("tiny", vocab_size=1200), 16, 24, 10, 10, 600, seed=21, score_tol=5e-5)
+
+
+@pytest.mark.parametrize("name,B,L,T", [("t5-base", 2, 96, 8), ("t5-large", 1, 512, 10)])
+def test_model_base_large_dims_fp32(hip, name, B, L, T):
+    """BASELINE.json configs[2] / configs[4] dims (d=768/H=12/F=3072 and d=1024/H=16/F=4096, L up to 512), two layers per
+    stack so the CPU oracle stays fast; V = 32100."""
+    cfg = O.T5Cfg.named(name, num_layers=2, num_decoder_layers=2)
+    # (ReLU masks of pre-activations within fp32 rounding of zero may flip between summation orders at F = 4096)
+    cases.model_train_case(hip, cfg, B, L, T, "fp32", 0.0, nll_tol=2e-4, grad_tol=1e-2)
+
+
+def test_generate_base_beam20_collaborative_vocab(hip):
+    """BASELINE.json configs[3]: T5-base dims, beam 20, vocabulary grown by 500 <CIk> tokens (collaborative indexing,
+    main.py:190-193) -> V = 32600; ids drawn from the added-token range."""
+    cfg = O.T5Cfg.named("t5-base", num_layers=2, num_decoder_layers=2, vocab_size=32600)
+    import random
+    rnd = random.Random(3)
+    items = set()
+    while len(items) < 400:
+        items.add(tuple([0, 5] + [rnd.randint(32100, 32599) for _ in range(rnd.randint(2, 4))] + [1]))
+    from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+    import torch
+    params = O.init_params(cfg, 7)
+    m = cases.build_model(hip, cfg, params, "fp32")
+    m.eval()
+    ids, ww, mask, _, _ = cases.synth_batch(cfg, 3, 40, 4, 5)
+    trie = Trie(sorted(items))
+    out = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=30, prefix_allowed_tokens_fn=prefix_allowed_tokens_fn(trie),
+                     num_beams=20, num_return_sequences=20, output_scores=True, return_dict_in_generate=True)
+    with torch.no_grad():
+        s_ref, sc_ref = O.beam_search(params, cfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), 20, 30)
+    cases.compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, 2e-4)
+
+
+def test_bf16_large_L512_runs(hip):
+    """configs[4] shape in fast mode: T5-large dims at L = 512 (finite loss and gradients; parity is covered in fp32)."""
+    import torch
+    cfg = O.T5Cfg.named("t5-large", num_layers=2, num_decoder_layers=2, dropout=0.1)
+    m = cases.build_model(hip, cfg, O.init_params(cfg, 5), "bf16", dropout=0.1)
+    m.train()
+    ids, ww, mask, labels, out_attn = cases.synth_batch(cfg, 4, 512, 10, 3)
+    nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"]
+    loss = O.runner_loss(nll, out_attn.to(nll.device))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(nll).all() and torch.isfinite(m._grads).all() and float(m._grads.abs().max()) > 0
