@@ -31,11 +31,58 @@ def _encode(tokenizer, texts):
     return enc["input_ids"], enc["attention_mask"]
 
 
+class WordCacheEncoder:
+    """Tokenises prompts word by word with a per-word cache.  SentencePiece/T5 never merges across whitespace (every
+    whitespace-separated word is segmented on its own, prefixed by U+2581), so concat(pieces(word)) + </s> equals the
+    tokenizer's own output -- but OpenP5 prompts are built from a few hundred template words plus item / user ids that
+    repeat all the time, so after warm-up a 64-prompt batch costs ~1 ms instead of ~8 ms of Unigram Viterbi (which would
+    make the input pipeline slower than the MI355X training step).  `ok` is False when a
+    self-check against the wrapped tokenizer fails (then the collator falls back to the tokenizer itself)."""
+
+    PROBE = "Considering ML1M user_12 has interacted with ML1M items item_1001 , item_27 . What is next ?  <x> a,b"
+
+    def __init__(self, tokenizer, max_length=512):
+        self.tok, self.max_length = tokenizer, max_length
+        self.eos = tokenizer.eos_token_id
+        self.pad = getattr(tokenizer, "pad_token_id", 0) or 0
+        self.cache = {}
+        try:
+            self.ok = self.eos is not None and self.encode_one(self.PROBE) == tokenizer(self.PROBE, truncation=True, max_length=max_length)["input_ids"]
+        except Exception:
+            self.ok = False
+
+    def _word(self, w):
+        ids = self.cache.get(w)
+        if ids is None:
+            ids = self.tok.encode(w, add_special_tokens=False)
+            self.cache[w] = ids
+        return ids
+
+    def encode_one(self, text):
+        out = []
+        for w in text.split():
+            out.extend(self._word(w))
+        return out[: self.max_length - 1] + [self.eos]
+
+    def __call__(self, texts):
+        rows = [self.encode_one(t) for t in texts]
+        L = max(len(r) for r in rows)
+        ids = np.full((len(rows), L), self.pad, dtype=np.int64)
+        mask = np.zeros((len(rows), L), dtype=np.int64)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = r
+            mask[i, : len(r)] = 1
+        return ids, mask
+
+
 class Collator:
-    def __init__(self, tokenizer):
+    def __init__(self, tokenizer, fast=True):
         self.tokenizer = tokenizer
         self._starts = None
         self._pad_id = getattr(tokenizer, "pad_token_id", 0) or 0
+        self._fast = WordCacheEncoder(tokenizer) if fast else None
+        if self._fast is not None and not self._fast.ok:
+            self._fast = None
 
     def _start_table(self, max_id: int) -> np.ndarray:
         if self._starts is None or len(self._starts) <= max_id:
@@ -55,12 +102,12 @@ class Collator:
         return ww
 
     def _common(self, batch):
-        input_ids, input_attention = _encode(self.tokenizer, [b["input"] for b in batch])
-        output_ids, output_attention = _encode(self.tokenizer, [b["output"] for b in batch])
-        ids = np.asarray(input_ids, dtype=np.int64)
+        enc = self._fast if self._fast is not None else (lambda texts: tuple(np.asarray(x, dtype=np.int64) for x in _encode(self.tokenizer, texts)))
+        ids, input_attention = enc([b["input"] for b in batch])
+        output_ids, output_attention = enc([b["output"] for b in batch])
         ww = self.whole_word_ids(ids)
-        return (torch.from_numpy(ids), torch.tensor(input_attention), torch.from_numpy(ww), torch.tensor(output_ids),
-                torch.tensor(output_attention))
+        return (torch.from_numpy(ids), torch.from_numpy(input_attention), torch.from_numpy(ww), torch.from_numpy(output_ids),
+                torch.from_numpy(output_attention))
 
     def __call__(self, batch):
         return self._common(batch)

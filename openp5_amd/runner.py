@@ -59,6 +59,42 @@ def masked_mean_loss(nll, output_attention):
     return (loss.sum(dim=1) / m.sum(dim=1).clamp(min=1)).mean()
 
 
+class Prefetcher:
+    """Background collation: the DataLoader (tokenisation + whole-word ids, num_workers=0 as in main.py:61) runs in a thread
+    and stays `depth` batches ahead, so host-side batch preparation overlaps the asynchronously issued GPU step instead of
+    serialising with it (the reference collates in the training loop)."""
+
+    def __init__(self, loader, depth=3, pin=False):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=depth)
+        self.pin = pin
+        self._done = object()
+        self.err = None
+
+        def work():
+            try:
+                for batch in loader:
+                    if self.pin:
+                        batch = [t.pin_memory() if torch.is_tensor(t) else t for t in batch]
+                    self.q.put(batch)
+            except BaseException as e:   # surfaced in the consumer
+                self.err = e
+            self.q.put(self._done)
+
+        self.t = threading.Thread(target=work, daemon=True)
+        self.t.start()
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is self._done:
+                if self.err is not None:
+                    raise self.err
+                return
+            yield item
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -131,7 +167,7 @@ class DistributedRunner:
             self.model.train()
             losses, n_samples = [], 0
             t0 = time.perf_counter()
-            for batch in self.train_loader:
+            for batch in Prefetcher(self.train_loader, pin=torch.cuda.is_available()):
                 input_ids, attn, whole_ids, output_ids, output_attention = self._to_dev(batch)[:5]
                 out = self.model(input_ids=input_ids, whole_word_ids=whole_ids, attention_mask=attn, labels=output_ids,
                                  alpha=self.args.alpha, return_dict=True)

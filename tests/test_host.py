@@ -214,3 +214,21 @@ def test_dataset_and_sampler_equal_reference(tmp_path):
         sr = RS.DistMultiDataTaskSampler(ConcatDataset([ref]), 4, 2, 1, seed=2023)
         sm.set_epoch(epoch); sr.set_epoch(epoch)
         assert list(iter(sm)) == list(iter(sr)) and len(sm) == len(sr)
+
+
+def test_word_cache_encoder_equals_tokenizer(tok, tmp_path):
+    """the cached word-level tokenisation used by the collator is identical to the tokenizer's own batch encoding"""
+    from openp5_amd.collator import WordCacheEncoder
+    args = make_args(str(tmp_path))
+    random.seed(1)
+    ds = MultiTaskDataset(args, "Toy", "train")
+    texts = [ds[i]["input"] for i in range(0, len(ds), 7)] + [ds[i]["output"] for i in range(0, len(ds), 11)]
+    texts += ["  leading and   multiple   spaces ", "x" * 5 + " " + " ".join(f"item_{i}" for i in range(700))]    # incl. a > 512-token prompt
+    enc = WordCacheEncoder(tok)
+    assert enc.ok
+    ids, mask = enc(texts)
+    ref = tok(texts, padding="longest", truncation=True, max_length=512)
+    assert ids.tolist() == ref["input_ids"] and mask.tolist() == ref["attention_mask"]
+    a = Collator(tok, fast=True)([{"input": t, "output": "Toy item_1001"} for t in texts[:9]])
+    b = Collator(tok, fast=False)([{"input": t, "output": "Toy item_1001"} for t in texts[:9]])
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
