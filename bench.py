@@ -243,8 +243,13 @@ def main():
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
-            "roofline": {"bound": "mfma", "kernel": "p5_gemm_kernel<bf16,128,128,KC,KC>", "shape": [Mg, Ng, Kg], "achieved": ach,
-                         "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, "traffic": None,
+            # dominant kernel family = the bf16 MFMA GEMM (forward / dgrad / wgrad instantiations are ~70 % of the step,
+            # profiles/r01_train_t5small_b64_kernel_stats.md); timed live on its largest forward shape.  `traffic` is the
+            # PMC-measured HBM bytes per launch of exactly this kernel+shape (2 x FETCH_SIZE + WRITE_SIZE with the gfx950
+            # correction, profiles/r01_pmc_gemm.md) -- a recorded measurement, not collected inside this run.
+            "roofline": {"bound": "mfma", "kernel": "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>", "shape": [Mg, Ng, Kg],
+                         "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                         "traffic": 75.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None, "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
                          "avg_launch_us": t_k * 1e6},
         }
         if not args.no_cpu and world == 1:
