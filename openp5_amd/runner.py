@@ -246,7 +246,18 @@ class DistributedRunner:
         return results
 
     def _item_sequences(self, ds, candidates):
-        return [[0] + self.tokenizer.encode(f"{ds.dataset} item_{c}") for c in candidates]
+        """[decoder start] + token ids of "<dataset> item_<id>" per candidate (DistributedRunner.py:344-350); tokenised once per
+        item and cached -- the per-user filtered protocol (:286-297) would otherwise re-tokenise every item for every user."""
+        cache = self.__dict__.setdefault("_item_tok_cache", {})
+        out = []
+        for c in candidates:
+            key = (ds.dataset, c)
+            seq = cache.get(key)
+            if seq is None:
+                seq = [0] + self.tokenizer.encode(f"{ds.dataset} item_{c}")
+                cache[key] = seq
+            out.append(seq)
+        return out
 
     def _generate(self, batch, fn, num_beams, max_length):
         input_ids, attn, whole_ids, output_ids = batch[0], batch[1], batch[2], batch[3]
