@@ -73,9 +73,10 @@ int p5_backward(P5Engine* e, const float* dnll, void* stream);
 /* arena range [begin,end) whose gradients are final once `stage` has run (for bucketed all-reduce) */
 int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end);
 
-int p5_grad_sumsq(const float* grads, int64_t n, float* out_scalar, void* stream);   /* out += sum g^2 */
+/* out_partials: float[1024], fully overwritten; p5_adamw_step sums them in a fixed order (bit-identical on every rank) */
+int p5_grad_sumsq(const float* grads, int64_t n, float* out_partials, void* stream);
 int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n,
-                  const float* sumsq /* or NULL */, float max_norm, float grad_scale, float lr, float beta1, float beta2,
+                  const float* sumsq /* float[1024] from p5_grad_sumsq, or NULL = no clipping */, float max_norm, float grad_scale, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step_t, void* stream);
 
 /* ---- generation ---- */

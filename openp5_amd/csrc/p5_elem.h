@@ -350,13 +350,14 @@ __global__ __launch_bounds__(256) void p5_sumsq_kernel(float* __restrict__ out, 
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
   s = block_reduce(s, false, sred);
-  if (threadIdx.x == 0) atomicAdd(out, s);
-}
+  if (threadIdx.x == 0) out[blockIdx.x] = s;     // one partial per workgroup: summed in a fixed order by the consumer, so
+}                                                // every data-parallel rank derives bit-identical clip factors
+#define P5_SUMSQ_PARTS 1024
 
 struct P5AdamArgs {
   float* p; const float* g; float* m; float* v;
   void* shadow;            // bf16 compute copy or nullptr
-  const float* sumsq;      // device scalar: sum of squared grads (already all-reduced); nullptr => no clipping
+  const float* sumsq;      // device float[P5_SUMSQ_PARTS] partial sums of squared grads; nullptr => no clipping
   size_t n;
   float lr, beta1, beta2, eps, wd, max_norm, grad_scale;
   float bc1, bc2;          // 1 - beta1^t, 1 - beta2^t
@@ -365,7 +366,16 @@ struct P5AdamArgs {
 __global__ __launch_bounds__(256) void p5_adamw_kernel(P5AdamArgs a) {
   float coef = a.grad_scale;
   if (a.sumsq) {
-    const float norm = sqrtf(*a.sumsq) * a.grad_scale;
+    __shared__ float sp[256];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < P5_SUMSQ_PARTS; i += 256) t += a.sumsq[i];      // fixed order -> deterministic
+    sp[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if ((int)threadIdx.x < st) sp[threadIdx.x] += sp[threadIdx.x + st];
+      __syncthreads();
+    }
+    const float norm = sqrtf(sp[0]) * a.grad_scale;
     const float c = a.max_norm / (norm + 1e-6f);
     coef *= (c < 1.f ? c : 1.f);
   }

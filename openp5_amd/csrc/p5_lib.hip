@@ -1011,7 +1011,7 @@ int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_
 }
 
 int p5_grad_sumsq(const float* grads, int64_t n, float* out_scalar, void* stream) {
-  P5_LAUNCH(p5_sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out_scalar, grads, (size_t)n);
+  P5_LAUNCH(p5_sumsq_kernel, dim3(P5_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, out_scalar, grads, (size_t)n);
   return P5_KCHECK();
 }
 int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq, float max_norm,

@@ -420,6 +420,10 @@ class P5T5Native(nn.Module):
             for w in self._pending:
                 w.wait()
             self._pending = []
+            if self._side is not None:
+                # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
+                # stream they were issued from (gloo on device tensors) need the explicit edge side -> main
+                torch.cuda.current_stream().wait_stream(self._side)
         else:
             self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
         for name, p in self.named_parameters():

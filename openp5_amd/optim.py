@@ -31,7 +31,7 @@ class FusedAdamW:
         dev = model._flat.device
         self.m = torch.zeros_like(model._flat)
         self.v = torch.zeros_like(model._flat)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1024, dtype=torch.float32, device=dev)    # per-workgroup partial sums of g^2
 
     def current_lr(self):
         if self.total_steps <= 0:
@@ -47,7 +47,6 @@ class FusedAdamW:
         world = max(1, int(getattr(mdl, "ddp_world", 1)))
         use_clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if use_clip:
-            self.sumsq.zero_()
             be.check(lib.p5_grad_sumsq(P(mdl._grads), mdl._n, P(self.sumsq), sp), "p5_grad_sumsq")
         be.check(lib.p5_adamw_step(P(mdl._flat), P(mdl._grads), P(self.m), P(self.v), P(mdl._shadow), mdl._n,
                                    P(self.sumsq) if use_clip else None, float(self.max_grad_norm or 0.0), 1.0 / world,
@@ -59,7 +58,7 @@ class FusedAdamW:
         self.model.zero_grad()
 
     def grad_norm(self):
-        return math.sqrt(float(self.sumsq.item()))
+        return math.sqrt(float(self.sumsq.double().sum().item())) / max(1, int(getattr(self.model, "ddp_world", 1)))
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t, "sched_steps": self.sched_steps}
