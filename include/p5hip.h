@@ -80,13 +80,16 @@ int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* s
                   float eps, float weight_decay, int step_t, void* stream);
 
 /* ---- generation ---- */
-int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children);
+int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children, int excluded_words);
 /* trie in CSR: child_off[n_nodes+1], child_tok/child_node[n_edges]; node 0 = empty prefix.
  * out_seq int32 [B,K,max_len] (pad-filled, starts with pad=decoder start), out_score fp32 [B,K], out_len int32 [B,K].
- * host_flags: 2 ints of HOST-visible pinned memory used for the early-exit check (or NULL: run all steps). */
+ * excluded_nodes: optional uint32 bitmap [B, excluded_words] over trie node ids; bit n of row b set = node n does not
+ * exist in item b's trie (the per-user history exclusion of the filtered protocol, DistributedRunner.py:286-297,
+ * without building one trie per user).  NULL / 0 = nothing excluded. */
 int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
-                const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
+                const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,
+                const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
 /* step-wise variant for arbitrary Python prefix_allowed_tokens_fn callables is built from the two calls below */
 int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
               int B, int L, void* enc_out /* T [B*L, d] */, void* ws, int64_t ws_bytes, void* stream);

@@ -35,8 +35,8 @@ PROTOTYPES = {
     "p5_backward_stage_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
-    "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32]),
-    "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp]),
+    "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
+    "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
     "p5_encode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i64, vp]),
     "p5_op_gemm": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, u32, f32, vp]),
     "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),

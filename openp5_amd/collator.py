@@ -76,8 +76,12 @@ class WordCacheEncoder:
 
 
 class Collator:
-    def __init__(self, tokenizer, fast=True):
+    def __init__(self, tokenizer, fast=True, solo_rows=False):
+        """solo_rows: compute whole-word ids as if every row were collated alone.  The reference zeroes only the last
+        COLUMN of the padded batch, so its inputs depend on batch composition; the per-user filtered protocol is defined at
+        batch size 1 (DistributedRunner.py:271-337), and this flag lets it be batched with bit-identical inputs."""
         self.tokenizer = tokenizer
+        self.solo_rows = bool(solo_rows)
         self._starts = None
         self._pad_id = getattr(tokenizer, "pad_token_id", 0) or 0
         self._fast = WordCacheEncoder(tokenizer) if fast else None
@@ -99,6 +103,9 @@ class Collator:
         base = np.maximum.accumulate(np.where(is_pad, c, 0), axis=1)
         ww = c - base
         ww[:, -1] = 0
+        if self.solo_rows:     # what each row would get in a batch of its own: its last real token (</s>) is "the last column"
+            n = (~is_pad).sum(axis=1)
+            ww[np.arange(len(ww)), np.maximum(n, 1) - 1] = 0
         return ww
 
     def _common(self, batch):

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
                                                           const float* __restrict__ logits, int ldl, int V,
                                                           const int* __restrict__ node, const float* __restrict__ run_score,
                                                           const int* __restrict__ child_off, const int* __restrict__ child_tok,
-                                                          int max_c, int K2) {
+                                                          const int* __restrict__ child_node, const uint32_t* __restrict__ excluded,
+                                                          int excl_words, int Kb, int max_c, int K2) {
   __shared__ float sm[4], ss[4];
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
@@ -201,7 +202,17 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
   const float rs = run_score[r];
   const bool in_lds = nc <= P5_ROW_LDS_CAND;
   float* cs = in_lds ? sc : cand_score + (size_t)r * max_c;
-  for (int c = tid; c < nc; c += 256) cs[c] = (lr[child_tok[c0 + c]] - lse) + rs;
+  // per-item excluded-node bitmap (filtered evaluation, DistributedRunner.py:286-297): a child whose subtree holds only
+  // items the user has already interacted with does not exist in that user's trie
+  const uint32_t* ex = excluded ? excluded + (size_t)(r / Kb) * excl_words : nullptr;
+  for (int c = tid; c < nc; c += 256) {
+    float v = (lr[child_tok[c0 + c]] - lse) + rs;
+    if (ex) {
+      const int cn = child_node[c0 + c];
+      if ((ex[cn >> 5] >> (cn & 31)) & 1u) v = P5_NEG_INF;
+    }
+    cs[c] = v;
+  }
   __syncthreads();
   const int want = K2 < nc ? K2 : nc;
   for (int it = 0; it < want; ++it) {
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
       if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
     }
     block_argmax(bv, bi, s_val, s_idx);
-    if (bi == 0x7fffffff) {            // only -inf left (cannot happen for finite logits); stop early
+    if (bi == 0x7fffffff) {            // only excluded children left; stop early
       if (tid == 0) n_top[r] = it;
       return;
     }

@@ -149,7 +149,7 @@ struct Bump {
   }
 };
 
-struct GraphKey { int B, L, K, max_len, max_c; const void *ws, *trie, *roots, *P, *S; int sz; };
+struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S; int sz; };
 
 struct P5Engine {
   P5Config c;
@@ -734,10 +734,11 @@ struct GenWs {
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
   float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
   int64_t* mask_copy;
+  uint32_t* excluded;     // [B, excl_words] copy of the caller's per-item excluded-node bitmap (stable address for the graph)
   P5BeamState st;
 };
 
-static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_len, int max_c, GenWs* g) {
+static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_len, int max_c, int excl_words, GenWs* g) {
   const P5Config& c = e->c;
   const size_t sz = c.dtype == 1 ? 2 : 4;
   const int d = c.d_model, in = e->inner, F = c.d_ff;
@@ -760,6 +761,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.row_top_score = (float*)b.take(R * (size_t)(2 * K) * 4);
   w.row_top_c = (int*)b.take(R * (size_t)(2 * K) * 4);
   w.mask_copy = (int64_t*)b.take((size_t)B * L * 8);
+  w.excluded = (uint32_t*)b.take((size_t)B * (excl_words > 0 ? excl_words : 0) * 4 + 16);
   P5BeamState& st = w.st;
   st.run_seq = (int*)b.take(R * max_len * 4); st.run_seq_next = (int*)b.take(R * max_len * 4);
   st.fin_seq = (int*)b.take(R * max_len * 4); st.fin_seq_next = (int*)b.take(R * max_len * 4);
@@ -817,11 +819,13 @@ static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, 
 
 template <class T>
 static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
-                         const int* roots, int max_c, int* out_seq, float* out_score, int* out_len, char* ws, hipStream_t s) {
+                         const int* roots, const uint32_t* excluded, int excl_words, int max_c, int* out_seq, float* out_score, int* out_len,
+                         char* ws, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, R = B * K;
   GenWs w;
-  layout_gen(e, ws, B, L, K, max_len, max_c, &w);
+  layout_gen(e, ws, B, L, K, max_len, max_c, excl_words, &w);
+  if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
   P5_TRY(encoder_fwd<T>(e, s));
   for (int i = 0; i < c.n_dec_layers; ++i)
@@ -831,11 +835,13 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   P5_TRY(P5_KCHECK());
   const int Vp = (c.vocab_size + 63) / 64 * 64;
   hipMemcpyAsync(w.mask_copy, e->mask, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s);
+  if (excl_words > 0) hipMemcpyAsync(w.excluded, excluded, (size_t)B * excl_words * 4, hipMemcpyDeviceToDevice, s);
+  const uint32_t* excl = excl_words > 0 ? w.excluded : nullptr;
   auto step_body = [&]() -> int {
     hipMemsetAsync(w.st.flags, 0, 8, s);
     P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
     P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_cand, (const float*)w.logits, Vp,
-              c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, max_c, 2 * K);
+              c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, child_node, excl, excl_words, K, max_c, 2 * K);
     P5_TRY(P5_KCHECK());
     P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
               (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, c.eos_id, R);
@@ -848,7 +854,7 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   static const bool use_graph = !(getenv("P5_NO_GRAPH") && atoi(getenv("P5_NO_GRAPH")));
   GraphKey key;
   memset(&key, 0, sizeof(key));
-  key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.ws = ws; key.trie = child_off; key.roots = roots;
+  key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.excl_words = excl_words; key.ws = ws; key.trie = child_off; key.trie_tok = child_tok; key.trie_node = child_node; key.roots = roots;
   key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T);
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
   auto capture = [&]() {
@@ -1025,26 +1031,27 @@ int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* s
   return P5_KCHECK();
 }
 
-int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children) {
+int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int max_len, int max_children, int excluded_words) {
   P5Engine tmp = *e;
-  return layout_gen(&tmp, nullptr, B, L, K, max_len, max_children, nullptr);
+  return layout_gen(&tmp, nullptr, B, L, K, max_len, max_children, excluded_words, nullptr);
 }
 int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
-                int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots, int max_children,
-                int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
+                int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
+                const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
   P5_REQUIRE(e->P, "engine not bound");
   P5_REQUIRE(K >= 1 && K <= 64, "1 <= num_beams <= 64");
   P5_REQUIRE(max_len >= 2 && max_len <= 64, "2 <= max_length <= 64");
   P5_REQUIRE(L >= 1 && L <= 512, "1 <= L <= 512");
   P5_REQUIRE(max_children >= 1, "max_children");
   P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");
-  const int64_t need = layout_gen(e, nullptr, B, L, K, max_len, max_children, nullptr);
+  P5_REQUIRE(excluded_words >= 0 && (excluded_nodes || excluded_words == 0), "excluded_nodes / excluded_words");
+  const int64_t need = layout_gen(e, nullptr, B, L, K, max_len, max_children, excluded_words, nullptr);
   P5_REQUIRE(ws_bytes >= need, "workspace too small");
   e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
   return e->c.dtype == 1
-             ? generate_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, max_children, out_seq, out_score, out_len, (char*)ws,
+             ? generate_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children, out_seq, out_score, out_len, (char*)ws,
                                    (hipStream_t)stream)
-             : generate_impl<float>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, max_children, out_seq, out_score, out_len,
+             : generate_impl<float>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children, out_seq, out_score, out_len,
                                     (char*)ws, (hipStream_t)stream);
 }
 int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L,

@@ -55,3 +55,36 @@ def get_metrics_results(rel, metrics):
         elif name.startswith("ndcg"):
             res.append(ndcg_at_k(rel, int(k)))
     return np.array(res)
+
+
+# ---- token-id form of the same metrics: no batch_decode, no strings, no per-batch D2H.  Under the item trie
+# a generated sequence IS an item's token sequence, so string equality after decoding (DistributedRunner.py:376-387) and
+# token equality agree; the K hypotheses are ranked by score with a stable sort exactly like `_ranked`. ----
+def rel_results_ids(sequences, scores, gold_ids, k, pad_id=0):
+    """sequences [B*k, S] int (column 0 = decoder start), scores [B*k], gold_ids [B, T] -> bool [B, k] on the same device."""
+    import torch
+    import torch.nn.functional as F
+    B = gold_ids.shape[0]
+    gen = sequences.reshape(B, k, -1)[:, :, 1:]
+    width = max(gen.shape[-1], gold_ids.shape[-1])
+    gen = F.pad(gen, (0, width - gen.shape[-1]), value=pad_id)
+    gold = F.pad(gold_ids, (0, width - gold_ids.shape[-1]), value=pad_id)
+    rel = (gen == gold[:, None, :]).all(-1)
+    order = torch.sort(scores.reshape(B, k), dim=1, descending=True, stable=True).indices
+    return torch.gather(rel, 1, order)
+
+
+def get_metrics_results_ids(rel, metrics):
+    """float64 [len(metrics)] sums over users, left on rel's device."""
+    import torch
+    relf = rel.to(torch.float64)
+    disc = 1.0 / torch.log2(torch.arange(rel.shape[1], device=rel.device, dtype=torch.float64) + 2.0)
+    out = []
+    for m in metrics:
+        name, k = m.lower().split("@")
+        k = int(k)
+        if name.startswith("hit"):
+            out.append((relf[:, :k].sum(1) > 0).to(torch.float64).sum())
+        elif name.startswith("ndcg"):
+            out.append((relf[:, :k] * disc[:k]).sum())
+    return torch.stack(out)

@@ -453,10 +453,11 @@ class P5T5Native(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, whole_word_ids=None, max_length: int = 20,
                  prefix_allowed_tokens_fn: Optional[Callable] = None, num_beams: int = 1, num_return_sequences: Optional[int] = None,
-                 output_scores: bool = False, return_dict_in_generate: bool = False, trie=None, roots=None, **unused):
+                 output_scores: bool = False, return_dict_in_generate: bool = False, trie=None, roots=None, excluded=None, **unused):
         """Constrained beam search (DistributedRunner.py:361-371).  `prefix_allowed_tokens_fn` made by
         `openp5_amd.trie.prefix_allowed_tokens_fn` -- or by the reference's own generation_trie.prefix_allowed_tokens_fn,
-        whose closure holds the Trie -- runs fully on the device.  `trie` may be passed directly (Trie / CompiledTrie)."""
+        whose closure holds the Trie -- runs fully on the device.  `trie` may be passed directly (Trie / CompiledTrie).
+        `excluded`: optional uint32 [B, words] bitmap from `CompiledTrie.excluded_bitmap` -- per-user history exclusion."""
         dev = self._be.device
         K = int(num_beams)
         nret = int(num_return_sequences or K)
@@ -490,12 +491,19 @@ class P5T5Native(nn.Module):
             roots_t = torch.as_tensor(roots, dtype=torch.int32, device=dev).contiguous()
         self._sync_shadow()
         maxc = max(1, trie.max_children)
-        ws = self._workspace(self._lib.p5_generate_workspace_bytes(self._engine, B, L, K, max_length, maxc), "_gen_ws")
+        excl_t, excl_words = None, 0
+        if excluded is not None:
+            excl_np = np.ascontiguousarray(excluded.cpu().numpy() if torch.is_tensor(excluded) else excluded, dtype=np.uint32)
+            if excl_np.ndim != 2 or excl_np.shape[0] != B or excl_np.shape[1] * 32 < trie.n_nodes:
+                raise ValueError(f"excluded bitmap must be [B={B}, >= {(trie.n_nodes + 31) // 32}] uint32, got {excl_np.shape}")
+            excl_words = int(excl_np.shape[1])
+            excl_t = torch.from_numpy(excl_np.view(np.int32)).to(dev)
+        ws = self._workspace(self._lib.p5_generate_workspace_bytes(self._engine, B, L, K, max_length, maxc, excl_words), "_gen_ws")
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)
         ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
         self._be.check(self._lib.p5_generate(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), B, L, K, max_length,
-                                             _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, _ptr(seq), _ptr(score), _ptr(ln), _ptr(ws),
+                                             _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), _ptr(excl_t), excl_words, maxc, _ptr(seq), _ptr(score), _ptr(ln), _ptr(ws),
                                              ws.numel(), self._be.stream_ptr()), "p5_generate")
         out_len = 1 + int(ln[:, :nret].max().item())
         sequences = seq[:, :nret, :out_len].reshape(B * nret, out_len).to(torch.int64)

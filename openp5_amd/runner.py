@@ -22,7 +22,7 @@ from . import evaluate
 from .collator import Collator, TestCollator
 from .data import TestDataset
 from .optim import FusedAdamW
-from .trie import Trie, prefix_allowed_tokens_fn
+from .trie import CompiledTrie, Trie, prefix_allowed_tokens_fn
 
 
 def parse_runner_args(parser):
@@ -47,6 +47,8 @@ def parse_runner_args(parser):
     parser.add_argument("--test_before_train", type=int, default=1, help="whether test before training")
     parser.add_argument("--test_filtered", type=int, default=0, help="whether filter out the items in the training data.")
     parser.add_argument("--test_filtered_batch", type=int, default=1, help="whether testing with filtered data in batch.")
+    parser.add_argument("--id_metrics", type=int, default=1, help="compare generated token ids with the gold ids on the device "
+                        "instead of decoding to strings (same Hit/NDCG; 0 = the reference's string path).")
     parser.add_argument("--compute_dtype", type=str, default="bf16", help="bf16 (fast) or fp32 (parity) engine arithmetic")
     return parser
 
@@ -114,6 +116,7 @@ class DistributedRunner:
         self.test_epoch, self.valid_select = args.test_epoch, args.valid_select
         self.test_before_train = args.test_before_train
         self.test_filtered, self.test_filtered_batch = args.test_filtered, args.test_filtered_batch
+        self.id_metrics = int(getattr(args, "id_metrics", 1))
         self.metrics = args.metrics.split(",")
         self.generate_num = max(int(m.split("@")[1]) for m in self.metrics)
         self.get_testloader()
@@ -137,7 +140,8 @@ class DistributedRunner:
 
     def get_testloader(self):
         self.testloaders = []
-        collator = TestCollator(self.tokenizer) if self.test_filtered > 0 else Collator(self.tokenizer)
+        collator = (TestCollator(self.tokenizer, solo_rows=(self.test_filtered_batch == 0)) if self.test_filtered > 0
+                    else Collator(self.tokenizer))
         for dataset in self.args.datasets.split(","):
             for task in self.args.tasks.split(","):
                 testdata = TestDataset(self.args, dataset, task)
@@ -239,7 +243,6 @@ class DistributedRunner:
                 if self.test_filtered_batch > 0:
                     results.append(self.test_dataset_task_filtered_batch(loader))
                 else:
-                    assert self.args.eval_batch_size == 1
                     results.append(self.test_dataset_task_filtered(loader))
             else:
                 results.append(self.test_dataset_task(loader))
@@ -268,8 +271,28 @@ class DistributedRunner:
         gen = self.tokenizer.batch_decode(pred["sequences"], skip_special_tokens=True)
         return gold, gen, pred["sequences_scores"].detach().cpu().tolist()
 
+    def _generate_ids(self, batch, num_beams, max_length, **kw):
+        """ID-level evaluation of one batch: bool relevance [B, K] on the device (no decode to strings)."""
+        pred = self.model.generate(input_ids=batch[0], attention_mask=batch[1], whole_word_ids=batch[2], max_length=max_length,
+                                   num_beams=num_beams, num_return_sequences=num_beams, output_scores=True,
+                                   return_dict_in_generate=True, **kw)
+        return evaluate.rel_results_ids(pred["sequences"], pred["sequences_scores"], batch[3].to(pred["sequences"].device), num_beams)
+
+    def _dataset_trie(self, ds):
+        """Item trie of a dataset, compiled once, with the item -> path index used for per-user exclusion."""
+        cache = self.__dict__.setdefault("_trie_cache", {})
+        ent = cache.get(ds.dataset)
+        if ent is None:
+            items = list(ds.all_items)
+            seqs = self._item_sequences(ds, items)
+            trie = Trie(seqs)
+            ct = CompiledTrie.from_trie(trie)
+            ct.index_items(seqs)
+            ent = cache[ds.dataset] = (trie, ct, {it: i for i, it in enumerate(items)})
+        return ent
+
     def _finish(self, metrics_res, test_total, testloader, t0):
-        metrics_res = torch.tensor(metrics_res, dtype=torch.float64, device=self.device)
+        metrics_res = torch.as_tensor(metrics_res, dtype=torch.float64).to(self.device)
         total = torch.tensor(float(test_total), dtype=torch.float64, device=self.device)
         if self.world > 1:
             dist.all_reduce(metrics_res, op=dist.ReduceOp.SUM)
@@ -287,30 +310,46 @@ class DistributedRunner:
     def test_dataset_task(self, testloader):
         """DistributedRunner.py:339-399 (max_length 50 there)."""
         ds = testloader.dataset
-        fn = prefix_allowed_tokens_fn(Trie(self._item_sequences(ds, ds.all_items)))
-        metrics_res, test_total, t0 = np.zeros(len(self.metrics)), 0, time.perf_counter()
+        trie, ct, _ = self._dataset_trie(ds)
+        fn = prefix_allowed_tokens_fn(trie)
+        metrics_res, test_total, t0 = 0, 0, time.perf_counter()
         for batch in testloader:
-            gold, gen, scores = self._generate(self._to_dev(batch), fn, self.generate_num, 50)
-            rel = evaluate.rel_results(gen, gold, scores, self.generate_num)
+            batch = self._to_dev(batch)
+            if self.id_metrics:
+                rel = self._generate_ids(batch, self.generate_num, 50, trie=ct)
+                metrics_res = metrics_res + evaluate.get_metrics_results_ids(rel, self.metrics)
+            else:
+                gold, gen, scores = self._generate(batch, fn, self.generate_num, 50)
+                rel = evaluate.rel_results(gen, gold, scores, self.generate_num)
+                metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
             test_total += len(rel)
-            metrics_res += evaluate.get_metrics_results(rel, self.metrics)
         return self._finish(metrics_res, test_total, testloader, t0)
 
     @torch.no_grad()
     def test_dataset_task_filtered(self, testloader):
         """DistributedRunner.py:271-337: one trie per user = all items minus the user's history."""
         ds = testloader.dataset
-        candidates = set(ds.all_items)
-        metrics_res, test_total, t0 = np.zeros(len(self.metrics)), 0, time.perf_counter()
+        _, ct, index = self._dataset_trie(ds)
+        metrics_res, test_total, t0 = 0, 0, time.perf_counter()
         for batch in testloader:
             batch = self._to_dev(batch)
-            user_idx = int(batch[5][0])
-            positive = ds.positive[ds.id2user[user_idx]]
-            fn = prefix_allowed_tokens_fn(Trie(self._item_sequences(ds, candidates - positive)))
-            gold, gen, scores = self._generate(batch, fn, self.generate_num, 30)
-            rel = evaluate.rel_results(gen, gold, scores, self.generate_num)
+            # the reference rebuilds Trie(all_items - positive) per user (hence its eval_batch_size == 1); here the shared
+            # device trie is used with one excluded-node bitmap per user, so any batch size works
+            users = [ds.id2user[int(u)] for u in batch[5].detach().cpu().tolist()]
+            excluded = ct.excluded_bitmap([[index[i] for i in ds.positive[u] if i in index] for u in users])
+            if self.id_metrics:
+                rel = self._generate_ids(batch, self.generate_num, 30, trie=ct, excluded=excluded)
+                metrics_res = metrics_res + evaluate.get_metrics_results_ids(rel, self.metrics)
+            else:
+                input_ids, attn, whole_ids, output_ids = batch[0], batch[1], batch[2], batch[3]
+                pred = self.model.generate(input_ids=input_ids, attention_mask=attn, whole_word_ids=whole_ids, max_length=30, trie=ct,
+                                           excluded=excluded, num_beams=self.generate_num, num_return_sequences=self.generate_num,
+                                           output_scores=True, return_dict_in_generate=True)
+                gold = self.tokenizer.batch_decode(output_ids, skip_special_tokens=True)
+                gen = self.tokenizer.batch_decode(pred["sequences"], skip_special_tokens=True)
+                rel = evaluate.rel_results(gen, gold, pred["sequences_scores"].detach().cpu().tolist(), self.generate_num)
+                metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
             test_total += len(rel)
-            metrics_res += evaluate.get_metrics_results(rel, self.metrics)
         return self._finish(metrics_res, test_total, testloader, t0)
 
     @torch.no_grad()
@@ -319,14 +358,14 @@ class DistributedRunner:
         ds = testloader.dataset
         fn = prefix_allowed_tokens_fn(Trie(self._item_sequences(ds, set(ds.all_items))))
         width = self.generate_num + ds.max_positive
-        metrics_res, test_total, t0 = np.zeros(len(self.metrics)), 0, time.perf_counter()
+        metrics_res, test_total, t0 = 0, 0, time.perf_counter()
         for batch in testloader:
             batch = self._to_dev(batch)
             gold, gen, scores = self._generate(batch, fn, width, 30)
             rel = evaluate.rel_results_filtered(ds.positive_text, ds.id2user, batch[5].detach().cpu().numpy(), width, gen, gold, scores,
                                                 self.generate_num)
             test_total += len(rel)
-            metrics_res += evaluate.get_metrics_results(rel, self.metrics)
+            metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
         return self._finish(metrics_res, test_total, testloader, t0)
 
 

@@ -126,6 +126,43 @@ class CompiledTrie:
     def from_sequences(seqs: Iterable[Sequence[int]]) -> "CompiledTrie":
         return CompiledTrie.from_trie(Trie(seqs))
 
+    # ---- per-user exclusion without per-user tries (DistributedRunner.py:286-297 rebuilds a Trie over
+    # `all_items - positive` for every user; the same trie is "the full trie minus every node all of whose items are
+    # excluded", which is a bitmap over node ids) ----
+    def index_items(self, seqs: Sequence[Sequence[int]]) -> None:
+        """Record, for each item sequence (in the caller's order), the node ids along its path."""
+        edge = {}
+        off, tok, nxt = self.child_off, self.child_tok, self.child_node
+        for n in range(self.n_nodes):
+            for e in range(off[n], off[n + 1]):
+                edge[(n, int(tok[e]))] = int(nxt[e])
+        depth = max((len(q) for q in seqs), default=0)
+        paths = np.full((len(seqs), depth), -1, dtype=np.int32)
+        for i, q in enumerate(seqs):
+            n = 0
+            for j, t in enumerate(q):
+                n = edge[(n, int(t))]
+                paths[i, j] = n
+        self.item_paths = paths
+        cnt = np.zeros(self.n_nodes, dtype=np.int64)
+        np.add.at(cnt, paths[paths >= 0], 1)
+        self.items_under = cnt
+        self.excluded_words = (self.n_nodes + 31) // 32
+
+    def excluded_bitmap(self, excluded_items: Sequence[Sequence[int]]) -> np.ndarray:
+        """uint32 [B, excluded_words]: bit n of row b is set when every item below node n is in excluded_items[b]
+        (indices into the list given to `index_items`)."""
+        bm = np.zeros((len(excluded_items), self.excluded_words), dtype=np.uint32)
+        for b, items in enumerate(excluded_items):
+            items = np.unique(np.asarray(list(items), dtype=np.int64))      # a duplicate must not count twice
+            if items.size == 0:
+                continue
+            nodes = self.item_paths[items].ravel()
+            u, c = np.unique(nodes[nodes >= 0], return_counts=True)
+            dead = u[self.items_under[u] == c]
+            np.bitwise_or.at(bm[b], dead >> 5, (np.uint32(1) << (dead & 31).astype(np.uint32)))
+        return bm
+
     def children(self, node: int):
         a, b = self.child_off[node], self.child_off[node + 1]
         return self.child_tok[a:b], self.child_node[a:b]

@@ -363,6 +363,37 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
     return out
 
 
+def generate_excluded_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, frac=0.4):
+    """Per-user history exclusion (DistributedRunner.py:286-297): the shared device trie + one excluded-node bitmap per user
+    must rank exactly like the reference protocol's per-user Trie(all_items - positive)."""
+    from openp5_amd.trie import CompiledTrie
+    params = O.init_params(ocfg, 7)
+    m = build_model(be, ocfg, params, dtype)
+    m.eval()
+    ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
+    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
+    ct = CompiledTrie.from_sequences(items)
+    ct.index_items(items)
+    rnd = random.Random(seed + 1)
+    excluded = [sorted(rnd.sample(range(n_items), int(frac * n_items) if b else 0)) for b in range(B)]   # user 0: no history
+    excluded[-1] = excluded[-1] + excluded[-1][:2]                                                   # duplicates are harmless
+    out = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=max_len, trie=ct,
+                     excluded=ct.excluded_bitmap(excluded), num_beams=K, num_return_sequences=K, output_scores=True,
+                     return_dict_in_generate=True)
+    tries = [Trie([it for i, it in enumerate(items) if i not in set(ex)]) for ex in excluded]
+    with torch.no_grad():
+        s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: tries[b].get(s.tolist()), K, max_len)
+    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
+    gen = out["sequences"].view(B, K, -1).cpu().tolist()
+    for b in range(B):
+        banned = {tuple(items[i]) for i in excluded[b]}
+        for k in range(K):
+            row = gen[b][k]
+            if 1 in row:
+                assert tuple(row[:row.index(1) + 1]) not in banned
+    return out
+
+
 def train_trajectory_case(be, ocfg, B, L, T, steps=3, dtype="fp32", lr=1e-2, tol=2e-4):
     """N fused steps (forward + backward + clip + HF-AdamW + linear warmup) against the oracle's restatement of the
     reference step (DistributedRunner.py:63-87, SingleRunner.py:178-219): parameter trajectories must coincide."""

@@ -62,6 +62,11 @@ def test_generate(emu, via):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
 
 
+def test_generate_excluded_history(emu):
+    """filtered protocol: shared trie + per-user excluded-node bitmap == one Trie(all_items - positive) per user."""
+    cases.generate_excluded_case(emu, O.T5Cfg.named("tiny"), 3, 14, 5, 12, 40)
+
+
 def test_generate_few_items(emu):
     """fewer items than beams: junk (-1e9) hypotheses appear exactly as in HF."""
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 11, 6, 9, 7, seed=9, score_tol=1e4)

@@ -81,6 +81,12 @@ def test_generate_t5_small(hip):
     cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4)
 
 
+def test_generate_excluded_history(hip):
+    """filtered protocol on the device: per-user excluded-node bitmaps over the shared trie."""
+    cases.generate_excluded_case(hip, O.T5Cfg.named("tiny"), 3, 14, 5, 12, 40)
+    cases.generate_excluded_case(hip, O.T5Cfg.named("t5-small"), 4, 48, 10, 12, 300, score_tol=1e-4, frac=0.7)
+
+
 def test_train_trajectory_fp32(hip):
     cases.train_trajectory_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6)
 

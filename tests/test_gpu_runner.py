@@ -48,3 +48,44 @@ def test_runner_end_to_end(hip, tmp_path):
     runner2 = DistributedRunner(model2, tok, loader, None, hip.device, args, 0)
     res2 = runner2.test()
     assert res2 == res
+
+
+def test_filtered_evaluation_on_device(hip, tmp_path):
+    """--test_filtered 1 --test_filtered_batch 0 (the released test_command protocol): shared device trie + per-user
+    excluded-node bitmaps at batch 10 == the reference's one-trie-per-user protocol at batch 1 with string metrics."""
+    from openp5_amd import evaluate
+    from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+    tok = build_offline_tokenizer()
+    flags = ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics", "hit@1,hit@5,ndcg@10", "--batch_size", "16",
+             "--sample_num", "1,1", "--max_his", "10", "--test_filtered", "1", "--test_filtered_batch", "0"]
+    cfg = P5ModelConfig.from_backbone("t5-small", dropout_rate=0.0)
+    model = P5T5Native(cfg, dtype="fp32", backend=hip, seed=5)
+    model.resize_token_embeddings(len(tok))
+
+    def runner_for(extra):
+        args = make_args(str(tmp_path), flags + extra)
+        random.seed(0)
+        train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+        loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                            collate_fn=Collator(tok))
+        return DistributedRunner(model, tok, loader, None, hip.device, args, 0)
+
+    fast = runner_for(["--eval_batch_size", "10"])
+    got = fast.test()
+    slow = runner_for(["--eval_batch_size", "1", "--id_metrics", "0"])
+    ref = []
+    for loader in slow.testloaders:
+        ds = loader.dataset
+        sums, n = 0, 0
+        for batch in loader:
+            batch = slow._to_dev(batch)
+            positive = ds.positive[ds.id2user[int(batch[5][0])]]
+            fn = prefix_allowed_tokens_fn(Trie(slow._item_sequences(ds, set(ds.all_items) - positive)))
+            gold, gen, scores = slow._generate(batch, fn, slow.generate_num, 30)
+            rel = evaluate.rel_results(gen, gold, scores, slow.generate_num)
+            sums = sums + evaluate.get_metrics_results(rel, slow.metrics)
+            n += len(rel)
+        ref.append(dict(zip(slow.metrics, (sums / n).tolist())))
+    for g, r in zip(got, ref):
+        for k in r:
+            assert abs(g[k] - r[k]) < 1e-12, (got, ref)

@@ -232,3 +232,70 @@ def test_word_cache_encoder_equals_tokenizer(tok, tmp_path):
     a = Collator(tok, fast=True)([{"input": t, "output": "Toy item_1001"} for t in texts[:9]])
     b = Collator(tok, fast=False)([{"input": t, "output": "Toy item_1001"} for t in texts[:9]])
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_excluded_bitmap_equals_filtered_trie():
+    """full CSR trie + excluded-node bitmap allows exactly the tokens of Trie(remaining items) at every prefix."""
+    import random as _r
+    from openp5_amd.trie import CompiledTrie, Trie
+    rnd = _r.Random(4)
+    items = sorted({tuple([0, 5] + [rnd.randint(6, 12) for _ in range(rnd.randint(1, 4))] + [1]) for _ in range(200)})
+    items = [list(x) for x in items]
+    ct = CompiledTrie.from_sequences(items)
+    ct.index_items(items)
+    assert ct.items_under[ct.item_paths[0][0]] == len(items)
+    for frac in (0.0, 0.3, 0.9, 1.0):
+        ex = rnd.sample(range(len(items)), int(frac * len(items)))
+        bm = ct.excluded_bitmap([ex, []])
+        assert bm.shape == (2, (ct.n_nodes + 31) // 32) and not bm[1].any()
+        rest = Trie([it for i, it in enumerate(items) if i not in set(ex)])
+        stack = [(0, [])]
+        while stack:
+            node, prefix = stack.pop()
+            toks, kids = ct.children(node)
+            alive = [(int(t), int(k)) for t, k in zip(toks, kids) if not (bm[0][k >> 5] >> (k & 31)) & 1]
+            assert sorted(t for t, _ in alive) == sorted(rest.get(prefix)), prefix
+            stack.extend((k, prefix + [t]) for t, k in alive)
+
+
+def test_id_metrics_match_string_metrics():
+    from openp5_amd import evaluate
+    torch.manual_seed(0)
+    B, K, S = 7, 5, 6
+    gold = torch.randint(3, 9, (B, S - 2))
+    gold = torch.cat([gold, torch.ones(B, 1, dtype=torch.long), torch.zeros(B, 1, dtype=torch.long)], 1)      # ... </s> <pad>
+    seqs = torch.randint(3, 9, (B, K, S + 1))
+    seqs[:, :, 0] = 0
+    seqs[:, :, -3] = 1
+    seqs[:, :, -2:] = 0
+    for b in range(B):
+        if b % 2 == 0:
+            seqs[b, b % K, 1:1 + gold.shape[1]] = gold[b]
+            seqs[b, b % K, 1 + gold.shape[1]:] = 0
+    scores = torch.randn(B, K)
+    scores[3, 1] = scores[3, 2]                                                   # a tie: stable order must be kept
+    rel = evaluate.rel_results_ids(seqs.view(B * K, -1), scores.view(-1), gold, K)
+    as_str = lambda row: " ".join(str(int(t)) for t in row if int(t) > 1)      # what batch_decode(skip_special_tokens) keeps
+    rel_s = evaluate.rel_results([as_str(r) for r in seqs.view(B * K, -1)], [as_str(g) for g in gold], scores.view(-1).tolist(), K)
+    assert rel.int().tolist() == rel_s and rel.any()
+    metrics = ["hit@1", "hit@3", "ndcg@3", "ndcg@5"]
+    a = evaluate.get_metrics_results_ids(rel, metrics)
+    b = evaluate.get_metrics_results(rel_s, metrics)
+    assert torch.allclose(a, torch.as_tensor(b), atol=1e-12)
+
+
+def test_collator_solo_rows_equals_batch_of_one():
+    from openp5_amd.collator import TestCollator
+    from openp5_amd.tokenizer import build_offline_tokenizer
+    tok = build_offline_tokenizer(2400)
+    rows = [{"input": "Toy user_1 has interacted with Toy items item_1001 , item_1002 ; what next ?", "output": "Toy item_1003", "user_idx": 0},
+            {"input": "Toy user_2 likes item_1004", "output": "Toy item_1001", "user_idx": 1},
+            {"input": "What would Toy user_3 want after item_1002 , item_1005 ?", "output": "Toy item_1004", "user_idx": 2}]
+    batched = TestCollator(tok, solo_rows=True)(rows)
+    plain = TestCollator(tok)(rows)
+    assert not torch.equal(batched[2], plain[2])                 # the reference's quirk: only the last COLUMN is zeroed
+    for i, r in enumerate(rows):
+        one = TestCollator(tok)([r])
+        n = one[0].shape[1]
+        assert torch.equal(batched[0][i, :n], one[0][0]) and torch.equal(batched[2][i, :n], one[2][0])
+        assert int(batched[2][i, n:].sum()) == 0 and int(batched[1][i].sum()) == n

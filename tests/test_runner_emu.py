@@ -63,6 +63,53 @@ def test_runner_train_and_eval(emu, tmp_path):
     assert last < first
 
 
+def _eval_runner(emu, tmp_path, tok, extra):
+    args = make_args(str(tmp_path), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics",
+                                     "hit@1,hit@5,ndcg@5", "--batch_size", "8", "--sample_num", "1,1", "--max_his", "8"] + extra)
+    random.seed(0)
+    train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+    loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                        collate_fn=Collator(tok))
+    return DistributedRunner(tiny_model(emu, len(tok)), tok, loader, None, torch.device("cpu"), args, 0)
+
+
+def test_id_metrics_equal_string_metrics(emu, tmp_path):
+    """token-id relevance on the device == decode + string equality (DistributedRunner.py:376-387)."""
+    tok = build_offline_tokenizer(VOCAB)
+    a = _eval_runner(emu, tmp_path, tok, ["--eval_batch_size", "6", "--id_metrics", "1"]).test()
+    b = _eval_runner(emu, tmp_path, tok, ["--eval_batch_size", "6", "--id_metrics", "0"]).test()
+    assert a == b
+
+
+def test_filtered_protocol_matches_per_user_tries(emu, tmp_path):
+    """--test_filtered 1 --test_filtered_batch 0: shared trie + per-user bitmap, at batch size 5, against the reference
+    protocol restated literally: batch size 1, a fresh Trie(all_items - positive) per user, string metrics."""
+    from openp5_amd import evaluate
+    from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+    tok = build_offline_tokenizer(VOCAB)
+    flags = ["--test_filtered", "1", "--test_filtered_batch", "0"]
+    fast = _eval_runner(emu, tmp_path, tok, flags + ["--eval_batch_size", "5"])
+    got = fast.test()
+    slow = _eval_runner(emu, tmp_path, tok, flags + ["--eval_batch_size", "1", "--id_metrics", "0"])
+    got_b1 = slow.test()
+    ref = []
+    slow.model.eval()
+    for loader in slow.testloaders:
+        ds = loader.dataset
+        sums, n = 0, 0
+        for batch in loader:
+            positive = ds.positive[ds.id2user[int(batch[5][0])]]
+            fn = prefix_allowed_tokens_fn(Trie(slow._item_sequences(ds, set(ds.all_items) - positive)))
+            gold, gen, scores = slow._generate(batch, fn, slow.generate_num, 30)
+            rel = evaluate.rel_results(gen, gold, scores, slow.generate_num)
+            sums = sums + evaluate.get_metrics_results(rel, slow.metrics)
+            n += len(rel)
+        ref.append(dict(zip(slow.metrics, (sums / n).tolist())))
+    for g, g1, r in zip(got, got_b1, ref):
+        for k in r:
+            assert abs(g[k] - r[k]) < 1e-12 and abs(g1[k] - r[k]) < 1e-12, (g, g1, r)
+
+
 def _ddp_worker(rank, world, port, tmp, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
