@@ -41,6 +41,8 @@ typedef struct P5Config {
 typedef struct P5Engine P5Engine;
 
 const char* p5_last_error(void);
+/* process-wide tuning knobs (tests / benchmarks): "gemm_v2" = 0|2|3, "gemm_tile" = 0|64|128 */
+int p5_set_option(const char* name, int value);
 int p5_abi_version(void);
 int p5_is_emulator(void);   /* 1 only for the test-only host emulation build under tests/emu */
 
@@ -100,7 +102,8 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
                const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
 int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream);
 int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
-                      const float* rstd, const float* dres_in, int rows, int d, void* stream);
+                      const float* rstd, const float* dres_in, int rows, int d,
+                      float* dw_partial /* scratch float[1024*d]: the engine's partial-sum mode; NULL = atomics */, void* stream);
 int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table,
                    const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
                    int ldv, int ldo, int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);

@@ -18,6 +18,7 @@ class P5Config(C.Structure):
 # name -> (restype, argtypes)
 PROTOTYPES = {
     "p5_last_error": (C.c_char_p, []),
+    "p5_set_option": (i32, [C.c_char_p, i32]),
     "p5_abi_version": (i32, []),
     "p5_is_emulator": (i32, []),
     "p5_engine_create": (i32, [C.POINTER(P5Config), C.POINTER(vp)]),
@@ -40,7 +41,7 @@ PROTOTYPES = {
     "p5_encode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i64, vp]),
     "p5_op_gemm": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, u32, f32, vp]),
     "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),
-    "p5_op_rmsnorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "p5_op_rmsnorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "p5_op_attn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u32, f32, vp]),
     "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                             i32, i32, i32, i32, vp, u32, f32, vp]),

@@ -50,6 +50,38 @@ template <class T> struct AttnC {
   static constexpr int PPR = 64 * SZ / 16;    // 16-byte pieces per tile row
 };
 
+// A wave's [16][64] fp32 result (MFMA C layout: lane owns rows g*4+r, column li of every 16-column block) -> global rows of
+// 64 T elements.  Staged through the wave's own [16][TS] LDS scratch so that each lane issues 16-byte stores of whole
+// 128-/256-byte row segments instead of sixteen 2-byte stores (no barrier: a wave's LDS operations execute in order).
+template <class T>
+__device__ static __forceinline__ void wave_store_16x64(T* __restrict__ out, size_t ld, int row0, int row_end, const f32x4 (&acc)[4],
+                                                        const float (&rs)[4], char* pw, int lane) {
+  using C = AttnC<T>;
+  const int g = lane >> 4, li = lane & 15;
+  if ((ld % C::EPF) != 0 || ((uintptr_t)out % 16) != 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + g * 4 + r;
+      if (row >= row_end) continue;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) out[(size_t)row * ld + dt * 16 + li] = from_f<T>(acc[dt][r] * rs[r]);
+    }
+    return;
+  }
+  P5_WAVE_SYNC();      // the scratch may still be read by slower lanes of this wave (emulator)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(T*)(pw + (g * 4 + r) * C::TS + (dt * 16 + li) * C::SZ) = from_f<T>(acc[dt][r] * rs[r]);
+  P5_WAVE_SYNC();
+  constexpr int RPP = 64 / C::PPR;       // rows covered by one wave instruction
+#pragma unroll
+  for (int p = 0; p < 16 / RPP; ++p) {
+    const int lr = p * RPP + lane / C::PPR, piece = lane % C::PPR;
+    if (row0 + lr < row_end) st16(out + (size_t)(row0 + lr) * ld + piece * C::EPF, ld16(pw + lr * C::TS + piece * 16));
+  }
+}
+
 template <class T>
 __device__ static __forceinline__ void stage_tile64(char* lds, const T* base, int ld, int valid_rows, int tid) {
   using C = AttnC<T>;
@@ -234,16 +266,10 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
       }
     }
   }
-  T* O = (T*)a.O;
+  float inv[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + g * 4 + r;
-    if (qi >= a.Lq) continue;
-    const float inv = l[r] > 0.f ? 1.f / l[r] : 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      O[((size_t)b * a.Lq + qi) * a.ldo + h * 64 + dt * 16 + li] = from_f<T>(o[dt][r] * inv);
-  }
+  for (int r = 0; r < 4; ++r) inv[r] = l[r] > 0.f ? 1.f / l[r] : 0.f;
+  wave_store_16x64<T>((T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64, a.ldo, q0, a.Lq, o, inv, pw, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -365,14 +391,9 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
       for (int dt = 0; dt < 4; ++dt) mma16<T>(dq[dt], dsa, tile_frag_ks<T>(tileK, dt * 16, kc, lane));
     }
   }
-  T* dQ = (T*)a.dQ;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + g * 4 + r;
-    if (qi >= a.Lq) continue;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      dQ[((size_t)b * a.Lq + qi) * a.lddq + h * 64 + dt * 16 + li] = from_f<T>(dq[dt][r]);
+  {
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, pw, lane);
   }
   if (a.d_rel_table) {
     // relative positions -> buckets inside the workgroup, then one global atomic per (bucket, head) into one of
@@ -493,15 +514,7 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
       }
     }
   }
-  T* dK = (T*)a.dK; T* dV = (T*)a.dV;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kj = k0 + g * 4 + r;
-    if (kj >= a.Lk) continue;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dK[((size_t)b * a.Lk + kj) * a.lddk + h * 64 + dt * 16 + li] = from_f<T>(dk[dt][r]);
-      dV[((size_t)b * a.Lk + kj) * a.lddv + h * 64 + dt * 16 + li] = from_f<T>(dv[dt][r]);
-    }
-  }
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, pP, lane);
+  wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, pS, lane);
 }

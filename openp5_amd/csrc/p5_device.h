@@ -160,6 +160,28 @@ __device__ static __forceinline__ void glds16(const void* g, char* lds_wave_base
 #define P5_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// lanes of ONE wave exchanging data through LDS: hardware executes a wave's LDS operations in order, the host emulator
+// runs lanes one after the other and needs an explicit rendezvous
+#ifdef P5_EMU
+#define P5_WAVE_SYNC() emu::wave_barrier()
+#else
+#define P5_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+// ---- hand-placed waits / barrier / scheduler hints for software-pipelined main loops -----------------------
+// P5_WAIT_VM(n): wait until at most n of this wave's vector-memory ops (incl. direct-to-LDS copies) are outstanding;
+// P5_BARRIER_LDS(): workgroup barrier that orders LDS traffic only (no vmcnt(0) like __syncthreads());
+// P5_SCHED_GROUP(mask, n): next n instructions of class mask (0x008 MFMA, 0x020 VMEM read, 0x100 DS read) in the schedule.
+#ifdef P5_EMU
+#define P5_WAIT_VM(n) ((void)0)
+#define P5_BARRIER_LDS() __syncthreads()
+#define P5_SCHED_GROUP(mask, n) ((void)0)
+#else
+#define P5_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define P5_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define P5_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll

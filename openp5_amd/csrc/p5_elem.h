@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void p5_embed_bwd_kernel(float* __restrict__ d
   }
 }
 
+// EPF (4 or 8) consecutive fp32 values as 16-byte accesses (the compiler otherwise emits one dword access per element,
+// each touching every cache line of the row again)
+template <int EPF> __device__ static __forceinline__ void ldf(const float* __restrict__ p, float (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < EPF / 4; ++q) {
+    const f32x4 t = *(const f32x4*)(p + 4 * q);
+    v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+  }
+}
+template <int EPF> __device__ static __forceinline__ void stf(float* __restrict__ p, const float (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < EPF / 4; ++q) *(f32x4*)(p + 4 * q) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K2: T5LayerNorm (HF modeling_t5.py:59-72): y = w * x * rsqrt(mean(x^2) + eps), fp32 statistics.
 // Optional dropout on y (final norms, P5_T5.py:179-180).  Saves rstd for the backward.
@@ -90,12 +104,13 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_fwd_kernel(T* __restrict__ y, 
   for (int i = 0; i < 4; ++i) {
     const int c = lane + i * 64;
     if (c < npc) {
-      float o[8];
+      float o[8], wv[8];
+      ldf<EPF>(w + c * EPF, wv);
 #pragma unroll
       for (int e = 0; e < EPF; ++e) {
         // reference order: (x * rstd) rounded to the activation dtype, then * weight
         const float n = to_f<T>(from_f<T>(xv[i][e] * rstd));
-        o[e] = w[c * EPF + e] * n;
+        o[e] = wv[e] * n;
         if (do_drop) o[e] = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c * EPF + e), drop.thr) ? o[e] * drop.scale : 0.f;
       }
       st16(y + (size_t)row * d + c * EPF, pack16<T>(o));
@@ -137,12 +152,14 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
       if (c < npc) {
         unpack16<T>(ld16(dy + (size_t)row * d + c * EPF), dyv[i]);
         unpack16<T>(ld16(x + (size_t)row * d + c * EPF), xh[i]);
+        float wv[8];
+        ldf<EPF>(w + c * EPF, wv);
 #pragma unroll
         for (int e = 0; e < EPF; ++e) {
           if (din) dyv[i][e] = p5_keep(seed_in, drop_in.site_key, (uint32_t)(row * d + c * EPF + e), drop_in.thr) ? dyv[i][e] * drop_in.scale : 0.f;
           xh[i][e] *= rstd;
           dwacc[i][e] += dyv[i][e] * xh[i][e];
-          dyv[i][e] *= w[c * EPF + e];
+          dyv[i][e] *= wv[e];
           dot += dyv[i][e] * xh[i][e];
         }
       }
@@ -152,15 +169,17 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
     for (int i = 0; i < 4; ++i) {
       const int c = lane + i * 64;
       if (c < npc) {
-        float o[8];
+        float o[8], rin[8], rout[8];
+        const size_t g0 = (size_t)row * d + c * EPF;
+        if (dres_in) ldf<EPF>(dres_in + g0, rin);
 #pragma unroll
         for (int e = 0; e < EPF; ++e) {
-          const size_t gi = (size_t)row * d + c * EPF + e;
           float v = rstd * (dyv[i][e] - xh[i][e] * dot);
-          if (dres_in) v += dres_in[gi];
-          dres_out[gi] = v;
-          o[e] = dnx ? (p5_keep(seed_nx, drop_next.site_key, (uint32_t)gi, drop_next.thr) ? v * drop_next.scale : 0.f) : v;
+          if (dres_in) v += rin[e];
+          rout[e] = v;
+          o[e] = dnx ? (p5_keep(seed_nx, drop_next.site_key, (uint32_t)(g0 + e), drop_next.thr) ? v * drop_next.scale : 0.f) : v;
         }
+        stf<EPF>(dres_out + g0, rout);
         if (dy_next) st16(dy_next + (size_t)row * d + c * EPF, pack16<T>(o));
       }
     }
@@ -190,12 +209,17 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
 // out(T) = dropmask(in fp32)  -- top of the encoder backward (grad of drop(final_norm(x)) arrives in fp32)
 template <class T>
 __global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, const float* __restrict__ in, size_t n, P5Drop drop) {
+  constexpr int EPF = TT<T>::EPF;      // n is a multiple of d_model, hence of EPF
   const bool dd = drop.state != nullptr && drop.thr != 0;
   const uint32_t seed = p5_seed(drop);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float v = in[i];
-    if (dd) v = p5_keep(seed, drop.site_key, (uint32_t)i, drop.thr) ? v * drop.scale : 0.f;
-    out[i] = from_f<T>(v);
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPF; i < n; i += (size_t)gridDim.x * 256 * EPF) {
+    float v[8];
+    ldf<EPF>(in + i, v);
+    if (dd) {
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) v[e] = p5_keep(seed, drop.site_key, (uint32_t)(i + e), drop.thr) ? v[e] * drop.scale : 0.f;
+    }
+    st16(out + i, pack16<T>(v));
   }
 }
 
@@ -228,7 +252,14 @@ __global__ __launch_bounds__(256) void p5_reduce_copies_kernel(float* __restrict
 // fp32 master -> compute-dtype shadow (bf16 fast mode)
 template <class T>
 __global__ __launch_bounds__(256) void p5_cast_kernel(T* __restrict__ out, const float* __restrict__ in, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = from_f<T>(in[i]);
+  constexpr int EPF = TT<T>::EPF;
+  const size_t nv = n / EPF * EPF;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPF; i < nv; i += (size_t)gridDim.x * 256 * EPF) {
+    float v[8];
+    ldf<EPF>(in + i, v);
+    st16(out + i, pack16<T>(v));
+  }
+  for (size_t i = nv + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = from_f<T>(in[i]);
 }
 
 // gated-gelu epilogue (T5 v1.1 / Flan: HF modeling_t5.py:97-123): h = gelu_new(u0) * u1, u = [u0 | u1] per row
@@ -324,15 +355,19 @@ template <class T>
 __global__ __launch_bounds__(256) void p5_ce_bwd_kernel(T* __restrict__ dlogits, const float* __restrict__ logits,
                                                        const float* __restrict__ lse, const int64_t* __restrict__ labels,
                                                        const float* __restrict__ dnll, int V, int ldl, int ldd) {
+  // grid (rows, column slices); one 16-byte store per lane (ldl, ldd are multiples of 64: the lm_head GEMM pads V)
+  constexpr int EPF = TT<T>::EPF;
   const int row = blockIdx.x;
   const float* lr = logits + (size_t)row * ldl;
   const int64_t lab = labels[row];
   const float g = (lab == -100) ? 0.f : dnll[row];
   const float l = lse[row];
-  for (int j = threadIdx.x; j < ldd; j += 256) {
-    float v = 0.f;
-    if (j < V) v = (expf(lr[j] - l) - (j == lab ? 1.f : 0.f)) * g;
-    dlogits[(size_t)row * ldd + j] = from_f<T>(v);
+  for (int j = (blockIdx.y * 256 + threadIdx.x) * EPF; j < ldd; j += gridDim.y * 256 * EPF) {
+    float v[8], o[8];
+    ldf<EPF>(lr + j, v);
+#pragma unroll
+    for (int e = 0; e < EPF; ++e) o[e] = (j + e < V) ? (expf(v[e] - l) - (j + e == lab ? 1.f : 0.f)) * g : 0.f;
+    st16(dlogits + (size_t)row * ldd + j, pack16<T>(o));
   }
 }
 

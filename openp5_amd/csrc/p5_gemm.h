@@ -360,3 +360,199 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------
+// v2 main loop for the bf16 K-contiguous x K-contiguous case (every forward Linear): same tile, same LDS image
+// (128-byte rows copied straight into LDS, XOR-swizzled), same epilogue as p5_gemm_kernel, but software-pipelined by
+// hand.  The compiler's schedule of the loop above reads a fragment group, waits lgkmcnt(0), issues 8 MFMAs, reads the
+// next group ... and ends every K-step with vmcnt(0) + barrier, so the matrix pipe idles during every LDS round trip and
+// a step lasts at least one global-load latency.  Here
+//   * fragments are double-buffered in registers: the 8 ds_read_b128 of the next 32-wide K-half are issued under the 16
+//     MFMAs of the current one (sched_group_barrier pins the 1 read : 2 MFMA interleave);
+//   * NST = 3: a three-deep LDS ring.  The copy of stage s+2 is issued at the top of step s, the single barrier sits in
+//     the MIDDLE of the step (after a counted vmcnt that only waits for stage s+1, which has had a whole step to land),
+//     and the second half prefetches the first fragments of stage s+1 -- no LDS or HBM latency is exposed in steady state;
+//   * NST = 2: two stages (two workgroups per CU instead of one); fragments of both K-halves are requested at the top.
+// ---------------------------------------------------------------------------------------------------------
+template <bool B> struct P5Bool { static constexpr bool value = B; };
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
+  using T = bf16;
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int ASZ = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int CST = BN * 2 + 16;
+  constexpr int LDS_BYTES = (NST * STAGE > BM * CST) ? NST * STAGE : BM * CST;
+  constexpr int NDMA = (BM + BN) / 32;                // direct-to-LDS wave instructions per wave per stage
+  constexpr int NFR = TM + TN, NMM = TM * TN;
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  static_assert(NMM >= NFR, "interleave pattern: one fragment read per MFMA");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef P5_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS destinations of the copies stay in SGPRs
+#endif
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  {
+    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.x + blockIdx.y * gx;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (lid / gx) * BM;
+    n0 = (lid % gx) * BN;
+  }
+  const int nst = g.K / 64;
+  const int per = (nst + g.splitk - 1) / g.splitk;
+  const int st_begin = blockIdx.z * per;
+  const int st_end = (st_begin + per < nst) ? st_begin + per : nst;
+  if (st_begin >= st_end) return;
+  const int n = st_end - st_begin;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source pointers of this wave's copies (row = 8 rows per wave instruction, 16-byte slot XOR-ed with row & 7 on
+  // the source side: a wave instruction's LDS image is linear); they advance by 128 bytes per stage
+  const T* srcA[BM / 32];
+  const T* srcB[BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) {
+    const int row = (wave * (BM / 32) + i) * 8 + (lane >> 3);
+    int gr = m0 + row;
+    gr = gr < g.M ? gr : g.M - 1;
+    srcA[i] = (const T*)g.A + (size_t)gr * g.lda + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    const int row = (wave * (BN / 32) + i) * 8 + (lane >> 3);
+    int gr = n0 + row;
+    gr = gr < g.N ? gr : g.N - 1;
+    srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+  }
+  auto copy_one = [&](int buf, int idx) {   // idx-th wave instruction of the copy of the next not-yet-copied stage
+    char* b = lds + buf * STAGE;
+    if (idx < BM / 32) {
+      glds16(srcA[idx], b + (wave * (BM / 32) + idx) * 1024);
+      srcA[idx] += 64;
+    } else {
+      const int i = idx - BM / 32;
+      glds16(srcB[i], b + ASZ + (wave * (BN / 32) + i) * 1024);
+      srcB[i] += 64;
+    }
+  };
+  auto copy_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) copy_one(buf, i);
+  };
+  // fragment idx of a K-half, in the order the MFMAs below first need them: A row-block 0, all B column-blocks, other A
+  auto load_one = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, int c, int idx) {
+    const char* b = lds + buf * STAGE;
+    if (idx == 0) fa[0] = frag_load_kc128<T>(b, wm * (BM / 2), c, lane);
+    else if (idx <= TN) fb[idx - 1] = frag_load_kc128<T>(b + ASZ, wn * (BN / 2) + (idx - 1) * 16, c, lane);
+    else fa[idx - TN] = frag_load_kc128<T>(b, wm * (BM / 2) + (idx - TN) * 16, c, lane);
+  };
+  auto load_frags = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, int c) {
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) load_one(fa, fb, buf, c, i);
+  };
+  u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+
+  if constexpr (NST == 3) {
+    // one K-step; COPY: the copy of stage s+2 goes out (ring slot nb2, last read before the barrier of step s-1);
+    // NEXT: stage s+1 exists -- its first fragments are prefetched behind the mid-step barrier.
+    // The instruction order below IS the schedule: a fence after every MFMA keeps hipcc from regrouping it.
+    auto step = [&](auto copy_c, auto next_c, int buf, int nb1, int nb2) {
+      constexpr bool COPY = decltype(copy_c)::value, NEXT = decltype(next_c)::value;
+      P5_SCHED_FENCE();
+#pragma unroll
+      for (int t = 0; t < NMM; ++t) {
+        mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
+        P5_SCHED_FENCE();
+        if (t < NFR) load_one(fa1, fb1, buf, 1, t);
+        if constexpr (COPY)
+          if (t < NDMA) copy_one(nb2, t);
+        P5_SCHED_FENCE();
+      }
+      if constexpr (NEXT) {
+        if constexpr (COPY) P5_WAIT_VM(NDMA); else P5_WAIT_VM(0);   // this wave's share of stage s+1 has landed
+        P5_BARRIER_LDS();                                           // ... everyone's; and slot `buf` is fully read
+        P5_SCHED_FENCE();
+      }
+#pragma unroll
+      for (int t = 0; t < NMM; ++t) {
+        mma16<T>(acc[t / TN][t % TN], fa1[t / TN], fb1[t % TN]);
+        P5_SCHED_FENCE();
+        if constexpr (NEXT)
+          if (t < NFR) load_one(fa0, fb0, nb1, 0, t);
+        P5_SCHED_FENCE();
+      }
+    };
+    copy_stage(0);
+    if (n > 1) {
+      copy_stage(1);
+      P5_WAIT_VM(NDMA);
+    } else {
+      P5_WAIT_VM(0);
+    }
+    P5_BARRIER_LDS();
+    load_frags(fa0, fb0, 0, 0);
+    int buf = 0, s = 0;
+    for (; s + 2 < n; ++s) {
+      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
+      step(P5Bool<true>(), P5Bool<true>(), buf, nb1, nb2);
+      buf = nb1;
+    }
+    if (s + 1 < n) {
+      const int nb1 = buf == 2 ? 0 : buf + 1;
+      step(P5Bool<false>(), P5Bool<true>(), buf, nb1, 0);
+      buf = nb1;
+    }
+    step(P5Bool<false>(), P5Bool<false>(), buf, 0, 0);
+  } else {
+    // two-slot ring: the copy of stage s+1 is issued at the top of step s and has the whole step to land; the barrier sits
+    // at the END of the step, so only the first fragment reads of the next stage are exposed (16 reads against 128 MFMAs
+    // for a 256x256 tile)
+    auto step = [&](auto copy_c, int buf) {
+      constexpr bool COPY = decltype(copy_c)::value;
+      P5_SCHED_FENCE();
+#pragma unroll
+      for (int t = 0; t < NMM; ++t) {
+        mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
+        P5_SCHED_FENCE();
+        if (t < NFR) load_one(fa1, fb1, buf, 1, t);
+        if constexpr (COPY)
+          if (t < NDMA) copy_one(buf ^ 1, t);
+        P5_SCHED_FENCE();
+      }
+#pragma unroll
+      for (int t = 0; t < NMM; ++t) {
+        mma16<T>(acc[t / TN][t % TN], fa1[t / TN], fb1[t % TN]);
+        P5_SCHED_FENCE();
+      }
+      if constexpr (COPY) {
+        P5_WAIT_VM(0);
+        P5_BARRIER_LDS();
+        P5_SCHED_FENCE();
+        load_frags(fa0, fb0, buf ^ 1, 0);
+        P5_SCHED_FENCE();
+      }
+    };
+    copy_stage(0);
+    P5_WAIT_VM(0);
+    P5_BARRIER_LDS();
+    load_frags(fa0, fb0, 0, 0);
+    int s = 0;
+    for (; s + 1 < n; ++s) step(P5Bool<true>(), s & 1);
+    step(P5Bool<false>(), s & 1);
+  }
+  P5_BARRIER_LDS();     // all fragment reads retired before the epilogue reuses the ring
+  gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
+}

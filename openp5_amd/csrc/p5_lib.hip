@@ -38,12 +38,26 @@ static int kcheck(const char* where) {
 // =====================================================================================================
 // launchers
 // =====================================================================================================
+// tuning knobs (p5_set_option / environment): gemm_v2 = LDS stages (2 or 3) of the hand-pipelined main loop, 0 = v1 loop
+static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0;
+static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
+
 template <class T, int BM, int BN>
 static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
   const int mode = g.a_ks * 2 + g.b_ks;
   // direct-to-LDS staging for K-contiguous operands whenever every K-step is full (fast-mode dtype only)
   const bool dma = sizeof(T) == 2 && (g.K % (TT<T>::KCH * 2)) == 0;
+  const int v2 = g_opt_gemm_v2;
+  if constexpr (sizeof(T) == 2 && BM == 256) {
+    P5_REQUIRE(mode == 0 && dma, "gemm: 256x256 tiles need bf16 K-contiguous operands with K % 64 == 0");
+    P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g);
+    return P5_KCHECK();
+  }
+  if constexpr (sizeof(T) == 2 && BM == 128) {
+    if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
+    if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
+  }
   if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
   else if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false>), grid, block, 0, s, g);
   else if (mode == 1 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, false>), grid, block, 0, s, g);
@@ -65,7 +79,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   if (g.b_ks) P5_REQUIRE(g.N % EPF == 0 || g.ldb >= ((g.N + EPF - 1) / EPF) * EPF, "gemm: B N-extent (KS)");
   if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm: accumulate epilogues need fp32 C");
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  static const int force_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;       // dev knobs
+  const int force_tile = g_opt_gemm_tile;
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   const bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
@@ -81,6 +95,8 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     }
   }
   if (g.splitk > 1) P5_REQUIRE(g.epi == P5_EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
+  if constexpr (sizeof(T) == 2)
+    if (force_tile == 256) return launch_gemm_tile<T, 256, 256>(g, s);
   return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
 }
 
@@ -633,7 +649,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     e->side_done_valid[0] = e->side_done_valid[1] = false;
 #endif
     begin_sublayer(e);
-    P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
+    P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
               e->labels, dnll, c.vocab_size, e->Vp, e->Vp);
     P5_TRY(P5_KCHECK());
     const float alpha = 1.0f / sqrtf((float)d);
@@ -644,7 +660,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
       P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dres_b, d, Md, d, c.vocab_size, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
       const size_t n = (size_t)Md * d;
-      P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
+      P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
                 (const float*)e->dres_b, n, no_drop());
       P5_TRY(P5_KCHECK());
     }
@@ -696,7 +712,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   if (stage == nd + 2) {
     join_side(e, s);      // d_enc is accumulated on the side stream
     const size_t n = (size_t)M * d;
-    P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
+    P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
               (const float*)e->d_enc, n, no_drop());
     P5_TRY(P5_KCHECK());
     e->dres_cur = e->dres_a;
@@ -909,6 +925,12 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
 extern "C" {
 
 const char* p5_last_error(void) { return g_err.c_str(); }
+int p5_set_option(const char* name, int value) {
+  if (!strcmp(name, "gemm_v2")) g_opt_gemm_v2 = value;
+  else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
+  else return fail("p5_set_option: unknown option");
+  return 0;
+}
 int p5_abi_version(void) { return 1; }
 int p5_is_emulator(void) {
 #ifdef P5_EMU
@@ -1086,9 +1108,16 @@ int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const floa
                     : rmsnorm_fwd<float>((hipStream_t)stream, y, rstd, x, w, rows, d, eps, no_drop());
 }
 int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w, const float* rstd,
-                      const float* dres_in, int rows, int d, void* stream) {
-  return dtype == 1 ? rmsnorm_bwd<bf16>((hipStream_t)stream, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop())
-                    : rmsnorm_bwd<float>((hipStream_t)stream, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop());
+                      const float* dres_in, int rows, int d, float* dw_partial, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int nblk = 0;
+  P5_TRY(dtype == 1 ? rmsnorm_bwd<bf16>(s, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop(), dw_partial, &nblk)
+                    : rmsnorm_bwd<float>(s, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop(), dw_partial, &nblk));
+  if (dw_partial) {    // the engine's mode: per-workgroup partials + a separate reduction
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64, nblk >= 64 ? 16 : 1), dim3(256), 0, s, dw, (const float*)dw_partial, nblk, d);
+    P5_TRY(P5_KCHECK());
+  }
+  return 0;
 }
 int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table, const int* lut,
                    int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int causal,

@@ -76,6 +76,17 @@ def gemm_case(be, dtype, M, N, K, a_ks, b_ks, epi=0, c_f32=0, splitk=1, seed=0):
     return err
 
 
+def gemm_v2_case(be, stages, M, N, K, epi):
+    lib = be.lib
+    try:
+        be.check(lib.p5_set_option(b"gemm_v2", stages), "set_option")
+        be.check(lib.p5_set_option(b"gemm_tile", 128), "set_option")
+        return gemm_case(be, 1, M, N, K, 0, 0, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if epi == 4 else 1)
+    finally:
+        lib.p5_set_option(b"gemm_v2", 0)
+        lib.p5_set_option(b"gemm_tile", 0)
+
+
 def rmsnorm_case(be, dtype, rows, d, seed=0):
     g = torch.Generator().manual_seed(seed)
     tt = TT[dtype]
@@ -91,20 +102,26 @@ def rmsnorm_case(be, dtype, rows, d, seed=0):
     rstd = torch.zeros(rows)
     xd, wd, yd, rd = dev(be, x), dev(be, w), dev(be, y), dev(be, rstd)
     be.check(be.lib.p5_op_rmsnorm_fwd(dtype, P(yd), P(rd), P(xd), P(wd), rows, d, 1e-6, be.stream_ptr()), "rmsnorm_fwd")
+    dyd, dresd = dev(be, dy), dev(be, dres)      # keep the device buffers alive across the launch
+    tol = 1e-5 if dtype == 0 else 3e-2
+    e_y = (yd.cpu().float() - yr.detach()).abs().max().item()
+    assert e_y <= tol * 4, f"rmsnorm fwd dtype={dtype} rows={rows} d={d}: y {e_y:.3e}"
+    for partial in (False, True):                # dw by atomics / by per-workgroup partials + reduction (the engine's mode)
+        _rmsnorm_bwd_check(be, dtype, rows, d, tt, xr, wr, dres, xd, wd, rd, dyd, dresd, partial, tol)
+
+
+def _rmsnorm_bwd_check(be, dtype, rows, d, tt, xr, wr, dres, xd, wd, rd, dyd, dresd, partial, tol):
     dres_out = dev(be, torch.zeros(rows, d))
     dy_next = dev(be, torch.zeros(rows, d, dtype=tt))
     dw = dev(be, torch.zeros(d))
-    dyd, dresd = dev(be, dy), dev(be, dres)      # keep the device buffers alive across the launch
+    scratch = dev(be, torch.zeros(1024 * d)) if partial else None
     be.check(be.lib.p5_op_rmsnorm_bwd(dtype, P(dres_out), P(dy_next), P(dw), P(dyd), P(xd), P(wd), P(rd), P(dresd), rows, d,
-                                      be.stream_ptr()), "rmsnorm_bwd")
+                                      P(scratch) if partial else None, be.stream_ptr()), "rmsnorm_bwd")
     sync(be)
-    tol = 1e-5 if dtype == 0 else 3e-2
-    e_y = (yd.cpu().float() - yr.detach()).abs().max().item()
     e_dx = (dres_out.cpu() - (xr.grad + dres)).abs().max().item()
     e_dw = (dw.cpu() - wr.grad).abs().max().item()
     e_nx = (dy_next.cpu().float() - dres_out.cpu()).abs().max().item()
-    msg = f"rmsnorm dtype={dtype} rows={rows} d={d}: y {e_y:.3e} dx {e_dx:.3e} dw {e_dw:.3e} next {e_nx:.3e}"
-    assert e_y <= tol * 4, msg
+    msg = f"rmsnorm dtype={dtype} rows={rows} d={d} partial={partial}: dx {e_dx:.3e} dw {e_dw:.3e} next {e_nx:.3e}"
     assert e_dx <= tol * 8, msg
     assert e_dw <= tol * 8 * max(1.0, rows ** 0.5), msg
     assert e_nx <= (1e-6 if dtype == 0 else 5e-2), msg

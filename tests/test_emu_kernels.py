@@ -19,6 +19,14 @@ def test_gemm(emu, dtype, shape):
     cases.gemm_case(emu, dtype, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if epi == 4 else 1)
 
 
+@pytest.mark.parametrize("stages", [2, 3])
+@pytest.mark.parametrize("shape", [(130, 200, 64, 0), (100, 72, 192, 2), (128, 128, 320, 1), (40, 136, 128, 4)])
+def test_gemm_pipelined_loop(emu, stages, shape):
+    """the hand-pipelined K loop (bf16, both operands K-contiguous, 128x128 tiles): 1..5 K-steps cover prologue, steady state and
+    both tail steps of the three-slot ring; epi 4 = split-K with atomics."""
+    cases.gemm_v2_case(emu, stages, *shape)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_rmsnorm(emu, dtype):
     cases.rmsnorm_case(emu, dtype, 37, 128)

@@ -31,3 +31,5 @@ run(512, 32100, 512, 0, 0, c_f32=1)
 run(4096, 4096, 4096, 0, 0)
 run(8192, 2048, 4096, 0, 0)
 run(512, 1536, 512, 0, 0); run(512, 512, 512, 0, 0); run(512, 2048, 512, 0, 0)
+run(Mt, 2048, 512, 0, 1, epi=3)      # dgrad through wo with the ReLU/dropout mask epilogue
+run(Mt, 512, 2048, 0, 1, epi=0)
