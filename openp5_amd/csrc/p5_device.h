@@ -152,6 +152,20 @@ __device__ static __forceinline__ void glds16(const void* g, char* lds_wave_base
 }
 #endif
 
+// "raw" direct-to-LDS copy: the same instruction issued through inline asm.  hipcc orders every LDS read behind ALL
+// direct-to-LDS copies it knows to be in flight (s_waitcnt vmcnt(0) before the read: it cannot prove that the read does
+// not alias a copy), which serialises a multi-stage ring.  A raw copy is invisible to that logic; the caller owns the
+// ordering: P5_WAIT_VM(n) + P5_BARRIER_LDS() before anybody reads the copied bytes.  (M0 is not otherwise used by the
+// kernels that issue raw copies.)
+#ifdef P5_EMU
+#define glds16_raw glds16
+#else
+__device__ static __forceinline__ void glds16_raw(const void* g, char* lds_wave_base) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)lds_wave_base));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory");
+}
+#endif
+
 // compiler scheduling fence: nothing is moved across it (used to keep an end-of-step barrier BELOW the MFMAs it follows
 // in program order -- hipcc otherwise hoists "s_waitcnt vmcnt(0); s_barrier" above them and serialises copy and math)
 #ifdef P5_EMU

@@ -41,6 +41,7 @@ struct P5GemmArgs {
   int epi;
   int c_f32;        // 1: C is fp32 regardless of T
   int splitk;       // >=1
+  int ring;         // launcher-internal: use the multi-stage ring kernel
   float alpha;
   P5Drop drop;
 };
@@ -132,6 +133,54 @@ __device__ static __forceinline__ u32x4 frag_load_kc128(const char* lds, int t0,
   return ld16(lds + row * 128 + ((((c << 2) | (lane >> 4)) ^ (row & 7)) << 4));
 }
 
+// K-STRIDED operand (element (r,k) at p[k*ld + r]: dgrad weights, both wgrad operands) straight from HBM into LDS.
+// LDS image of one K-step = [64 k-rows][R elements], rows back to back (a wave instruction writes 1 KiB linearly, so
+// there is no room for row padding).  ds_read_b64_tr_b16 serves 32 lanes per LDS cycle and those touch 8 different
+// k-rows at the same column range, i.e. the same banks; the 16-byte chunk index inside a row is therefore XOR-ed with
+// 2*s(row) -- s picks a different 32-byte bank slot for each of the 8 rows -- again on the SOURCE address.
+template <int R> __device__ static __forceinline__ int ksd_swz(int krow) {
+  if constexpr (R >= 128) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
+  else return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+}
+// Needs K % 64 == 0 and nrows % 8 == 0; chunks past the matrix edge are clamped (they feed C rows/cols never stored).
+template <class T, int R>
+__device__ static __forceinline__ void stage_dma_ks(char* lds, const T* __restrict__ p, int ld, int r0, int k0, int nrows, int tid) {
+  static_assert(sizeof(T) == 2, "direct-to-LDS staging is a bf16 path");
+  constexpr int RB = R * 2, CPR = RB / 16, RPI = 1024 / RB, NI = 64 / RPI / 4;   // NI wave instructions per wave (4 waves)
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = wave * NI + i;
+    const int krow = q * RPI + lane / CPR;
+    int cg = (lane % CPR) ^ ksd_swz<R>(krow);
+    const int cmax = (nrows - r0) / 8 - 1;
+    cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
+    glds16(p + (size_t)(k0 + krow) * ld + r0 + cg * 8, lds + q * 1024);
+  }
+}
+template <class T, int R>
+__device__ static __forceinline__ u32x4 frag_load_ksd(const char* lds, int t0, int c, int lane) {
+  constexpr int RB = R * 2;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = c * 32 + g * 8 + (i >> 2);                 // rows row and row + 4 share ksd_swz (bits 0,1,3 only)
+  const int cg = (t0 >> 3) + ((i & 3) >> 1);
+  const char* base = lds + row * RB + ((cg ^ ksd_swz<R>(row)) << 4) + ((i & 1) << 3);
+  const u32x2 lo = lds_tr16_b64(base);
+  const u32x2 hi = lds_tr16_b64(base + 4 * RB);
+  u32x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+// byte offset of this lane's transpose reads for fragment t0 inside a K-chunk of the image above (K-chunk c adds c*32 rows,
+// the second read 4 rows: both immediates) -- loop-invariant, so a software-pipelined loop keeps it in a register
+template <int R> __device__ static __forceinline__ int ksd_lane_off(int t0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int row = g * 8 + (i >> 2);
+  const int cg = (t0 >> 3) + ((i & 3) >> 1);
+  return row * (R * 2) + ((cg ^ ksd_swz<R>(row)) << 4) + ((i & 1) << 3);
+}
+
 // one 16-row fragment (rows t0..t0+15 of the tile) for this lane
 template <class T, int R, bool KS>
 __device__ static __forceinline__ u32x4 frag_load(const char* lds, int t0, int lane) {
@@ -178,13 +227,15 @@ __device__ static __forceinline__ float gemm_epi_apply(const P5GemmArgs& g, floa
   return v;
 }
 
-template <class T, int BM, int BN, int LDSB>
-__device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], char* lds, int m0, int n0, int tid) {
-  constexpr int TM = BM / 32, TN = BN / 32;
+template <class T, int BM, int BN, int LDSB, int NT = 256, int WNW = 2>
+__device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 (&acc)[BM / (16 * (NT / 64 / WNW))][BN / (16 * WNW)], char* lds,
+                                                     int m0, int n0, int tid) {
+  constexpr int WMW = NT / 64 / WNW;                  // waves along M x waves along N; wave tile = (BM/WMW) x (BN/WNW)
+  constexpr int TM = BM / (16 * WMW), TN = BN / (16 * WNW);
   constexpr int CST = BN * 2 + 16;                    // LDS row stride of the staged bf16 C tile
   static_assert(LDSB >= BM * CST, "LDS buffer too small for the staged C tile");
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   const uint32_t seed = p5_seed(g.drop);
   const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
 
@@ -199,16 +250,16 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int lr = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-            const int lc = wn * (BN / 2) + j * 16 + (lane & 15);
+            const int lr = wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
+            const int lc = wn * (BN / WNW) + j * 16 + (lane & 15);
             *(bf16*)(lds + lr * CST + lc * 2) = f2bf(acc[i][j][r] * g.alpha);
           }
       __syncthreads();
       constexpr int PPR = BN / 8;                 // 16-byte pieces per tile row
-      constexpr int NPIECE = BM * PPR / 256;
+      constexpr int NPIECE = BM * PPR / NT;
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i) {
-        const int p = tid + i * 256;
+        const int p = tid + i * NT;
         const int lr = p / PPR, pc = p % PPR;
         const int row = m0 + lr, col = n0 + pc * 8;
         if (row >= g.M || col >= g.N) continue;
@@ -231,10 +282,10 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+      const int col = n0 + wn * (BN / WNW) + j * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+        const int row = m0 + wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
         if (row >= g.M || col >= g.N) continue;
         const size_t ci = (size_t)row * g.ldc + col;
         float auxv = 0.f;
@@ -258,7 +309,9 @@ template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool 
 __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int KCH = TT<T>::KCH;
-  constexpr int ACH = LdsChunk<T, BM, AKS>::BYTES, BCH = LdsChunk<T, BN, BKS>::BYTES;
+  // bytes of one 32-deep K-chunk of an operand tile in LDS (direct-to-LDS images are unpadded)
+  constexpr int ACH = (ADMA && AKS) ? 32 * BM * 2 : LdsChunk<T, BM, AKS>::BYTES;
+  constexpr int BCH = (BDMA && BKS) ? 32 * BN * 2 : LdsChunk<T, BN, BKS>::BYTES;
   constexpr int STAGE = NCK * (ACH + BCH);
   constexpr int NA = AKS ? (KCH * (BM / TT<T>::EPF) / 256) : (BM * 4 / 256);
   constexpr int NB = BKS ? (KCH * (BN / TT<T>::EPF) / 256) : (BN * 4 / 256);
@@ -296,8 +349,7 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  static_assert(!(ADMA && AKS) && !(BDMA && BKS), "direct-to-LDS staging is for K-contiguous operands");
-  static_assert(!(ADMA || BDMA) || NCK == 2, "direct-to-LDS staging copies 128-byte rows = two K-chunks per step");
+  static_assert(!(ADMA || BDMA) || NCK == 2, "direct-to-LDS staging copies whole K-steps = two K-chunks");
   u32x4 ra[NCK][ADMA ? 1 : NA], rb[NCK][BDMA ? 1 : NB];
 #pragma unroll
   for (int c = 0; c < NCK; ++c) {
@@ -305,8 +357,10 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
     if constexpr (!ADMA) stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
     if constexpr (!BDMA) stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
   }
-  if constexpr (ADMA) stage_dma128<T, BM>(lds, A, g.lda, m0, st_begin * NCK * KCH, g.M, tid);
-  if constexpr (BDMA) stage_dma128<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
+  if constexpr (ADMA && !AKS) stage_dma128<T, BM>(lds, A, g.lda, m0, st_begin * NCK * KCH, g.M, tid);
+  if constexpr (ADMA && AKS) stage_dma_ks<T, BM>(lds, A, g.lda, m0, st_begin * NCK * KCH, g.M, tid);
+  if constexpr (BDMA && !BKS) stage_dma128<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
+  if constexpr (BDMA && BKS) stage_dma_ks<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
 #pragma unroll
   for (int c = 0; c < NCK; ++c) {
     if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * ACH, tid);
@@ -326,8 +380,10 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
         if constexpr (!ADMA) stage_load<T, BM, AKS>(ra[c], A, g.lda, m0, k0, g.M, g.K, tid);
         if constexpr (!BDMA) stage_load<T, BN, BKS>(rb[c], Bp, g.ldb, n0, k0, g.N, g.K, tid);
       }
-      if constexpr (ADMA) stage_dma128<T, BM>(nb, A, g.lda, m0, (st + 1) * NCK * KCH, g.M, tid);
-      if constexpr (BDMA) stage_dma128<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
+      if constexpr (ADMA && !AKS) stage_dma128<T, BM>(nb, A, g.lda, m0, (st + 1) * NCK * KCH, g.M, tid);
+      if constexpr (ADMA && AKS) stage_dma_ks<T, BM>(nb, A, g.lda, m0, (st + 1) * NCK * KCH, g.M, tid);
+      if constexpr (BDMA && !BKS) stage_dma128<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
+      if constexpr (BDMA && BKS) stage_dma_ks<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
     }
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
@@ -336,10 +392,14 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
       u32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[i] = ADMA ? frag_load_kc128<T>(base, wm * (BM / 2) + i * 16, c, lane) : frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
+        fa[i] = (ADMA && AKS)   ? frag_load_ksd<T, BM>(base, wm * (BM / 2) + i * 16, c, lane)
+                : ADMA          ? frag_load_kc128<T>(base, wm * (BM / 2) + i * 16, c, lane)
+                                : frag_load<T, BM, AKS>(la, wm * (BM / 2) + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[j] = BDMA ? frag_load_kc128<T>(base + NCK * ACH, wn * (BN / 2) + j * 16, c, lane) : frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
+        fb[j] = (BDMA && BKS)   ? frag_load_ksd<T, BN>(base + NCK * ACH, wn * (BN / 2) + j * 16, c, lane)
+                : BDMA          ? frag_load_kc128<T>(base + NCK * ACH, wn * (BN / 2) + j * 16, c, lane)
+                                : frag_load<T, BN, BKS>(lb, wn * (BN / 2) + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -377,8 +437,14 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool B> struct P5Bool { static constexpr bool value = B; };
 
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
+#ifdef P5_EMU
+#define P5_WAVES_PER_SIMD(lo, hi)
+#else
+#define P5_WAVES_PER_SIMD(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+// (three and more stages fill the LDS of a CU with one workgroup = one wave per SIMD: let it have the whole register file)
+template <int BM, int BN, int NST, bool AKS = false, bool BKS = false>
+__global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5_gemm2_kernel(P5GemmArgs g) {
   using T = bf16;
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int ASZ = BM * 128, STAGE = (BM + BN) * 128;
@@ -386,7 +452,8 @@ __global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
   constexpr int LDS_BYTES = (NST * STAGE > BM * CST) ? NST * STAGE : BM * CST;
   constexpr int NDMA = (BM + BN) / 32;                // direct-to-LDS wave instructions per wave per stage
   constexpr int NFR = TM + TN, NMM = TM * TN;
-  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  static_assert(NST >= 2 && NST <= 4, "two to four LDS stages");
+  constexpr int PFD = NST - 1;                        // stages in flight ahead of the one being multiplied
   static_assert(NMM >= NFR, "interleave pattern: one fragment read per MFMA");
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -421,31 +488,51 @@ __global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
 
   // per-lane source pointers of this wave's copies (row = 8 rows per wave instruction, 16-byte slot XOR-ed with row & 7 on
   // the source side: a wave instruction's LDS image is linear); they advance by 128 bytes per stage
+  // K-strided operands: [64 k-rows][R] image with the chunk swizzle of stage_dma_ks; they advance by 64 rows per stage
   const T* srcA[BM / 32];
   const T* srcB[BN / 32];
+  size_t incA = AKS ? (size_t)64 * g.lda : 64, incB = BKS ? (size_t)64 * g.ldb : 64;
 #pragma unroll
   for (int i = 0; i < BM / 32; ++i) {
-    const int row = (wave * (BM / 32) + i) * 8 + (lane >> 3);
-    int gr = m0 + row;
-    gr = gr < g.M ? gr : g.M - 1;
-    srcA[i] = (const T*)g.A + (size_t)gr * g.lda + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+    if constexpr (AKS) {
+      constexpr int CPR = BM / 8, RPI = 512 / BM;
+      const int krow = (wave * (BM / 32) + i) * RPI + lane / CPR;
+      int cg = (lane % CPR) ^ ksd_swz<BM>(krow);
+      const int cmax = (g.M - m0) / 8 - 1;
+      cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
+      srcA[i] = (const T*)g.A + ((size_t)st_begin * 64 + krow) * g.lda + m0 + cg * 8;
+    } else {
+      const int row = (wave * (BM / 32) + i) * 8 + (lane >> 3);
+      int gr = m0 + row;
+      gr = gr < g.M ? gr : g.M - 1;
+      srcA[i] = (const T*)g.A + (size_t)gr * g.lda + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+    }
   }
 #pragma unroll
   for (int i = 0; i < BN / 32; ++i) {
-    const int row = (wave * (BN / 32) + i) * 8 + (lane >> 3);
-    int gr = n0 + row;
-    gr = gr < g.N ? gr : g.N - 1;
-    srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+    if constexpr (BKS) {
+      constexpr int CPR = BN / 8, RPI = 512 / BN;
+      const int krow = (wave * (BN / 32) + i) * RPI + lane / CPR;
+      int cg = (lane % CPR) ^ ksd_swz<BN>(krow);
+      const int cmax = (g.N - n0) / 8 - 1;
+      cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
+      srcB[i] = (const T*)g.B + ((size_t)st_begin * 64 + krow) * g.ldb + n0 + cg * 8;
+    } else {
+      const int row = (wave * (BN / 32) + i) * 8 + (lane >> 3);
+      int gr = n0 + row;
+      gr = gr < g.N ? gr : g.N - 1;
+      srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+    }
   }
   auto copy_one = [&](int buf, int idx) {   // idx-th wave instruction of the copy of the next not-yet-copied stage
     char* b = lds + buf * STAGE;
     if (idx < BM / 32) {
-      glds16(srcA[idx], b + (wave * (BM / 32) + idx) * 1024);
-      srcA[idx] += 64;
+      glds16_raw(srcA[idx], b + (wave * (BM / 32) + idx) * 1024);
+      srcA[idx] += incA;
     } else {
       const int i = idx - BM / 32;
-      glds16(srcB[i], b + ASZ + (wave * (BN / 32) + i) * 1024);
-      srcB[i] += 64;
+      glds16_raw(srcB[i], b + ASZ + (wave * (BN / 32) + i) * 1024);
+      srcB[i] += incB;
     }
   };
   auto copy_stage = [&](int buf) {
@@ -453,69 +540,90 @@ __global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
     for (int i = 0; i < NDMA; ++i) copy_one(buf, i);
   };
   // fragment idx of a K-half, in the order the MFMAs below first need them: A row-block 0, all B column-blocks, other A
-  auto load_one = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, int c, int idx) {
-    const char* b = lds + buf * STAGE;
-    if (idx == 0) fa[0] = frag_load_kc128<T>(b, wm * (BM / 2), c, lane);
-    else if (idx <= TN) fb[idx - 1] = frag_load_kc128<T>(b + ASZ, wn * (BN / 2) + (idx - 1) * 16, c, lane);
-    else fa[idx - TN] = frag_load_kc128<T>(b, wm * (BM / 2) + (idx - TN) * 16, c, lane);
-  };
-  auto load_frags = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, int c) {
+  // K-strided operands: lane offsets of the transpose reads, fixed for the whole kernel
+  int koffA[AKS ? TM : 1], koffB[BKS ? TN : 1];
+  if constexpr (AKS) {
 #pragma unroll
-    for (int i = 0; i < NFR; ++i) load_one(fa, fb, buf, c, i);
+    for (int i = 0; i < TM; ++i) koffA[i] = ksd_lane_off<BM>(wm * (BM / 2) + i * 16, lane);
+  }
+  if constexpr (BKS) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) koffB[j] = ksd_lane_off<BN>(wn * (BN / 2) + j * 16, lane) + ASZ;
+  }
+  auto tr_frag = [](const char* p, int hi_off) {
+    const u32x2 lo = lds_tr16_b64(p), hi = lds_tr16_b64(p + hi_off);
+    u32x4 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    return r;
+  };
+  auto load_one = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, auto c_c, int idx) {
+    constexpr int c = decltype(c_c)::value ? 1 : 0;
+    const char* b = lds + buf * STAGE;
+    auto fra = [&](int i) {
+      if constexpr (AKS) return tr_frag(b + koffA[i] + c * 32 * BM * 2, 4 * BM * 2);
+      else return frag_load_kc128<T>(b, wm * (BM / 2) + i * 16, c, lane);
+    };
+    auto frb = [&](int j) {
+      if constexpr (BKS) return tr_frag(b + koffB[j] + c * 32 * BN * 2, 4 * BN * 2);
+      else return frag_load_kc128<T>(b + ASZ, wn * (BN / 2) + j * 16, c, lane);
+    };
+    if (idx == 0) fa[0] = fra(0);
+    else if (idx <= TN) fb[idx - 1] = frb(idx - 1);
+    else fa[idx - TN] = fra(idx - TN);
+  };
+  auto load_frags = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], int buf, auto c_c) {
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) load_one(fa, fb, buf, c_c, i);
   };
   u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 
-  if constexpr (NST == 3) {
-    // one K-step; COPY: the copy of stage s+2 goes out (ring slot nb2, last read before the barrier of step s-1);
-    // NEXT: stage s+1 exists -- its first fragments are prefetched behind the mid-step barrier.
+  if constexpr (NST >= 3) {
+    // ONE loop body for every K-step (peeled prologue / tail variants make hipcc shuffle the 64 accumulators through
+    // ~100 register copies per step): every step issues a stage copy and prefetches "the next stage's" first fragments.
+    // Past the end of the K range the copy re-fetches the last stage into a free ring slot (`inc` drops to 0) and the
+    // prefetched fragments are never multiplied -- a few hundred wasted bytes per workgroup for a loop without branches,
+    // with a constant vmcnt: at the mid-step barrier exactly PFD-1 younger stage copies may still be in flight.
     // The instruction order below IS the schedule: a fence after every MFMA keeps hipcc from regrouping it.
-    auto step = [&](auto copy_c, auto next_c, int buf, int nb1, int nb2) {
-      constexpr bool COPY = decltype(copy_c)::value, NEXT = decltype(next_c)::value;
+    auto step = [&](int buf, int nb1, int nb2) {
       P5_SCHED_FENCE();
 #pragma unroll
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
         P5_SCHED_FENCE();
-        if (t < NFR) load_one(fa1, fb1, buf, 1, t);
-        if constexpr (COPY)
-          if (t < NDMA) copy_one(nb2, t);
+        if (t < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), t);
+        if (t < NDMA) copy_one(nb2, t);     // stage s+PFD -> ring slot of stage s-1 (read out before that step's barrier)
         P5_SCHED_FENCE();
       }
-      if constexpr (NEXT) {
-        if constexpr (COPY) P5_WAIT_VM(NDMA); else P5_WAIT_VM(0);   // this wave's share of stage s+1 has landed
-        P5_BARRIER_LDS();                                           // ... everyone's; and slot `buf` is fully read
-        P5_SCHED_FENCE();
-      }
+      P5_WAIT_VM((PFD - 1) * NDMA);         // this wave's share of stage s+1 has landed
+      P5_BARRIER_LDS();                     // ... everyone's; and slot `buf` is fully read
+      P5_SCHED_FENCE();
 #pragma unroll
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa1[t / TN], fb1[t % TN]);
         P5_SCHED_FENCE();
-        if constexpr (NEXT)
-          if (t < NFR) load_one(fa0, fb0, nb1, 0, t);
+        if (t < NFR) load_one(fa0, fb0, nb1, P5Bool<false>(), t);
         P5_SCHED_FENCE();
       }
     };
-    copy_stage(0);
-    if (n > 1) {
-      copy_stage(1);
-      P5_WAIT_VM(NDMA);
-    } else {
-      P5_WAIT_VM(0);
+    // a copy post-increments its source pointers: the increment must already be 0 when the LAST stage is copied
+    auto before_copy_of = [&](int stage) {
+      if (stage >= n - 1) { incA = 0; incB = 0; }
+    };
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) {
+      before_copy_of(q);
+      copy_stage(q);
     }
+    P5_WAIT_VM((PFD - 1) * NDMA);
     P5_BARRIER_LDS();
-    load_frags(fa0, fb0, 0, 0);
+    load_frags(fa0, fb0, 0, P5Bool<false>());
     int buf = 0, s = 0;
-    for (; s + 2 < n; ++s) {
-      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
-      step(P5Bool<true>(), P5Bool<true>(), buf, nb1, nb2);
+    do {    // n >= 1; (a for loop's zero-trip guard makes hipcc read all 64 accumulators back to VGPRs in every iteration)
+      const int nb1 = buf == NST - 1 ? 0 : buf + 1, nb2 = buf == 0 ? NST - 1 : buf - 1;
+      before_copy_of(s + PFD);
+      step(buf, nb1, nb2);
       buf = nb1;
-    }
-    if (s + 1 < n) {
-      const int nb1 = buf == 2 ? 0 : buf + 1;
-      step(P5Bool<false>(), P5Bool<true>(), buf, nb1, 0);
-      buf = nb1;
-    }
-    step(P5Bool<false>(), P5Bool<false>(), buf, 0, 0);
+    } while (++s < n);
   } else {
     // two-slot ring: the copy of stage s+1 is issued at the top of step s and has the whole step to land; the barrier sits
     // at the END of the step, so only the first fragment reads of the next stage are exposed (16 reads against 128 MFMAs
@@ -527,7 +635,7 @@ __global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
         P5_SCHED_FENCE();
-        if (t < NFR) load_one(fa1, fb1, buf, 1, t);
+        if (t < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), t);
         if constexpr (COPY)
           if (t < NDMA) copy_one(buf ^ 1, t);
         P5_SCHED_FENCE();
@@ -541,18 +649,148 @@ __global__ __launch_bounds__(256) void p5_gemm2_kernel(P5GemmArgs g) {
         P5_WAIT_VM(0);
         P5_BARRIER_LDS();
         P5_SCHED_FENCE();
-        load_frags(fa0, fb0, buf ^ 1, 0);
+        load_frags(fa0, fb0, buf ^ 1, P5Bool<false>());
         P5_SCHED_FENCE();
       }
     };
     copy_stage(0);
     P5_WAIT_VM(0);
     P5_BARRIER_LDS();
-    load_frags(fa0, fb0, 0, 0);
+    load_frags(fa0, fb0, 0, P5Bool<false>());
     int s = 0;
     for (; s + 1 < n; ++s) step(P5Bool<true>(), s & 1);
     step(P5Bool<false>(), s & 1);
   }
   P5_BARRIER_LDS();     // all fragment reads retired before the epilogue reuses the ring
   gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// 256x256 tiles, eight waves: the 128x128 kernels copy (BM+BN)/(BM*BN) = 1/64 byte from L2 into LDS per MAC and stall at
+// ~0.9 PFLOP/s on that copy rate whatever the loop looks like; a 256x256 tile halves it.  One
+// workgroup of 512 threads per CU (2 waves per SIMD, <= 256 registers each): waves as WMW x WNW, wave tile
+// (BM/WMW) x (BN/WNW) = 128 x 64 -> 128 accumulator registers.  Fragments cannot be double-buffered per K-half at this
+// size, so A fragments run through a 4-deep register ring three MFMA groups ahead of their use and the B fragments of
+// the other K-half are fetched during the first groups of the current one.  Two-slot LDS ring (2 x 64 KiB): the copy of
+// stage s+1 is issued during step s, "vmcnt(0) + barrier" closes the step, then 7 fragment reads restart the pipeline.
+// bf16, both operands K-contiguous, K % 64 == 0; bf16 C through the LDS-staged epilogue (135 KiB) or fp32/atomic direct.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WMW, int WNW>
+__global__ __launch_bounds__(WMW* WNW * 64) void p5_gemm3_kernel(P5GemmArgs g) {
+  using T = bf16;
+  constexpr int NW = WMW * WNW, NT = NW * 64;
+  constexpr int TM = BM / (16 * WMW), TN = BN / (16 * WNW);
+  constexpr int ASZ = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int CST = BN * 2 + 16;
+  constexpr int LDS_BYTES = (2 * STAGE > BM * CST) ? 2 * STAGE : BM * CST;
+  constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW), NDMA = NA + NB;   // direct-to-LDS wave instructions per wave per stage
+  constexpr int RA = 4, PF = 3;                                           // A-fragment ring / prefetch distance (MFMA groups)
+  constexpr int NG = 2 * TM;                                              // MFMA groups per K-step: (K-half, A row-block)
+  static_assert(TN <= TM && NDMA <= NG && PF < RA && PF <= TM, "static schedule below");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef P5_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave / WNW, wn = wave % WNW;
+  int m0, n0;
+  {
+    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.x + blockIdx.y * gx;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    m0 = (lid / gx) * BM;
+    n0 = (lid % gx) * BN;
+  }
+  const int nst = g.K / 64;
+  const int per = (nst + g.splitk - 1) / g.splitk;
+  const int st_begin = blockIdx.z * per;
+  const int st_end = (st_begin + per < nst) ? st_begin + per : nst;
+  if (st_begin >= st_end) return;
+  const int n = st_end - st_begin;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* srcA[NA];
+  const T* srcB[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave * NA + i) * 8 + (lane >> 3);
+    int gr = m0 + row;
+    gr = gr < g.M ? gr : g.M - 1;
+    srcA[i] = (const T*)g.A + (size_t)gr * g.lda + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave * NB + i) * 8 + (lane >> 3);
+    int gr = n0 + row;
+    gr = gr < g.N ? gr : g.N - 1;
+    srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + (size_t)st_begin * 64 + (((lane & 7) ^ (row & 7)) * 8);
+  }
+  auto copy_one = [&](int buf, int idx) {
+    char* b = lds + buf * STAGE;
+    if (idx < NA) {
+      glds16(srcA[idx], b + (wave * NA + idx) * 1024);
+      srcA[idx] += 64;
+    } else {
+      const int i = idx - NA;
+      glds16(srcB[i], b + ASZ + (wave * NB + i) * 1024);
+      srcB[i] += 64;
+    }
+  };
+  u32x4 ar[RA], bc[2][TN];
+  auto load_a = [&](int buf, int gi) {        // A fragment of MFMA group gi (K-half gi / TM, row-block gi % TM) into its ring slot
+    ar[gi % RA] = frag_load_kc128<T>(lds + buf * STAGE, wm * (BM / WMW) + (gi % TM) * 16, gi / TM, lane);
+  };
+  auto load_b = [&](int buf, int c, int j) {
+    bc[c][j] = frag_load_kc128<T>(lds + buf * STAGE + ASZ, wn * (BN / WNW) + j * 16, c, lane);
+  };
+  auto restart = [&](int buf) {               // the reads that must precede the first MFMA of a stage
+#pragma unroll
+    for (int j = 0; j < TN; ++j) load_b(buf, 0, j);
+#pragma unroll
+    for (int gi = 0; gi < PF; ++gi) load_a(buf, gi);
+  };
+  auto step = [&](auto copy_c, int buf) {
+    constexpr bool COPY = decltype(copy_c)::value;
+    P5_SCHED_FENCE();
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        mma16<T>(acc[gi % TM][j], ar[gi % RA], bc[gi / TM][j]);
+        P5_SCHED_FENCE();
+        if (j == 0 && gi + PF < NG) load_a(buf, gi + PF);
+        if (j == 1 && gi < TN) load_b(buf, 1, gi);
+        if constexpr (COPY)
+          if (j == 2 % TN && gi < NDMA) copy_one(buf ^ 1, gi);
+        P5_SCHED_FENCE();
+      }
+    }
+    if constexpr (COPY) {
+      P5_WAIT_VM(0);
+      P5_BARRIER_LDS();
+      P5_SCHED_FENCE();
+      restart(buf ^ 1);
+      P5_SCHED_FENCE();
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) copy_one(0, i);
+  P5_WAIT_VM(0);
+  P5_BARRIER_LDS();
+  restart(0);
+  int s = 0;
+  for (; s + 1 < n; ++s) step(P5Bool<true>(), s & 1);
+  step(P5Bool<false>(), s & 1);
+  P5_BARRIER_LDS();     // all fragment reads retired before the epilogue reuses the ring
+  gemm_epilogue<T, BM, BN, LDS_BYTES, NT, WNW>(g, acc, lds, m0, n0, tid);
 }

@@ -41,6 +41,8 @@ static int kcheck(const char* where) {
 // tuning knobs (p5_set_option / environment): gemm_v2 = LDS stages (2 or 3) of the hand-pipelined main loop, 0 = v1 loop
 static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0;
 static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
+static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
+static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 
 template <class T, int BM, int BN>
 static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
@@ -51,15 +53,22 @@ static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
   const int v2 = g_opt_gemm_v2;
   if constexpr (sizeof(T) == 2 && BM == 256) {
     P5_REQUIRE(mode == 0 && dma, "gemm: 256x256 tiles need bf16 K-contiguous operands with K % 64 == 0");
-    P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g);
+    P5_LAUNCH((p5_gemm3_kernel<BM, BN, 2, 4>), grid, dim3(512), 0, s, g);
     return P5_KCHECK();
   }
   if constexpr (sizeof(T) == 2 && BM == 128) {
     if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
+    if (mode == 3 && dma && (g.N % 8) == 0 && (g.M % 8) == 0 && (v2 >= 3 || g.ring)) {
+      if (v2 == 3) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
+      else P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4, true, true>), grid, block, 0, s, g);
+      return P5_KCHECK();
+    }
   }
   if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
   else if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false>), grid, block, 0, s, g);
+  else if (mode == 1 && dma && (g.N % 8) == 0 && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
+  else if (mode == 3 && dma && (g.N % 8) == 0 && (g.M % 8) == 0 && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
   else if (mode == 1 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, false>), grid, block, 0, s, g);
   else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, false, false>), grid, block, 0, s, g);
   else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, false, false>), grid, block, 0, s, g);
@@ -82,7 +91,18 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   const int force_tile = g_opt_gemm_tile;
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
-  const bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
+  bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
+  // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
+  // split-K so that tiles x splits ~ 256 (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
+  // below 48 tiles the 64x64 kernel still wins)
+  if (sizeof(T) == 2 && !force_tile && g_opt_gemm_ring && g.a_ks && g.b_ks && g.epi == P5_EPI_ATOMIC && g.splitk <= 0 && t128 >= 48 &&
+      t128 <= 256 && g.K >= 2048 && (g.K % 64) == 0 && (g.M % 8) == 0 && (g.N % 8) == 0) {
+    g.ring = 1;
+    big = true;
+    int sk = (int)((256 + t128 / 2) / t128);
+    const int maxs = g.K / 64 / 8;
+    g.splitk = sk < 1 ? 1 : (sk > maxs ? maxs : sk);
+  }
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   if (g.splitk <= 0) {
     g.splitk = 1;
@@ -340,7 +360,7 @@ static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, 
                 int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop) {
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
-  g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.alpha = alpha; g.drop = drop;
+  g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
   return launch_gemm<T>(g, s);
 }
 // y = x W^T
@@ -928,6 +948,8 @@ const char* p5_last_error(void) { return g_err.c_str(); }
 int p5_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_v2")) g_opt_gemm_v2 = value;
   else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
+  else if (!strcmp(name, "gemm_ksdma")) g_opt_gemm_ksdma = value;
+  else if (!strcmp(name, "gemm_ring")) g_opt_gemm_ring = value;
   else return fail("p5_set_option: unknown option");
   return 0;
 }
@@ -1100,7 +1122,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
                void* stream) {
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
-  g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
+  g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
 }
 int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream) {

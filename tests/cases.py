@@ -76,12 +76,12 @@ def gemm_case(be, dtype, M, N, K, a_ks, b_ks, epi=0, c_f32=0, splitk=1, seed=0):
     return err
 
 
-def gemm_v2_case(be, stages, M, N, K, epi):
+def gemm_v2_case(be, stages, M, N, K, epi, tile=128, ks=0):
     lib = be.lib
     try:
         be.check(lib.p5_set_option(b"gemm_v2", stages), "set_option")
-        be.check(lib.p5_set_option(b"gemm_tile", 128), "set_option")
-        return gemm_case(be, 1, M, N, K, 0, 0, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if epi == 4 else 1)
+        be.check(lib.p5_set_option(b"gemm_tile", tile), "set_option")
+        return gemm_case(be, 1, M, N, K, ks, ks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if epi == 4 else 1)
     finally:
         lib.p5_set_option(b"gemm_v2", 0)
         lib.p5_set_option(b"gemm_tile", 0)

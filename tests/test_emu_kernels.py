@@ -27,6 +27,35 @@ def test_gemm_pipelined_loop(emu, stages, shape):
     cases.gemm_v2_case(emu, stages, *shape)
 
 
+@pytest.mark.parametrize("stages", [3, 4])
+@pytest.mark.parametrize("shape", [(136, 200, 64), (136, 72, 192), (128, 128, 384), (40, 264, 640), (8, 8, 128)])
+def test_gemm_pipelined_loop_wgrad(emu, stages, shape):
+    """the hand-pipelined loop on two K-strided operands (weight gradients): split-K 2 over 1..10 K-steps exercises every
+    prologue / steady-state / tail combination of the 3- and 4-slot rings."""
+    cases.gemm_v2_case(emu, stages, *shape, 4, ks=1)
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(72, 56, 128, 1, 1, 4), (200, 136, 192, 1, 1, 4), (130, 72, 64, 0, 1, 0), (96, 264, 256, 0, 1, 3),
+                                   (64, 8, 64, 1, 1, 4), (8, 200, 64, 1, 1, 4)])
+def test_gemm_strided_operands_direct_to_lds(emu, tile, shape):
+    """dgrad (B K-strided) and wgrad (both K-strided) with the swizzled direct-to-LDS image + transpose reads; ragged and
+    tiny M/N (chunk clamping), 1..4 K-steps, both tile sizes."""
+    M, N, K, aks, bks, epi = shape
+    lib = emu.lib
+    try:
+        emu.check(lib.p5_set_option(b"gemm_tile", tile), "set_option")
+        cases.gemm_case(emu, 1, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if (epi == 4 and K >= 128) else 1)
+    finally:
+        lib.p5_set_option(b"gemm_tile", 0)
+
+
+@pytest.mark.parametrize("shape", [(300, 264, 64, 0), (256, 512, 192, 2), (130, 256, 128, 1), (256, 256, 256, 4)])
+def test_gemm_256_tile(emu, shape):
+    """256x256 tile, eight waves, A-fragment register ring: 1..4 K-steps, ragged M/N edges, every bf16 epilogue."""
+    cases.gemm_v2_case(emu, 0, *shape, tile=256)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_rmsnorm(emu, dtype):
     cases.rmsnorm_case(emu, dtype, 37, 128)

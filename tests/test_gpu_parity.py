@@ -27,6 +27,28 @@ def test_gemm(hip, dtype, shape):
     cases.gemm_case(hip, dtype, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=0 if epi == 4 else 1)
 
 
+def test_gemm_ring_and_big_tile_kernels(hip):
+    """the hand-scheduled kernels on the hardware: 3-/4-slot rings (K-contiguous and K-strided operands, split-K),
+    256x256 tiles, swizzled direct-to-LDS images of K-strided operands under both tile sizes."""
+    for stages in (2, 3, 4):
+        cases.gemm_v2_case(hip, stages, 1024, 640, 512, 2)
+        cases.gemm_v2_case(hip, stages, 200, 136, 64, 1)
+    for stages in (3, 4):
+        cases.gemm_v2_case(hip, stages, 520, 264, 4096, 4, ks=1)
+        cases.gemm_v2_case(hip, stages, 136, 72, 192, 4, ks=1)
+    for shape in [(1024, 768, 512, 2), (300, 264, 64, 0), (512, 512, 2048, 1)]:
+        cases.gemm_v2_case(hip, 0, *shape, tile=256)
+    lib = hip.lib
+    for tile in (64, 128):
+        try:
+            hip.check(lib.p5_set_option(b"gemm_tile", tile), "set_option")
+            cases.gemm_case(hip, 1, 1024, 520, 1536, 0, 1, epi=3)                       # dgrad with the ReLU-mask epilogue
+            cases.gemm_case(hip, 1, 520, 264, 2048, 1, 1, epi=4, c_f32=1, splitk=4)     # wgrad
+        finally:
+            lib.p5_set_option(b"gemm_tile", 0)
+    cases.gemm_case(hip, 1, 512, 2048, 8192, 1, 1, epi=4, c_f32=1, splitk=0)           # launcher picks the ring kernel
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_rmsnorm(hip, dtype):
     cases.rmsnorm_case(hip, dtype, 37, 128)
