@@ -42,9 +42,33 @@ struct P5GemmArgs {
   int c_f32;        // 1: C is fp32 regardless of T
   int splitk;       // >=1
   int ring;         // launcher-internal: use the multi-stage ring kernel
+  int xcd_bm, xcd_bn;   // launcher-internal: tiles per XCD rectangle (0 = contiguous runs)
   float alpha;
   P5Drop drop;
 };
+
+// XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets
+// a contiguous run of tiles, n fastest inside an m row, so the A panel of a row and the B panels are fetched from HBM once
+// per XCD and then hit in its L2 instead of every workgroup streaming its own 2 x (tile x K) bytes.  When the launcher
+// finds an exact cover of the tile grid by 8 rectangles of xcd_bm x xcd_bn tiles it passes that shape instead: an XCD then
+// fetches xcd_bm A panels + xcd_bn B panels, least for the squarest rectangle (a 4 x 16 tile grid of a weight gradient:
+// 4 x 2 blocks move 6 panels per XCD and K-split, 1 x 8 runs move 9).
+template <int BM, int BN>
+__device__ static __forceinline__ void gemm_tile_origin(const P5GemmArgs& g, int& m0, int& n0) {
+  const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
+  const int bid = blockIdx.x + blockIdx.y * gx;
+  const int xcd = bid & 7, idx = bid >> 3;
+  if (g.xcd_bn > 0) {
+    const int bpr = gx / g.xcd_bn;                 // rectangles per row of rectangles
+    m0 = ((xcd / bpr) * g.xcd_bm + idx / g.xcd_bn) * BM;
+    n0 = ((xcd % bpr) * g.xcd_bn + idx % g.xcd_bn) * BN;
+    return;
+  }
+  const int q = nb >> 3, r = nb & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  m0 = (lid / gx) * BM;
+  n0 = (lid % gx) * BN;
+}
 
 // byte size of ONE 64-byte-K chunk of an operand tile of R rows
 template <class T, int R, bool KS> struct LdsChunk {
@@ -325,14 +349,7 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   // contiguous run of tiles -- n fastest inside an m row -- so the A panel of a row and the B panels are fetched from
   // HBM once per XCD and then hit in its L2, instead of every workgroup streaming its own 2 x (tile x K) bytes.
   int m0, n0;
-  {
-    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
-    const int bid = blockIdx.x + blockIdx.y * gx;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    m0 = (lid / gx) * BM;
-    n0 = (lid % gx) * BN;
-  }
+  gemm_tile_origin<BM, BN>(g, m0, n0);
   // split-K range (in steps of NCK chunks)
   const int nst = (g.K + KCH * NCK - 1) / (KCH * NCK);
   const int per = (nst + g.splitk - 1) / g.splitk;
@@ -465,14 +482,7 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
 #endif
   const int wm = wave >> 1, wn = wave & 1;
   int m0, n0;
-  {
-    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
-    const int bid = blockIdx.x + blockIdx.y * gx;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    m0 = (lid / gx) * BM;
-    n0 = (lid % gx) * BN;
-  }
+  gemm_tile_origin<BM, BN>(g, m0, n0);
   const int nst = g.K / 64;
   const int per = (nst + g.splitk - 1) / g.splitk;
   const int st_begin = blockIdx.z * per;
@@ -698,14 +708,7 @@ __global__ __launch_bounds__(WMW* WNW * 64) void p5_gemm3_kernel(P5GemmArgs g) {
 #endif
   const int wm = wave / WNW, wn = wave % WNW;
   int m0, n0;
-  {
-    const int gx = gridDim.x, nb = gridDim.x * gridDim.y;
-    const int bid = blockIdx.x + blockIdx.y * gx;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    m0 = (lid / gx) * BM;
-    n0 = (lid % gx) * BN;
-  }
+  gemm_tile_origin<BM, BN>(g, m0, n0);
   const int nst = g.K / 64;
   const int per = (nst + g.splitk - 1) / g.splitk;
   const int st_begin = blockIdx.z * per;

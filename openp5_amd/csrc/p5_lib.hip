@@ -42,11 +42,28 @@ static int kcheck(const char* where) {
 static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0;
 static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
+static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
 static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 
 template <class T, int BM, int BN>
-static int launch_gemm_tile(const P5GemmArgs& g, hipStream_t s) {
+static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
+  g.xcd_bm = g.xcd_bn = 0;
+  if (g_opt_gemm_xcd_rect) {
+    // exact cover of the gx x gy tile grid by 8 equal rectangles; keep the one with the smallest half-perimeter, and only if
+    // it beats the contiguous-run order (runs of q tiles: ~ceil(q / gx) rows x min(q, gx) columns)
+    const int gx = (int)grid.x, gy = (int)grid.y;
+    if ((gx * gy) % 8 == 0) {
+      const int q = gx * gy / 8;
+      int best = (q + gx - 1) / gx + (q < gx ? q : gx);
+      for (int bn = 1; bn <= gx; ++bn) {
+        if (gx % bn || q % bn) continue;
+        const int bm = q / bn;
+        if (bm > gy || gy % bm || (gx / bn) * (gy / bm) != 8) continue;
+        if (bm + bn < best) { best = bm + bn; g.xcd_bm = bm; g.xcd_bn = bn; }
+      }
+    }
+  }
   const int mode = g.a_ks * 2 + g.b_ks;
   // direct-to-LDS staging for K-contiguous operands whenever every K-step is full (fast-mode dtype only)
   const bool dma = sizeof(T) == 2 && (g.K % (TT<T>::KCH * 2)) == 0;
@@ -115,8 +132,17 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     }
   }
   if (g.splitk > 1) P5_REQUIRE(g.epi == P5_EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
-  if constexpr (sizeof(T) == 2)
-    if (force_tile == 256) return launch_gemm_tile<T, 256, 256>(g, s);
+  if constexpr (sizeof(T) == 2) {
+    // 256x256 tiles halve the L2->LDS bytes per MAC; they pay off once every CU gets a tile and the K loop is long enough to
+    // amortise the un-overlapped prologue/epilogue of the single resident workgroup (tools/gemm_v2_bench.py: 8192x2048x2048
+    // 80 -> 63 us, 4096^3 150 -> 110 us; at K = 512 it is a wash)
+    const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const bool kc_dma = !g.a_ks && !g.b_ks && (g.K % 64) == 0;
+    if (force_tile == 256 || (!force_tile && kc_dma && t256 >= 256 && g.K >= 1024 && g.splitk <= 1)) {
+      if (g.splitk <= 0) g.splitk = 1;
+      return launch_gemm_tile<T, 256, 256>(g, s);
+    }
+  }
   return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
 }
 
@@ -950,6 +976,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
   else if (!strcmp(name, "gemm_ksdma")) g_opt_gemm_ksdma = value;
   else if (!strcmp(name, "gemm_ring")) g_opt_gemm_ring = value;
+  else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else return fail("p5_set_option: unknown option");
   return 0;
 }

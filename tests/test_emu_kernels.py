@@ -13,7 +13,8 @@ def test_tr_probe(emu):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape", [(70, 50, 48, 0, 0, 0), (70, 56, 64, 0, 1, 0), (72, 56, 50, 1, 1, 4), (130, 200, 96, 0, 0, 1),
-                                   (66, 72, 40, 0, 0, 2), (64, 64, 136, 0, 1, 3)])
+                                   (66, 72, 40, 0, 0, 2), (64, 64, 136, 0, 1, 3),
+                                   (256, 512, 64, 0, 0, 0), (512, 256, 128, 1, 1, 4)])      # 32 tiles: 2x2-tile rectangles per XCD
 def test_gemm(emu, dtype, shape):
     M, N, K, aks, bks, epi = shape
     cases.gemm_case(emu, dtype, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=2 if epi == 4 else 1)

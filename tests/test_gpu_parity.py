@@ -47,6 +47,7 @@ def test_gemm_ring_and_big_tile_kernels(hip):
         finally:
             lib.p5_set_option(b"gemm_tile", 0)
     cases.gemm_case(hip, 1, 512, 2048, 8192, 1, 1, epi=4, c_f32=1, splitk=0)           # launcher picks the ring kernel
+    cases.gemm_case(hip, 1, 4096, 4096, 1024, 0, 0, epi=2)                              # launcher picks 256x256 tiles
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

@@ -31,6 +31,22 @@ def run2(m, n, v2, sk):
     r = run(m, n, Mt, 1, 1, 4, 1, 128, sk)
     lib.p5_set_option(b"gemm_v2", 0)
     return r
+def cmp(fn):
+    out = []
+    for rect in (0, 1):
+        lib.p5_set_option(b"gemm_xcd_rect", rect)
+        out.append(fn())
+    return " | ".join(out)
+print("wgrad, launcher heuristics: [contiguous runs | rectangles]")
+for (m, n) in [(1536, 512), (512, 512), (2048, 512), (512, 2048), (1024, 512)]:
+    print(f"  {m}x{n}:", cmp(lambda: run(m, n, Mt, 1, 1, 4, 1, 0, 0)))
+print("fwd: [runs | rectangles]")
+for (n, k) in [(2048, 512), (1536, 512), (512, 512), (512, 2048), (1024, 512)]:
+    print(f"  N={n} K={k}:", cmp(lambda: run(Mt, n, k, 0, 0, 0, 0, 0, 1)))
+print("dgrad: [runs | rectangles]")
+for (n, k) in [(512, 1536), (512, 512), (512, 2048), (2048, 512)]:
+    print(f"  N={n} K={k}:", cmp(lambda: run(Mt, n, k, 0, 1, 0, 0, 0, 1)))
+sys.exit(0)
 lib.p5_set_option(b"gemm_v2", 4)
 print("rel err pipelined wgrad:", [f"{check(*a):.1e}" for a in [(512, 2048, 8192, 1, 1, 128), (520, 264, 1024, 1, 1, 128)]])
 lib.p5_set_option(b"gemm_v2", 0)
