@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
   constexpr int LDS_BYTES = (NST * STAGE > BM * CST) ? NST * STAGE : BM * CST;
   constexpr int NDMA = (BM + BN) / 32;                // direct-to-LDS wave instructions per wave per stage
   constexpr int NFR = TM + TN, NMM = TM * TN;
-  static_assert(NST >= 2 && NST <= 4, "two to four LDS stages");
+  static_assert(NST >= 2 && NST <= 8 && (NST - 2) * ((BM + BN) / 32) <= 60, "LDS stages / vmcnt range");
   constexpr int PFD = NST - 1;                        // stages in flight ahead of the one being multiplied
   static_assert(NMM >= NFR, "interleave pattern: one fragment read per MFMA");
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];

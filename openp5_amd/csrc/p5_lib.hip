@@ -43,6 +43,7 @@ static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0
 static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
+static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
 static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 
 template <class T, int BM, int BN>
@@ -80,6 +81,16 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
       if (v2 == 3) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
       else P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4, true, true>), grid, block, 0, s, g);
       return P5_KCHECK();
+    }
+  }
+  if constexpr (sizeof(T) == 2 && BM == 64) {
+    // small problems (fewer tiles than CUs): the K loop of a lone workgroup is a chain of load latencies, ~1 us per step with
+    // one stage of lookahead.  Eight 16 KiB ring slots keep seven K-steps in flight (K = 512 is fetched entirely up front):
+    // 512x512x512 8.2 -> ~4 us.  This is what the decoder and the decode step are made of.
+    if (g.ring && dma) {
+      if (mode == 0) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, false>), grid, block, 0, s, g); return P5_KCHECK(); }
+      if (mode == 1) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, true>), grid, block, 0, s, g); return P5_KCHECK(); }
+      if (mode == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, true, true>), grid, block, 0, s, g); return P5_KCHECK(); }
     }
   }
   if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
@@ -121,6 +132,12 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     g.splitk = sk < 1 ? 1 : (sk > maxs ? maxs : sk);
   }
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  if (sizeof(T) == 2 && !big && !force_tile && g_opt_gemm_small_ring && !g.ring && tiles <= 256 && g.K >= 256 && (g.K % 64) == 0 &&
+      (!g.b_ks || (g.N % 8) == 0) && (!g.a_ks || (g.M % 8) == 0) && (g.a_ks == 0 || g.b_ks == 1) &&
+      (g.epi != P5_EPI_ATOMIC || g.K <= 1024)) {
+    g.ring = 1;                      // (long-K atomic problems keep the split-K path below)
+    if (g.splitk <= 0) g.splitk = 1;
+  }
   if (g.splitk <= 0) {
     g.splitk = 1;
     if (g.epi == P5_EPI_ATOMIC) {
@@ -976,6 +993,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
   else if (!strcmp(name, "gemm_ksdma")) g_opt_gemm_ksdma = value;
   else if (!strcmp(name, "gemm_ring")) g_opt_gemm_ring = value;
+  else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else return fail("p5_set_option: unknown option");
   return 0;

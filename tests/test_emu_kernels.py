@@ -28,6 +28,14 @@ def test_gemm_pipelined_loop(emu, stages, shape):
     cases.gemm_v2_case(emu, stages, *shape)
 
 
+@pytest.mark.parametrize("shape", [(70, 56, 256, 0, 0, 2), (72, 56, 320, 0, 1, 3), (72, 56, 512, 1, 1, 4), (200, 136, 1024, 0, 0, 1),
+                                   (64, 64, 256, 0, 1, 0), (8, 8, 256, 1, 1, 4)])
+def test_gemm_small_problem_ring(emu, shape):
+    """fewer tiles than CUs and K >= 256: the launcher picks the eight-slot ring (seven K-steps in flight), all operand modes."""
+    M, N, K, aks, bks, epi = shape
+    cases.gemm_case(emu, 1, M, N, K, aks, bks, epi=epi, c_f32=1 if epi == 4 else 0, splitk=1)
+
+
 @pytest.mark.parametrize("stages", [3, 4])
 @pytest.mark.parametrize("shape", [(136, 200, 64), (136, 72, 192), (128, 128, 384), (40, 264, 640), (8, 8, 128)])
 def test_gemm_pipelined_loop_wgrad(emu, stages, shape):
