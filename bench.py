@@ -71,16 +71,23 @@ def runner_loss(nll, out_attn):
     return (loss.sum(dim=1) / m.sum(dim=1).clamp(min=1)).mean()
 
 
-def time_gemm_kernel(be, M, N, K, iters=50):
-    """average duration of the dominant kernel (forward bf16 GEMM, 128x128 tile) measured with HIP events on the
-    stream the kernel is launched on."""
+def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
+    """average duration of a GEMM kernel measured with HIP events on the stream the kernel is launched on.
+    wgrad=False: forward bf16 GEMM y = x W^T (both operands K-contiguous, 128x128 tile);
+    wgrad=True : weight gradient dW[M,N] += dy^T x over K tokens (both operands K-strided, ring kernel, split-K atomics)."""
     import ctypes
-    A = torch.randn(M, K, device=be.device).to(torch.bfloat16)
-    Bm = torch.randn(N, K, device=be.device).to(torch.bfloat16)
-    C = torch.empty(M, N, device=be.device, dtype=torch.bfloat16)
     P = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
     s = torch.cuda.current_stream()
-    call = lambda: be.lib.p5_op_gemm(1, P(A), P(Bm), P(C), None, M, N, K, K, K, N, 0, 0, 0, 0, 0, 1, 1.0, None, 0, 0.0, be.stream_ptr())  # noqa: E731
+    if wgrad:
+        A = torch.randn(K, M, device=be.device).to(torch.bfloat16)
+        Bm = torch.randn(K, N, device=be.device).to(torch.bfloat16)
+        C = torch.zeros(M, N, device=be.device, dtype=torch.float32)
+        call = lambda: be.lib.p5_op_gemm(1, P(A), P(Bm), P(C), None, M, N, K, M, N, N, 0, 1, 1, 4, 1, 0, 1.0, None, 0, 0.0, be.stream_ptr())  # noqa: E731
+    else:
+        A = torch.randn(M, K, device=be.device).to(torch.bfloat16)
+        Bm = torch.randn(N, K, device=be.device).to(torch.bfloat16)
+        C = torch.empty(M, N, device=be.device, dtype=torch.bfloat16)
+        call = lambda: be.lib.p5_op_gemm(1, P(A), P(Bm), P(C), None, M, N, K, K, K, N, 0, 0, 0, 0, 0, 1, 1.0, None, 0, 0.0, be.stream_ptr())  # noqa: E731
     for _ in range(5):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,6 +238,8 @@ def main():
         Mg, Ng, Kg = B * L, c.d_ff, c.d_model
         t_k = time_gemm_kernel(be, Mg, Ng, Kg)
         ach = 2.0 * Mg * Ng * Kg / t_k / 1e12
+        t_w = time_gemm_kernel(be, Ng, Kg, Mg, wgrad=True)          # dW_i[F, d] over B*L tokens
+        ach_w = 2.0 * Mg * Ng * Kg / t_w / 1e12
         line = {
             "metric": "train_samples_per_sec", "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -243,14 +252,19 @@ def main():
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
-            # dominant kernel family = the bf16 MFMA GEMM (forward / dgrad / wgrad instantiations are ~70 % of the step,
-            # profiles/r01_train_t5small_b64_kernel_stats.md); timed live on its largest forward shape.  `traffic` is the
-            # PMC-measured HBM bytes per launch of exactly this kernel+shape (2 x FETCH_SIZE + WRITE_SIZE with the gfx950
+            # dominant kernel family = the bf16 MFMA GEMMs (p5_gemm_kernel forward/dgrad instantiations + the ring kernels are
+            # ~70 % of the kernel time, profiles/r01_train_t5small_b64_kernel_stats.md); `roofline` times the largest forward
+            # shape live, `roofline_wgrad` the same FLOPs as a weight gradient on the ring kernel (in the step that kernel
+            # shares the GPU with the main stream, so its in-step launches are longer; profiles/README.md).  `traffic` is
+            # the PMC-measured HBM bytes per launch of exactly this kernel+shape (2 x FETCH_SIZE + WRITE_SIZE with the gfx950
             # correction, profiles/r01_pmc_gemm.md) -- a recorded measurement, not collected inside this run.
             "roofline": {"bound": "mfma", "kernel": "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>", "shape": [Mg, Ng, Kg],
                          "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
                          "traffic": 75.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None, "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
                          "avg_launch_us": t_k * 1e6},
+            "roofline_wgrad": {"bound": "mfma", "kernel": "p5_gemm2_kernel<128,128,ring4,KS,KS>", "shape": [Ng, Kg, Mg], "achieved": ach_w,
+                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS, "traffic": None,
+                               "algorithmic_bytes": 2.0 * (Mg * Kg + Mg * Ng) + 4.0 * Ng * Kg, "avg_launch_us": t_w * 1e6},
         }
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline()

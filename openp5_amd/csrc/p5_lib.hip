@@ -44,6 +44,8 @@ static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE"
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
 static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
+static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
+static int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING_WGS")) : 160;      // target tiles x splits (in-step sweep: 96..192 equal, 256 +1.5 %)
 static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 
 template <class T, int BM, int BN>
@@ -78,7 +80,7 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
     if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 3 && dma && (g.N % 8) == 0 && (g.M % 8) == 0 && (v2 >= 3 || g.ring)) {
-      if (v2 == 3) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
+      if (v2 == 3 || (v2 == 0 && g_opt_gemm_ring_stages == 3)) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
       else P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4, true, true>), grid, block, 0, s, g);
       return P5_KCHECK();
     }
@@ -121,13 +123,14 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
   // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
-  // split-K so that tiles x splits ~ 256 (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
+  // split-K so that tiles x splits ~ 160: in isolation ~256 (every CU) is fastest, inside the step fewer, longer workgroups leave
+  // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
   // below 48 tiles the 64x64 kernel still wins)
   if (sizeof(T) == 2 && !force_tile && g_opt_gemm_ring && g.a_ks && g.b_ks && g.epi == P5_EPI_ATOMIC && g.splitk <= 0 && t128 >= 48 &&
       t128 <= 256 && g.K >= 2048 && (g.K % 64) == 0 && (g.M % 8) == 0 && (g.N % 8) == 0) {
     g.ring = 1;
     big = true;
-    int sk = (int)((256 + t128 / 2) / t128);
+    int sk = (int)((g_opt_gemm_ring_wgs + t128 / 2) / t128);
     const int maxs = g.K / 64 / 8;
     g.splitk = sk < 1 ? 1 : (sk > maxs ? maxs : sk);
   }
