@@ -43,6 +43,11 @@ struct P5GemmArgs {
   int splitk;       // >=1
   int ring;         // launcher-internal: use the multi-stage ring kernel
   int xcd_bm, xcd_bn;   // launcher-internal: tiles per XCD rectangle (0 = contiguous runs)
+  // RMSNorm folded into the GEMMs of the decode step: the norm weight lives in the B operand, the row
+  // statistic arrives / leaves as a sum of squares:
+  const float* rowss;   // [M] sum_j x[row,j]^2 of the A rows, or nullptr: acc *= rsqrt(rowss[row] * rowss_invd + rowss_eps)
+  float rowss_invd, rowss_eps;
+  float* ssq_out;       // [M] or nullptr: += sum of squares of the stored C row (as rounded to the C dtype)
   float alpha;
   P5Drop drop;
 };
@@ -271,13 +276,16 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int r = 0; r < 4; ++r) {
+          const int lr = wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
+          float sc = g.alpha;
+          if (g.rowss) sc *= rsqrtf(g.rowss[(m0 + lr) < g.M ? (m0 + lr) : (g.M - 1)] * g.rowss_invd + g.rowss_eps);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int lr = wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
+          for (int j = 0; j < TN; ++j) {
             const int lc = wn * (BN / WNW) + j * 16 + (lane & 15);
-            *(bf16*)(lds + lr * CST + lc * 2) = f2bf(acc[i][j][r] * g.alpha);
+            *(bf16*)(lds + lr * CST + lc * 2) = f2bf(acc[i][j][r] * sc);
           }
+        }
       __syncthreads();
       constexpr int PPR = BN / 8;                 // 16-byte pieces per tile row
       constexpr int NPIECE = BM * PPR / NT;
@@ -286,16 +294,32 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         const int p = tid + i * NT;
         const int lr = p / PPR, pc = p % PPR;
         const int row = m0 + lr, col = n0 + pc * 8;
-        if (row >= g.M || col >= g.N) continue;
-        float v[8];
-        unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
-        if (g.epi != P5_EPI_STORE) {
-          float av[8];
-          if (g.aux) unpack16<bf16>(ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
+        const bool ok = row < g.M && col < g.N;
+        float ss = 0.f;
+        if (ok) {
+          float v[8];
+          unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
+          if (g.epi != P5_EPI_STORE) {
+            float av[8];
+            if (g.aux) unpack16<bf16>(ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], g.aux ? av[e] : 0.f, seed, do_drop, row, col + e);
+            for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], g.aux ? av[e] : 0.f, seed, do_drop, row, col + e);
+          }
+          const u32x4 packed = pack16<bf16>(v);
+          st16((bf16*)g.C + (size_t)row * g.ldc + col, packed);
+          if (g.ssq_out) {    // sum of squares of the row as stored
+            float w[8];
+            unpack16<bf16>(packed, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += w[e] * w[e];
+          }
         }
-        st16((bf16*)g.C + (size_t)row * g.ldc + col, pack16<bf16>(v));
+        if (g.ssq_out) {      // (uniform branch) the PPR lanes of a tile row are adjacent: one atomic per tile row
+          static_assert(PPR <= 64 && (PPR & (PPR - 1)) == 0, "pieces per row: power of two within a wave");
+#pragma unroll
+          for (int m = PPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+          if (pc == 0 && row < g.M) atomicAdd(g.ssq_out + row, ss);
+        }
       }
       return;
     }
@@ -314,7 +338,13 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         const size_t ci = (size_t)row * g.ldc + col;
         float auxv = 0.f;
         if (g.aux) auxv = to_f<T>(((const T*)g.aux)[(size_t)row * g.ldaux + col]);
-        const float v = gemm_epi_apply(g, acc[i][j][r] * g.alpha, auxv, seed, do_drop, row, col);
+        float sc = g.alpha;
+        if (g.rowss) sc *= rsqrtf(g.rowss[row] * g.rowss_invd + g.rowss_eps);
+        const float v = gemm_epi_apply(g, acc[i][j][r] * sc, auxv, seed, do_drop, row, col);
+        if (g.ssq_out) {
+          const float w = g.c_f32 ? v : to_f<T>(from_f<T>(v));
+          atomicAdd(g.ssq_out + row, w * w);
+        }
         if (g.epi == P5_EPI_ATOMIC) {
           atomicAdd(((float*)g.C) + ci, v);
         } else if (g.epi == P5_EPI_ACCUM) {

@@ -46,6 +46,7 @@ static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GE
 static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
 static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
 static int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING_WGS")) : 160;      // target tiles x splits (in-step sweep: 96..192 equal, 256 +1.5 %)
+static int g_opt_decode_fused = getenv("P5_DECODE_FUSED") ? atoi(getenv("P5_DECODE_FUSED")) : 1;   // RMSNorm folded into the decode-step GEMMs
 static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 
 template <class T, int BM, int BN>
@@ -260,6 +261,11 @@ struct P5Engine {
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
+  // decode-step weights with the following RMSNorm weight folded in (W[out,in] * ln[in]): per decoder layer qkv / cross-q / wi,
+  // and the tied head E * final_ln; caller-owned buffer in the compute dtype (p5_engine_bind_decode_fold)
+  void* fold = nullptr;
+  std::vector<int64_t> fold_qkv, fold_q, fold_wi;
+  int64_t fold_E = 0, fold_count = 0;
 #ifndef P5_EMU
   hipGraphExec_t gen_graph_exec = nullptr;
   bool gen_graph_failed = false;
@@ -381,6 +387,20 @@ static void build_layout(P5Engine* e) {
   }
   add_param(e, "decoder.final_layer_norm.weight", 1, d, e->off_dec_fln);
   e->n_params = (e->n_params + 63) & ~(int64_t)63;
+  // folded decode-step weights (element offsets into the fold buffer, 64-element aligned)
+  {
+    const int in = c.n_heads * c.d_kv;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { const int64_t o = off; off += (n + 63) & ~(int64_t)63; return o; };
+    e->fold_qkv.clear(); e->fold_q.clear(); e->fold_wi.clear();
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      e->fold_qkv.push_back(take((int64_t)3 * in * d));
+      e->fold_q.push_back(take((int64_t)in * d));
+      e->fold_wi.push_back(take((int64_t)(c.gated_gelu ? 2 : 1) * F * d));
+    }
+    e->fold_E = take((int64_t)c.vocab_size * d);
+    e->fold_count = off;
+  }
 }
 
 template <class T> static const T* Wc(const P5Engine* e, int64_t off) {
@@ -403,11 +423,20 @@ static P5Drop no_drop() { P5Drop d; d.state = nullptr; d.site_key = 0; d.thr = 0
 
 template <class T>
 static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, int ldb, int bks, void* C, int ldc, int M, int N,
-                int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop) {
+                int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop, const float* rowss = nullptr,
+                float rowss_eps = 0.f, float* ssq_out = nullptr) {
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
+  g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = rowss_eps; g.ssq_out = ssq_out;
   return launch_gemm<T>(g, s);
+}
+// decode step: y = rmsnorm(x) W^T with the norm weight folded into Wf and the row statistic taken from `rowss` (sum of squares
+// of the rows of x, K = d_model); optional ssq_out collects the sum of squares of the rows of y for the NEXT norm
+template <class T>
+static int linear_fwd_fused(hipStream_t s, const void* x, int ldx, const T* Wf, void* y, int ldy, int M, int N, int K, int epi,
+                            const void* aux, int ldaux, float alpha, int c_f32, const float* rowss, float eps, float* ssq_out) {
+  return gemm<T>(s, x, ldx, 0, Wf, K, 0, y, ldy, M, N, K, epi, aux, ldaux, alpha, c_f32, no_drop(), rowss, eps, ssq_out);
 }
 // y = x W^T
 template <class T>
@@ -816,6 +845,7 @@ struct GenWs {
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
   float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
   int64_t* mask_copy;
+  float* ssq;             // [3 * n_dec_layers + 1][R] row sums of squares of the residual stream entering each norm (fused path)
   uint32_t* excluded;     // [B, excl_words] copy of the caller's per-item excluded-node bitmap (stable address for the graph)
   P5BeamState st;
 };
@@ -838,6 +868,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.qkv = b.take(R * 3 * in * sz); w.q = b.take(R * in * sz); w.o = b.take(R * in * sz);
   w.h = b.take(R * (c.gated_gelu ? 3 : 1) * F * sz); w.hn = b.take(R * d * sz);
   w.logits = (float*)b.take(R * Vp * 4);
+  w.ssq = (float*)b.take((size_t)(3 * c.n_dec_layers + 1) * R * 4);
   w.cand = (float*)b.take(R * (size_t)max_c * 4);
   w.n_cand = (int*)b.take(R * 4);
   w.row_top_score = (float*)b.take(R * (size_t)(2 * K) * 4);
@@ -857,45 +888,81 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
 }
 
 template <class T>
+static const T* Wf(const P5Engine* e, int64_t off) { return (const T*)e->fold + off; }
+
+// One decoder step over R = B*K rows.  With a fold buffer bound (p5_engine_bind_decode_fold) every RMSNorm except the
+// first disappears as a kernel: its weight is folded into the consuming projection (W * ln), its row statistic
+// sum(x^2) is accumulated by the residual epilogue that PRODUCES x (one atomic per 64-column tile row) and applied as a
+// row scale in the epilogue of the consuming GEMM -- 18 of 73 launches fewer for T5-small.
+template <class T>
 static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, R = B * K;
+  const bool fused = e->fold != nullptr && g_opt_decode_fused;
   P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.xa, Wc<T>(e, e->off_E), (const T*)nullptr,
             (const int64_t*)w.st.last_tok, (const int64_t*)nullptr, R, d, no_drop());
   P5_TRY(P5_KCHECK());
   void* x = w.xa; void* y = w.xb;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  int site = 0;                                   // index of the ssq row that holds sum(x^2) of the current x
+  auto ssq_row = [&](int k) { return w.ssq + (size_t)k * R; };
+  if (fused) hipMemsetAsync(w.ssq, 0, (size_t)(3 * c.n_dec_layers + 1) * R * 4, s);
   for (int i = 0; i < c.n_dec_layers; ++i) {
     const LayerOff& lo = e->dec[i];
-    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.sa.ln, R, d, c.eps, no_drop()));
-    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.sa.q), w.qkv, 3 * in, R, 3 * in, d));
+    // ---- self-attention ----
+    if (fused && i > 0) {
+      P5_TRY(linear_fwd_fused<T>(s, x, d, Wf<T>(e, e->fold_qkv[i]), w.qkv, 3 * in, R, 3 * in, d, P5_EPI_STORE, nullptr, 0, 1.f, 0,
+                                 ssq_row(site), c.eps, nullptr));
+    } else {
+      P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.sa.ln, R, d, c.eps, no_drop()));
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.sa.q), w.qkv, 3 * in, R, 3 * in, d));
+    }
     P5_LAUNCH((p5_dec_self_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i],
               (const int*)w.st.anc, (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H,
               (const int*)(w.st.flags + 2), max_len);
     P5_TRY(P5_KCHECK());
-    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.sa.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
+    ++site;
+    P5_TRY(gemm<T>(s, w.o, in, 0, Wc<T>(e, lo.sa.o), in, 0, y, d, R, d, in, P5_EPI_RESID_DROP, x, d, 1.f, 0, no_drop(), nullptr, 0.f,
+                   fused ? ssq_row(site) : nullptr));
     std::swap(x, y);
-    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ca.ln, R, d, c.eps, no_drop()));
-    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.ca.q), w.q, in, R, in, d));
+    // ---- cross-attention ----
+    if (fused) {
+      P5_TRY(linear_fwd_fused<T>(s, x, d, Wf<T>(e, e->fold_q[i]), w.q, in, R, in, d, P5_EPI_STORE, nullptr, 0, 1.f, 0, ssq_row(site), c.eps,
+                                 nullptr));
+    } else {
+      P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ca.ln, R, d, c.eps, no_drop()));
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.ca.q), w.q, in, R, in, d));
+    }
     P5_LAUNCH((p5_dec_cross_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.q, (const T*)w.kv_cross[i],
               (const int64_t*)w.mask_copy, R, H, K, L);
     P5_TRY(P5_KCHECK());
-    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.ca.o), y, d, R, d, in, P5_EPI_RESID_DROP, x, d));
+    ++site;
+    P5_TRY(gemm<T>(s, w.o, in, 0, Wc<T>(e, lo.ca.o), in, 0, y, d, R, d, in, P5_EPI_RESID_DROP, x, d, 1.f, 0, no_drop(), nullptr, 0.f,
+                   fused ? ssq_row(site) : nullptr));
     std::swap(x, y);
-    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ff_ln, R, d, c.eps, no_drop()));
+    // ---- feed-forward ----
+    if (!fused) P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ff_ln, R, d, c.eps, no_drop()));
+    const void* ffn_in = fused ? x : w.n;
+    const T* Wi = fused ? Wf<T>(e, e->fold_wi[i]) : Wc<T>(e, lo.wi);
+    const float* rs = fused ? ssq_row(site) : nullptr;
     if (c.gated_gelu) {
       T* u = (T*)w.h + (size_t)R * F;
-      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), u, 2 * F, R, 2 * F, d));
+      P5_TRY(linear_fwd_fused<T>(s, ffn_in, d, Wi, u, 2 * F, R, 2 * F, d, P5_EPI_STORE, nullptr, 0, 1.f, 0, rs, c.eps, nullptr));
       const size_t n = (size_t)R * F;
       P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (T*)w.h, (const T*)u, R, F, no_drop());
       P5_TRY(P5_KCHECK());
     } else {
-      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), w.h, F, R, F, d, P5_EPI_RELU_DROP));
+      P5_TRY(linear_fwd_fused<T>(s, ffn_in, d, Wi, w.h, F, R, F, d, P5_EPI_RELU_DROP, nullptr, 0, 1.f, 0, rs, c.eps, nullptr));
     }
-    P5_TRY(linear_fwd<T>(s, w.h, F, Wc<T>(e, lo.wo), y, d, R, d, F, P5_EPI_RESID_DROP, x, d));
+    ++site;
+    P5_TRY(gemm<T>(s, w.h, F, 0, Wc<T>(e, lo.wo), F, 0, y, d, R, d, F, P5_EPI_RESID_DROP, x, d, 1.f, 0, no_drop(), nullptr, 0.f,
+                   fused ? ssq_row(site) : nullptr));
     std::swap(x, y);
   }
+  if (fused)      // logits = (norm(x) * d^-0.5) E^T  with  E * final_ln folded
+    return linear_fwd_fused<T>(s, x, d, Wf<T>(e, e->fold_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0,
+                               1.0f / sqrtf((float)d), 1, ssq_row(site), c.eps, nullptr);
   P5_TRY(rmsnorm_fwd<T>(s, w.hn, nullptr, x, e->P + e->off_dec_fln, R, d, c.eps, no_drop()));
-  const int Vp = (c.vocab_size + 63) / 64 * 64;
   return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, 1.0f / sqrtf((float)d), 1);
 }
 
@@ -988,6 +1055,31 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
+// out[r, c] = W[r, c] * ln[c]  (fp32 product of the master weights, rounded once to the compute dtype)
+template <class T>
+__global__ __launch_bounds__(256) void p5_fold_norm_kernel(T* __restrict__ out, const float* __restrict__ W, const float* __restrict__ ln,
+                                                          size_t n, int cols) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = from_f<T>(W[i] * ln[i % cols]);
+}
+template <class T>
+static int refresh_fold(P5Engine* e, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner;
+  auto fold = [&](int64_t dst, int64_t w_off, int64_t ln_off, int64_t rows) -> int {
+    const size_t n = (size_t)rows * d;
+    P5_LAUNCH((p5_fold_norm_kernel<T>), dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, (T*)e->fold + dst,
+              (const float*)(e->P + w_off), (const float*)(e->P + ln_off), n, d);
+    return P5_KCHECK();
+  };
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const LayerOff& lo = e->dec[i];
+    P5_TRY(fold(e->fold_qkv[i], lo.sa.q, lo.sa.ln, 3 * in));       // q, k, v are contiguous in the arena
+    P5_TRY(fold(e->fold_q[i], lo.ca.q, lo.ca.ln, in));
+    P5_TRY(fold(e->fold_wi[i], lo.wi, lo.ff_ln, (int64_t)(c.gated_gelu ? 2 : 1) * c.d_ff));
+  }
+  return fold(e->fold_E, e->off_E, e->off_dec_fln, c.vocab_size);
+}
+
 extern "C" {
 
 const char* p5_last_error(void) { return g_err.c_str(); }
@@ -996,6 +1088,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
   else if (!strcmp(name, "gemm_ksdma")) g_opt_gemm_ksdma = value;
   else if (!strcmp(name, "gemm_ring")) g_opt_gemm_ring = value;
+  else if (!strcmp(name, "decode_fused")) g_opt_decode_fused = value;
   else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else return fail("p5_set_option: unknown option");
@@ -1042,6 +1135,13 @@ int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const
   e->P = params; e->G = grads; e->S = shadow; e->lut_enc = lut_enc; e->lut_dec = lut_dec; e->lut_half = lut_half; e->rng = rng_state;
   return 0;
 }
+int64_t p5_decode_fold_count(const P5Engine* e) { return e->fold_count; }
+int p5_engine_bind_decode_fold(P5Engine* e, void* buf) { e->fold = buf; return 0; }
+int p5_refresh_decode_fold(P5Engine* e, void* stream) {
+  P5_REQUIRE(e->P && e->fold, "engine / fold buffer not bound");
+  return e->c.dtype == 1 ? refresh_fold<bf16>(e, (hipStream_t)stream) : refresh_fold<float>(e, (hipStream_t)stream);
+}
+
 int p5_refresh_shadow(P5Engine* e, void* stream) {
   if (e->c.dtype != 1) return 0;
   const size_t n = (size_t)e->n_params;
@@ -1171,6 +1271,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
+  g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr;
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
 }
 int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream) {

@@ -119,6 +119,7 @@ class _P5LossFn(torch.autograd.Function):
 class P5T5Native(nn.Module):
     LUT_HALF = 512
     use_side_stream = True
+    fuse_decode_norms = True      # generate(): fold the decoder RMSNorms into the GEMMs around them
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
         super().__init__()
@@ -141,6 +142,8 @@ class P5T5Native(nn.Module):
         self.ddp_group = None
         self._pending = []
         self._side = None
+        self._fold = None
+        self._fold_dirty = True
         self._build(seed)
 
     # ------------------------------------------------------------------ engine / arena plumbing
@@ -160,6 +163,7 @@ class P5T5Native(nn.Module):
         if self._engine:
             self._lib.p5_engine_destroy(self._engine)
         self._engine = ctypes.c_void_p()
+        self._fold, self._fold_dirty = None, True       # sized by (and bound to) the engine
         cfg = self._cfg_struct()
         self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine)), "p5_engine_create")
         table = []
@@ -198,6 +202,7 @@ class P5T5Native(nn.Module):
             self._copy_in(old_state, strict=False)
         self._bind()
         self._shadow_dirty = True
+        self._fold_dirty = True
 
     def _register_dotted(self, name, p):
         parts = name.split(".")
@@ -248,9 +253,24 @@ class P5T5Native(nn.Module):
             self._be.check(self._lib.p5_refresh_shadow(self._engine, self._be.stream_ptr()), "p5_refresh_shadow")
         self._shadow_dirty = False
 
+    def _sync_decode_fold(self):
+        """Decode-step weights with the RMSNorm weights folded in (include/p5hip.h: p5_refresh_decode_fold); rebuilt lazily
+        from the fp32 master parameters whenever they have changed since the last generate()."""
+        if not self.fuse_decode_norms:
+            return
+        if self._fold is None:
+            n = int(self._lib.p5_decode_fold_count(self._engine))
+            self._fold = torch.empty(n, dtype=torch.bfloat16 if self.compute_dtype == 1 else torch.float32, device=self._flat.device)
+            self._be.check(self._lib.p5_engine_bind_decode_fold(self._engine, _ptr(self._fold)), "p5_engine_bind_decode_fold")
+            self._fold_dirty = True
+        if self._fold_dirty:
+            self._be.check(self._lib.p5_refresh_decode_fold(self._engine, self._be.stream_ptr()), "p5_refresh_decode_fold")
+            self._fold_dirty = False
+
     def mark_params_updated(self, shadow_fresh: bool = False):
         """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
         self._shadow_dirty = not shadow_fresh
+        self._fold_dirty = True
 
     # ------------------------------------------------------------------ nn.Module protocol
     def _apply(self, fn, recurse=True):
@@ -300,6 +320,7 @@ class P5T5Native(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing={missing} unexpected={unexpected}")
         self._shadow_dirty = True
+        self._fold_dirty = True
         return missing, unexpected
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -349,6 +370,7 @@ class P5T5Native(nn.Module):
         n = min(old, new_num_tokens)
         self.shared.weight[:n].copy_(old_E[:n])
         self._shadow_dirty = True
+        self._fold_dirty = True
         return self.shared
 
     def get_input_embeddings(self):
@@ -490,6 +512,7 @@ class P5T5Native(nn.Module):
         if roots is not None:
             roots_t = torch.as_tensor(roots, dtype=torch.int32, device=dev).contiguous()
         self._sync_shadow()
+        self._sync_decode_fold()
         maxc = max(1, trie.max_children)
         excl_t, excl_words = None, 0
         if excluded is not None:

@@ -108,6 +108,20 @@ def test_generate(emu, via):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
 
 
+def test_generate_unfused_decode_norms(emu):
+    """the decode step with separate RMSNorm kernels (p5_set_option decode_fused 0) -- the default folds them into the GEMMs."""
+    try:
+        emu.check(emu.lib.p5_set_option(b"decode_fused", 0), "set_option")
+        cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40)
+    finally:
+        emu.lib.p5_set_option(b"decode_fused", 1)
+
+
+def test_generate_gated_fused(emu):
+    """gated-gelu FFN (T5 v1.1) through the fused decode step."""
+    cases.generate_case(emu, O.T5Cfg.named("tiny", ff_act="gated-gelu"), 2, 12, 4, 10, 30, seed=11)
+
+
 def test_generate_excluded_history(emu):
     """filtered protocol: shared trie + per-user excluded-node bitmap == one Trie(all_items - positive) per user."""
     cases.generate_excluded_case(emu, O.T5Cfg.named("tiny"), 3, 14, 5, 12, 40)
