@@ -248,7 +248,7 @@ struct P5BeamState {
   int* unsat;                        // [B]
   int* anc; int* anc_next;           // [max_len, R]
   int64_t* last_tok;                 // [R] decoder input for the next step
-  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len
+  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len, [3] arrivals
 };
 
 // ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
@@ -284,7 +284,35 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   }
   if (tid == 0) s_nothit = 0;
   __syncthreads();
-  for (int it = 0; it < K2; ++it) {
+  __shared__ int ckey[1024];
+  const bool by_rank = Kb * K2 <= 1024;
+  if (by_rank) {
+    // every candidate computes its own rank in the (score desc, beam*max_c + child asc) order -- all in parallel instead of
+    // 2K rounds of block-wide arg-max; the 2K best land at their rank
+    for (int t = tid; t < Kb * K2; t += 256)
+      ckey[t] = (cs[t] == P5_NEG_INF) ? 0x7fffffff : (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2];
+    if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }   // fewer than 2K candidates
+    __syncthreads();
+    for (int t = tid; t < Kb * K2; t += 256) {
+      const float v = cs[t];
+      if (v == P5_NEG_INF) continue;
+      const int key = ckey[t];
+      int rank = 0;
+      for (int u = 0; u < Kb * K2; ++u) {
+        const float vu = cs[u];
+        rank += (vu > v || (vu == v && ckey[u] < key)) ? 1 : 0;
+      }
+      if (rank < K2) {
+        const int j = t / K2, c = key - j * max_c;
+        const int nd = st.run_node[b * Kb + j];
+        top_lp[rank] = v; top_beam[rank] = j;
+        top_tok[rank] = child_tok[child_off[nd] + c];
+        top_node[rank] = child_node[child_off[nd] + c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int it = 0; it < (by_rank ? 0 : K2); ++it) {
     float bv = P5_NEG_INF;
     int bi = 0x7fffffff;          // tie-break key = beam * max_c + child  (== HF's flat beam*V + token order)
     for (int t = tid; t < Kb * K2; t += 256) {
@@ -395,11 +423,18 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
     st.last_tok[b * Kb + tid] = (int64_t)top_tok[i];
     st.run_score[b * Kb + tid] = run_sc[tid];
   }
+  // the step counter advances once every workgroup of this launch is done with it (they all read it on entry): the last one
+  // to arrive bumps it -- this used to be a launch of its own
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(&st.flags[3], 1) == (int)gridDim.x - 1) {
+      st.flags[3] = 0;
+      st.flags[2] = cur_len + 1;
+    }
+  }
 }
 
-__global__ void p5_beam_tick_kernel(int* flags) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) flags[2] += 1;
-}
 
 // initial state: every beam at the trie node reached by the decoder start token, scores [0, -1e9, ...]
 __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const int* __restrict__ child_off, const int* __restrict__ child_tok,
@@ -425,5 +460,5 @@ __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const
     st.last_tok[i] = start_id;
   }
   if (i < B) st.unsat[i] = 1;
-  if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; }
+  if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; st.flags[3] = 0; }
 }

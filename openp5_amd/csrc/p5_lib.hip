@@ -994,8 +994,6 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
     P5_TRY(P5_KCHECK());
     P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
               (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, c.eos_id, R);
-    P5_TRY(P5_KCHECK());
-    P5_LAUNCH(p5_beam_tick_kernel, dim3(1), dim3(64), 0, s, w.st.flags);
     return P5_KCHECK();
   };
 #ifndef P5_EMU
