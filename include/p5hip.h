@@ -41,7 +41,8 @@ typedef struct P5Config {
 typedef struct P5Engine P5Engine;
 
 const char* p5_last_error(void);
-/* process-wide tuning knobs (tests / benchmarks): "gemm_v2" = 0|2|3, "gemm_tile" = 0|64|128 */
+/* process-wide tuning knobs (tests / benchmarks): "gemm_tile" = 0|64|128|256, "gemm_v2" = 0|2|3|4 (hand-pipelined loop for forced
+ * 128x128 tiles), "gemm_ring", "gemm_small_ring", "gemm_ksdma", "gemm_xcd_rect", "decode_fused" = 0|1 */
 int p5_set_option(const char* name, int value);
 int p5_abi_version(void);
 int p5_is_emulator(void);   /* 1 only for the test-only host emulation build under tests/emu */

@@ -232,7 +232,7 @@ struct Bump {
   }
 };
 
-struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S; int sz; };
+struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S, *fold; int sz, fused; };
 
 struct P5Engine {
   P5Config c;
@@ -1002,7 +1002,7 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   GraphKey key;
   memset(&key, 0, sizeof(key));
   key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.excl_words = excl_words; key.ws = ws; key.trie = child_off; key.trie_tok = child_tok; key.trie_node = child_node; key.roots = roots;
-  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T);
+  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.fused = g_opt_decode_fused;
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
   auto capture = [&]() {
     // (never during the very first step: the first launch of a kernel loads its code object, which is not allowed
