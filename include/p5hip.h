@@ -59,6 +59,9 @@ int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t
 int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const int* lut_enc, const int* lut_dec,
                    int lut_half, uint32_t* rng_state);
 int p5_refresh_shadow(P5Engine* e, void* stream);
+/* The caller has just zero-filled the gradient arena on the stream the next backward will use (optimizer.zero_grad()):
+ * that backward then skips its own clearing pass (243 MB for T5-small).  One-shot. */
+int p5_engine_grads_zeroed(P5Engine* e);
 /* optional second stream: weight-gradient GEMMs run on it, one sub-layer behind the dgrad chain (NULL = single stream) */
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream);
 

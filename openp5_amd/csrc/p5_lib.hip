@@ -261,6 +261,7 @@ struct P5Engine {
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
+  bool grads_zeroed = false;      // p5_engine_grads_zeroed(): the next backward need not clear the gradient arena again
   // decode-step weights with the following RMSNorm weight folded in (W[out,in] * ln[in]): per decoder layer qkv / cross-q / wi,
   // and the tied head E * final_ln; caller-owned buffer in the compute dtype (p5_engine_bind_decode_fold)
   void* fold = nullptr;
@@ -735,7 +736,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
   const int nd = c.n_dec_layers, ne = c.n_enc_layers;
   if (stage == 0) {
-    hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);
+    if (!e->grads_zeroed) hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);     // (the caller may just have done it: zero_grad())
+    e->grads_zeroed = false;
     hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     e->sub = -1;
@@ -1177,6 +1179,7 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   if (stage == p5_backward_num_stages(e) - 1) join_side(e, (hipStream_t)stream);
   return 0;
 }
+int p5_engine_grads_zeroed(P5Engine* e) { e->grads_zeroed = true; return 0; }
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
 #ifndef P5_EMU
   if (side_stream && !e->side) {
