@@ -273,6 +273,22 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         (g.aux == nullptr || ((g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0))) {
       // ---- LDS-staged epilogue: accumulators -> bf16 tile in LDS -> 16-byte rows (aux reads + C writes) ----
       // (the K loop ended with a barrier, so the staging buffers are free)
+      constexpr int PPR = BN / 8;                 // 16-byte pieces per tile row
+      constexpr int NPIECE = BM * PPR / NT;
+      // the aux pieces (residual / saved hidden) are requested BEFORE the accumulators are staged: inside the store loop below
+      // hipcc cannot move a load above the preceding C store (possible alias), which serialises NPIECE HBM round trips
+      constexpr bool PRE = NPIECE <= 8;
+      u32x4 auxr[PRE ? NPIECE : 1];
+      if constexpr (PRE) {
+        if (g.aux && g.epi != P5_EPI_STORE) {
+#pragma unroll
+          for (int i = 0; i < NPIECE; ++i) {
+            const int p = tid + i * NT;
+            const int row = m0 + p / PPR, col = n0 + (p % PPR) * 8;
+            auxr[i] = (row < g.M && col < g.N) ? ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col) : zero16();
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -287,8 +303,6 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
           }
         }
       __syncthreads();
-      constexpr int PPR = BN / 8;                 // 16-byte pieces per tile row
-      constexpr int NPIECE = BM * PPR / NT;
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i) {
         const int p = tid + i * NT;
@@ -301,7 +315,7 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
           unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
           if (g.epi != P5_EPI_STORE) {
             float av[8];
-            if (g.aux) unpack16<bf16>(ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
+            if (g.aux) unpack16<bf16>(PRE ? auxr[PRE ? i : 0] : ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], g.aux ? av[e] : 0.f, seed, do_drop, row, col + e);
           }
