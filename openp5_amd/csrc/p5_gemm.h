@@ -171,9 +171,12 @@ template <int R> __device__ static __forceinline__ int ksd_swz(int krow) {
   if constexpr (R >= 128) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
   else return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
 }
-// Needs K % 64 == 0 and nrows % 8 == 0; chunks past the matrix edge are clamped (they feed C rows/cols never stored).
+// Needs K % 64 == 0.  Chunks past the matrix edge feed C rows/cols that are never stored; they are clamped to the last whole
+// chunk of the k-row in MEMORY (ld, a multiple of 8), not of the matrix: a ragged row count (vocabulary 32100) still gets
+// its last partial chunk, and whatever lies between nrows and ld is readable padding.
 template <class T, int R>
 __device__ static __forceinline__ void stage_dma_ks(char* lds, const T* __restrict__ p, int ld, int r0, int k0, int nrows, int tid) {
+  (void)nrows;
   static_assert(sizeof(T) == 2, "direct-to-LDS staging is a bf16 path");
   constexpr int RB = R * 2, CPR = RB / 16, RPI = 1024 / RB, NI = 64 / RPI / 4;   // NI wave instructions per wave (4 waves)
   const int wave = tid >> 6, lane = tid & 63;
@@ -182,7 +185,7 @@ __device__ static __forceinline__ void stage_dma_ks(char* lds, const T* __restri
     const int q = wave * NI + i;
     const int krow = q * RPI + lane / CPR;
     int cg = (lane % CPR) ^ ksd_swz<R>(krow);
-    const int cmax = (nrows - r0) / 8 - 1;
+    const int cmax = (ld - r0) / 8 - 1;
     cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
     glds16(p + (size_t)(k0 + krow) * ld + r0 + cg * 8, lds + q * 1024);
   }
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
       constexpr int CPR = BM / 8, RPI = 512 / BM;
       const int krow = (wave * (BM / 32) + i) * RPI + lane / CPR;
       int cg = (lane % CPR) ^ ksd_swz<BM>(krow);
-      const int cmax = (g.M - m0) / 8 - 1;
+      const int cmax = (g.lda - m0) / 8 - 1;      // (row capacity of the k-row in memory, see stage_dma_ks)
       cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
       srcA[i] = (const T*)g.A + ((size_t)st_begin * 64 + krow) * g.lda + m0 + cg * 8;
     } else {
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
       constexpr int CPR = BN / 8, RPI = 512 / BN;
       const int krow = (wave * (BN / 32) + i) * RPI + lane / CPR;
       int cg = (lane % CPR) ^ ksd_swz<BN>(krow);
-      const int cmax = (g.N - n0) / 8 - 1;
+      const int cmax = (g.ldb - n0) / 8 - 1;
       cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
       srcB[i] = (const T*)g.B + ((size_t)st_begin * 64 + krow) * g.ldb + n0 + cg * 8;
     } else {

@@ -80,7 +80,7 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && BM == 128) {
     if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
-    if (mode == 3 && dma && (g.N % 8) == 0 && (g.M % 8) == 0 && (v2 >= 3 || g.ring)) {
+    if (mode == 3 && dma && (v2 >= 3 || g.ring)) {
       if (v2 == 3 || (v2 == 0 && g_opt_gemm_ring_stages == 3)) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
       else P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4, true, true>), grid, block, 0, s, g);
       return P5_KCHECK();
@@ -98,8 +98,8 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   }
   if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
   else if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false>), grid, block, 0, s, g);
-  else if (mode == 1 && dma && (g.N % 8) == 0 && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
-  else if (mode == 3 && dma && (g.N % 8) == 0 && (g.M % 8) == 0 && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
+  else if (mode == 1 && dma && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
+  else if (mode == 3 && dma && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
   else if (mode == 1 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, false>), grid, block, 0, s, g);
   else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, false, false>), grid, block, 0, s, g);
   else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, false, false>), grid, block, 0, s, g);
@@ -128,7 +128,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
   // below 48 tiles the 64x64 kernel still wins)
   if (sizeof(T) == 2 && !force_tile && g_opt_gemm_ring && g.a_ks && g.b_ks && g.epi == P5_EPI_ATOMIC && g.splitk <= 0 && t128 >= 48 &&
-      t128 <= 256 && g.K >= 2048 && (g.K % 64) == 0 && (g.M % 8) == 0 && (g.N % 8) == 0) {
+      t128 <= 256 && g.K >= 2048 && (g.K % 64) == 0) {
     g.ring = 1;
     big = true;
     int sk = (int)((g_opt_gemm_ring_wgs + t128 / 2) / t128);
@@ -137,7 +137,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   }
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
   if (sizeof(T) == 2 && !big && !force_tile && g_opt_gemm_small_ring && !g.ring && tiles <= 256 && g.K >= 256 && (g.K % 64) == 0 &&
-      (!g.b_ks || (g.N % 8) == 0) && (!g.a_ks || (g.M % 8) == 0) && (g.a_ks == 0 || g.b_ks == 1) &&
+      (g.a_ks == 0 || g.b_ks == 1) &&
       (g.epi != P5_EPI_ATOMIC || g.K <= 1024)) {
     g.ring = 1;                      // (long-K atomic problems keep the split-K path below)
     if (g.splitk <= 0) g.splitk = 1;
@@ -755,7 +755,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     {
       // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
       hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
-      P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dres_b, d, Md, d, c.vocab_size, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+      // (bf16: reduce over the padded vocabulary Vp = multiple of 64 so that both operands qualify for direct-to-LDS copies;
+      //  dlogits columns V..Vp are exact zeros and the rows "E[V..Vp)" are the finite first rows of the next tensor in the arena)
+      const int Kv = sizeof(T) == 2 ? e->Vp : c.vocab_size;
+      P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dres_b, d, Md, d, Kv, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
       const size_t n = (size_t)Md * d;
       P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
                 (const float*)e->dres_b, n, no_drop());
