@@ -263,7 +263,8 @@ def main():
                          "traffic": 75.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None, "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
                          "avg_launch_us": t_k * 1e6},
             "roofline_wgrad": {"bound": "mfma", "kernel": "p5_gemm2_kernel<128,128,ring4,KS,KS>", "shape": [Ng, Kg, Mg], "achieved": ach_w,
-                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS, "traffic": None,
+                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS,
+                               "traffic": 112.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None,   # PMC, profiles/r01_pmc_gemm.md
                                "algorithmic_bytes": 2.0 * (Mg * Kg + Mg * Ng) + 4.0 * Ng * Kg, "avg_launch_us": t_w * 1e6},
         }
         if not args.no_cpu and world == 1:
