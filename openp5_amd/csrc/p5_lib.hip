@@ -257,6 +257,7 @@ struct P5Engine {
   void *dy2[2] = {nullptr, nullptr}, *dh2[2] = {nullptr, nullptr}, *du2[2] = {nullptr, nullptr}, *dqkv2[2] = {nullptr, nullptr},
        *dkv2[2] = {nullptr, nullptr};
   void* dy_next = nullptr;
+  void *kv_all = nullptr, *dkv_all = nullptr;   // cross-attention K/V (and their gradients) of all decoder layers, [M, n_dec*2*inner]
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
   int norm_slot = 0;
   int sub = -1;
@@ -373,6 +374,15 @@ static void build_layout(P5Engine* e) {
   }
   add_param(e, "encoder.final_layer_norm.weight", 1, d, e->off_enc_fln);
   e->dec.resize(c.n_dec_layers);
+  // the cross-attention K/V projections of ALL decoder layers sit back to back ([n_dec * 2 * inner, d]): they all read the same
+  // encoder output, so forward, weight gradient and d(enc_out) are one GEMM each instead of one per layer.  The block lies
+  // between the encoder's final norm and the first decoder layer, i.e. inside the data-parallel bucket of the stage that
+  // follows the decoder (p5_backward_stage_range), which is when its gradient is complete.
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const std::string p = "decoder.block." + std::to_string(i) + ".layer.1.EncDecAttention";
+    add_param(e, p + ".k.weight", e->inner, d, e->dec[i].ca.k);     // inner*d is a multiple of 64: no padding in between
+    add_param(e, p + ".v.weight", e->inner, d, e->dec[i].ca.v);
+  }
   for (int i = 0; i < c.n_dec_layers; ++i) {
     LayerOff& l = e->dec[i];
     const std::string p = "decoder.block." + std::to_string(i);
@@ -380,7 +390,8 @@ static void build_layout(P5Engine* e) {
     l.begin = e->n_params;
     add_attn(e, p + ".layer.0.SelfAttention", l.sa);
     add_param(e, p + ".layer.0.layer_norm.weight", 1, d, l.sa.ln);
-    add_attn(e, p + ".layer.1.EncDecAttention", l.ca);
+    add_param(e, p + ".layer.1.EncDecAttention.q.weight", e->inner, d, l.ca.q);
+    add_param(e, p + ".layer.1.EncDecAttention.o.weight", d, e->inner, l.ca.o);
     add_param(e, p + ".layer.1.layer_norm.weight", 1, d, l.ca.ln);
     add_ff(p + ".layer.2", l);
     add_param(e, p + ".layer.2.layer_norm.weight", 1, d, l.ff_ln);
@@ -519,7 +530,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
       l.qkv = b.take(Md * 3 * in * sz); l.o_sa = b.take(Md * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * T * 4);
       l.x_ca = b.take(Md * d * sz);
       l.n_ca = b.take(Md * d * sz); l.rstd_ca = (float*)b.take(Md * 4);
-      l.q_ca = b.take(Md * in * sz); l.kv_ca = b.take(M * 2 * in * sz); l.o_ca = b.take(Md * in * sz);
+      l.q_ca = b.take(Md * in * sz); l.o_ca = b.take(Md * in * sz);
       l.lse_ca = (float*)b.take((size_t)B * H * T * 4);
       l.x_ff = b.take(Md * d * sz);
       l.n_ff = b.take(Md * d * sz); l.rstd_ff = (float*)b.take(Md * 4);
@@ -528,6 +539,9 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
       xprev = b.take(Md * d * sz);
     }
     e->dec_xf = xprev;
+    // cross-attention K/V of all layers: [M, n_dec * 2 * inner]; layer i owns columns [i * 2 * inner, (i + 1) * 2 * inner)
+    e->kv_all = b.take(M * (size_t)c.n_dec_layers * 2 * in * sz);
+    for (size_t i = 0; i < e->ds.size(); ++i) e->ds[i].kv_ca = e->kv_all ? (char*)e->kv_all + i * 2 * in * sz : nullptr;
     e->dec_rstd_f = (float*)b.take(Md * 4);
     e->dec_hn = b.take(Md * d * sz);
     e->logits = (float*)b.take(Md * Vp * 4);
@@ -546,11 +560,12 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     for (int p = 0; p < 2; ++p) {
       e->dy2[p] = b.take(Mx * d * sz);
       e->dqkv2[p] = b.take(Mx * 3 * in * sz);
-      e->dkv2[p] = b.take(M * 2 * in * sz);
+      e->dkv2[p] = nullptr;
       e->dh2[p] = b.take(Mx * F * sz);
       e->du2[p] = c.gated_gelu ? b.take(Mx * 2 * F * sz) : nullptr;
     }
     e->dy = e->dy2[0]; e->dqkv = e->dqkv2[0]; e->dkv = e->dkv2[0]; e->dh = e->dh2[0]; e->du = e->du2[0];
+    e->dkv_all = T > 0 ? b.take(M * (size_t)c.n_dec_layers * 2 * in * sz) : nullptr;     // d(K/V) of all layers, same column layout
     e->dlogits = b.take(Md * Vp * sz);
   }
   return (int64_t)((b.off + 255) & ~(size_t)255);
@@ -604,12 +619,20 @@ template <class T>
 static int decoder_fwd(P5Engine* e, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
-  if (e->side) {
-    fork_to_side(e, s);      // enc_out is ready
-    for (int i = 0; i < c.n_dec_layers; ++i) {
-      P5_TRY(linear_fwd<T>(e->side, e->enc_out, d, Wc<T>(e, e->dec[i].ca.k), e->ds[i].kv_ca, 2 * in, M, 2 * in, d));
+  const int nd_ = c.n_dec_layers, ldkv = nd_ * 2 * in;
+  {
+    // K/V projections of the encoder output for every layer: layer 0 on its own (the decoder needs it first), the rest as
+    // ONE GEMM over the contiguous weight block; on the side stream when there is one (they only depend on enc_out)
+    hipStream_t ks = e->side ? e->side : s;
+    if (e->side) fork_to_side(e, s);      // enc_out is ready
+    P5_TRY(linear_fwd<T>(ks, e->enc_out, d, Wc<T>(e, e->dec[0].ca.k), e->ds[0].kv_ca, ldkv, M, 2 * in, d));
 #ifndef P5_EMU
-      hipEventRecord(e->kv_ev[i], e->side);
+    if (e->side) hipEventRecord(e->kv_ev[0], e->side);
+#endif
+    if (nd_ > 1) {
+      P5_TRY(linear_fwd<T>(ks, e->enc_out, d, Wc<T>(e, e->dec[1].ca.k), e->ds[1].kv_ca, ldkv, M, (nd_ - 1) * 2 * in, d));
+#ifndef P5_EMU
+      if (e->side) hipEventRecord(e->kv_ev[1], e->side);
 #endif
     }
   }
@@ -636,14 +659,13 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
     // cross attention (zero position bias + encoder padding mask)
     P5_TRY(rmsnorm_fwd<T>(s, l.n_ca, l.rstd_ca, l.x_ca, e->P + lo.ca.ln, Md, d, c.eps, no_drop()));
     P5_TRY(linear_fwd<T>(s, l.n_ca, d, Wc<T>(e, lo.ca.q), l.q_ca, in, Md, in, d));
-    if (!e->side) P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, lo.ca.k), l.kv_ca, 2 * in, M, 2 * in, d));
 #ifndef P5_EMU
-    else hipStreamWaitEvent(s, e->kv_ev[i], 0);      // layer i's K/V projection was issued on the side stream up front
+    if (e->side && (i == 0 || (i == 1 && nd_ > 1))) hipStreamWaitEvent(s, e->kv_ev[i], 0);   // K/V projections were issued on the side stream up front
 #endif
     memset(&a, 0, sizeof(a));
     a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca;
     a.rel_table = nullptr; a.bucket_lut = nullptr; a.kmask = e->mask;
-    a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = 2 * in; a.ldo = in; a.causal = 0;
+    a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = ldkv; a.ldo = in; a.causal = 0;
     a.drop = mk_drop(e, 1, i, 3);
     P5_TRY(launch_attn_fwd<T>(a, s));
     P5_TRY(linear_fwd<T>(s, l.o_ca, in, Wc<T>(e, lo.ca.o), l.x_ff, d, Md, d, in, P5_EPI_RESID_DROP, l.x_ca, d, 1.f, 0, mk_drop(e, 1, i, 4)));
@@ -782,18 +804,14 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca; a.dO = e->dO;
-    a.dQ = e->dqkv; a.dK = e->dkv; a.dV = (T*)e->dkv + in; a.Dvec = e->Dvec;
-    a.kmask = e->mask; a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = 2 * in; a.ldo = in; a.lddo = in;
-    a.lddq = in; a.lddk = a.lddv = 2 * in; a.causal = 0; a.drop = mk_drop(e, 1, i, 3);
+    const int ldkv = nd * 2 * in;
+    T* dkv_i = (T*)e->dkv_all + (size_t)i * 2 * in;      // this layer's columns of d(K/V); consumed once, after the last layer
+    a.dQ = e->dqkv; a.dK = dkv_i; a.dV = dkv_i + in; a.Dvec = e->Dvec;
+    a.kmask = e->mask; a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = ldkv; a.ldo = in; a.lddo = in;
+    a.lddq = in; a.lddk = a.lddv = ldkv; a.causal = 0; a.drop = mk_drop(e, 1, i, 3);
     P5_TRY(launch_attn_bwd<T>(a, s));
     P5_TRY(linear_wgrad<T>(e, s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
     P5_TRY(linear_dgrad<T>(s, e->dqkv, in, Wc<T>(e, lo.ca.q), e->dn, d, Md, in, d));
-    P5_TRY(linear_wgrad<T>(e, s, e->dkv, 2 * in, e->enc_out, d, e->G + lo.ca.k, M, 2 * in, d));
-    // d(enc_out) += dKV Wkv is only consumed by the encoder backward: keep it off the decoder's dependent chain
-    // (side-stream launches are ordered among themselves, so the accumulation across layers is race-free)
-    P5_TRY(linear_dgrad<T>(e->side ? e->side : s, e->dkv, 2 * in, Wc<T>(e, lo.ca.k), e->d_enc, d, M, 2 * in, d,
-                           e->d_enc_started ? P5_EPI_ACCUM : P5_EPI_STORE, nullptr, 0, 1.f, 1));
-    e->d_enc_started = true;
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
     // self attention
     begin_sublayer(e);
@@ -802,6 +820,14 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     return 0;
   }
   if (stage == nd + 1) {
+    {
+      // every layer's d(K/V) is in place: ONE weight-gradient GEMM for the contiguous K/V block and ONE dgrad for d(enc_out)
+      // (K = n_dec * 2 * inner), both off the critical path on the side stream; the encoder backward joins it (stage nd + 2)
+      const int ldkv = nd * 2 * in;
+      P5_TRY(linear_wgrad<T>(e, s, e->dkv_all, ldkv, e->enc_out, d, e->G + e->dec[0].ca.k, M, ldkv, d));
+      P5_TRY(linear_dgrad<T>(e->side ? e->side : s, e->dkv_all, ldkv, Wc<T>(e, e->dec[0].ca.k), e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
+                             nullptr, 0, 1.f, 1));
+    }
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
               (const float*)(e->rel_partial + (size_t)REL_COPIES * c.rel_buckets * H), c.rel_buckets * H, REL_COPIES);
     P5_TRY(P5_KCHECK());
