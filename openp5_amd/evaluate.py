@@ -88,3 +88,29 @@ def get_metrics_results_ids(rel, metrics):
         elif name.startswith("ndcg"):
             out.append((relf[:, :k] * disc[:k]).sum())
     return torch.stack(out)
+
+
+def rel_results_filtered_ids(sequences, scores, gold_ids, positive_idx, seq2idx, k):
+    """ID form of `rel_results_filtered` (DistributedRunner.py:238-262): the `width` hypotheses of every user, ranked by score
+    (stable), minus those that are items of the user's history, cut to k; relevance = same item as the gold one.
+    sequences [B, width, S] / gold_ids [B, T] are integer arrays (numpy), column 0 of `sequences` is the decoder start;
+    seq2idx maps an item's token tuple (ending with </s>) to its index, positive_idx[b] is a set of such indices."""
+    def key(row):
+        n = len(row)
+        while n > 0 and row[n - 1] == 0:
+            n -= 1
+        return tuple(int(t) for t in row[:n])
+    out = []
+    for b in range(len(gold_ids)):
+        gold = seq2idx.get(key(gold_ids[b]), -2)
+        order = sorted(range(len(scores[b])), key=lambda r: -float(scores[b][r]))      # stable, like sorted() in the reference
+        row = []
+        for r in order:
+            idx = seq2idx.get(key(sequences[b][r][1:]), -1)
+            if idx in positive_idx[b]:
+                continue
+            row.append(1 if idx == gold else 0)
+            if len(row) >= k:
+                break
+        out.append(row)
+    return out

@@ -356,14 +356,32 @@ class DistributedRunner:
     def test_dataset_task_filtered_batch(self, testloader):
         """DistributedRunner.py:204-269: widen the beam by max_positive, filter the history afterwards."""
         ds = testloader.dataset
-        fn = prefix_allowed_tokens_fn(Trie(self._item_sequences(ds, set(ds.all_items))))
+        trie, ct, index = self._dataset_trie(ds)
+        fn = prefix_allowed_tokens_fn(trie)
         width = self.generate_num + ds.max_positive
+        seq2idx = None
+        if self.id_metrics:     # item token tuple (without the decoder start) -> item index: no batch_decode, no string sets
+            seq2idx = self.__dict__.setdefault("_seq2idx_cache", {}).get(ds.dataset)
+            if seq2idx is None:
+                items = list(ds.all_items)
+                seq2idx = {tuple(q[1:]): i for i, q in enumerate(self._item_sequences(ds, items))}
+                self._seq2idx_cache[ds.dataset] = seq2idx
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
         for batch in testloader:
             batch = self._to_dev(batch)
-            gold, gen, scores = self._generate(batch, fn, width, 30)
-            rel = evaluate.rel_results_filtered(ds.positive_text, ds.id2user, batch[5].detach().cpu().numpy(), width, gen, gold, scores,
-                                                self.generate_num)
+            if self.id_metrics:
+                pred = self.model.generate(input_ids=batch[0], attention_mask=batch[1], whole_word_ids=batch[2], max_length=30, trie=ct,
+                                           num_beams=width, num_return_sequences=width, output_scores=True, return_dict_in_generate=True)
+                B = batch[0].shape[0]
+                seqs = pred["sequences"].detach().cpu().numpy().reshape(B, width, -1)
+                sc = pred["sequences_scores"].detach().cpu().numpy().reshape(B, width)
+                users = [ds.id2user[int(u)] for u in batch[5].detach().cpu().tolist()]
+                pos = [{index[i] for i in ds.positive[u] if i in index} for u in users]
+                rel = evaluate.rel_results_filtered_ids(seqs, sc, batch[3].detach().cpu().numpy(), pos, seq2idx, self.generate_num)
+            else:
+                gold, gen, scores = self._generate(batch, fn, width, 30)
+                rel = evaluate.rel_results_filtered(ds.positive_text, ds.id2user, batch[5].detach().cpu().numpy(), width, gen, gold, scores,
+                                                    self.generate_num)
             test_total += len(rel)
             metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
         return self._finish(metrics_res, test_total, testloader, t0)

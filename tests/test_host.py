@@ -299,3 +299,34 @@ def test_collator_solo_rows_equals_batch_of_one():
         n = one[0].shape[1]
         assert torch.equal(batched[0][i, :n], one[0][0]) and torch.equal(batched[2][i, :n], one[2][0])
         assert int(batched[2][i, n:].sum()) == 0 and int(batched[1][i].sum()) == n
+
+
+def test_filtered_id_metrics_match_string_metrics():
+    import numpy as np
+    from openp5_amd import evaluate
+    rnd = random.Random(3)
+    items = [[5, 6, 10 + i, 1] for i in range(12)]                       # token sequences "... </s>"
+    text = {i: f"Toy item_{i}" for i in range(12)}
+    seq2idx = {tuple(q): i for i, q in enumerate(items)}
+    B, width, k, S = 5, 7, 3, 7
+    seqs = np.zeros((B, width, S), dtype=np.int64)
+    scores = np.zeros((B, width))
+    gold_ids = np.zeros((B, 5), dtype=np.int64)
+    gen_txt, gold_txt, positive_txt, positive_idx, id2user, user_idx = [], [], {}, [], {}, []
+    for b in range(B):
+        pick = rnd.sample(range(12), width)
+        for r, it in enumerate(pick):
+            seqs[b, r, 1:1 + len(items[it])] = items[it]
+            gen_txt.append(text[it])
+        scores[b] = [rnd.choice([-1.0, -2.0, -3.0]) for _ in range(width)]            # ties included
+        pos = set(rnd.sample(range(12), 4))
+        gold = rnd.choice([i for i in range(12) if i not in pos])
+        gold_ids[b, :len(items[gold])] = items[gold]
+        gold_txt.append(text[gold])
+        id2user[b] = f"U{b}"
+        user_idx.append(b)
+        positive_txt[f"U{b}"] = {text[i] for i in pos}
+        positive_idx.append(pos)
+    a = evaluate.rel_results_filtered_ids(seqs, scores, gold_ids, positive_idx, seq2idx, k)
+    ref = evaluate.rel_results_filtered(positive_txt, id2user, user_idx, width, gen_txt, gold_txt, scores.reshape(-1).tolist(), k)
+    assert a == ref and any(sum(r) for r in a)

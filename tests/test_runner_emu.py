@@ -81,6 +81,15 @@ def test_id_metrics_equal_string_metrics(emu, tmp_path):
     assert a == b
 
 
+def test_filtered_batch_id_metrics_equal_string_metrics(emu, tmp_path):
+    """--test_filtered 1 --test_filtered_batch 1 (widened beam, history filtered afterwards): item-index form == string form."""
+    tok = build_offline_tokenizer(VOCAB)
+    flags = ["--test_filtered", "1", "--test_filtered_batch", "1", "--eval_batch_size", "6"]
+    a = _eval_runner(emu, tmp_path, tok, flags + ["--id_metrics", "1"]).test()
+    b = _eval_runner(emu, tmp_path, tok, flags + ["--id_metrics", "0"]).test()
+    assert a == b and any(v > 0 for r in a for v in r.values())
+
+
 def test_filtered_protocol_matches_per_user_tries(emu, tmp_path):
     """--test_filtered 1 --test_filtered_batch 0: shared trie + per-user bitmap, at batch size 5, against the reference
     protocol restated literally: batch size 1, a fresh Trie(all_items - positive) per user, string metrics."""
