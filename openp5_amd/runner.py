@@ -359,6 +359,10 @@ class DistributedRunner:
         trie, ct, index = self._dataset_trie(ds)
         fn = prefix_allowed_tokens_fn(trie)
         width = self.generate_num + ds.max_positive
+        if width > 64:
+            raise ValueError(f"--test_filtered_batch 1 needs num_beams = {self.generate_num} + max history {ds.max_positive} = {width} > 64 "
+                             "(the device beam search keeps <= 64 beams per user); use --test_filtered_batch 0, which excludes each "
+                             "user's history inside the constrained search and works at any batch size")
         seq2idx = None
         if self.id_metrics:     # item token tuple (without the decoder start) -> item index: no batch_decode, no string sets
             seq2idx = self.__dict__.setdefault("_seq2idx_cache", {}).get(ds.dataset)
