@@ -313,7 +313,7 @@ class DistributedRunner:
         trie, ct, _ = self._dataset_trie(ds)
         fn = prefix_allowed_tokens_fn(trie)
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
-        for batch in testloader:
+        for batch in Prefetcher(testloader, pin=self.device.type == "cuda"):      # collation overlaps the previous generate()
             batch = self._to_dev(batch)
             if self.id_metrics:
                 rel = self._generate_ids(batch, self.generate_num, 50, trie=ct)
@@ -331,7 +331,7 @@ class DistributedRunner:
         ds = testloader.dataset
         _, ct, index = self._dataset_trie(ds)
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
-        for batch in testloader:
+        for batch in Prefetcher(testloader, pin=self.device.type == "cuda"):      # collation overlaps the previous generate()
             batch = self._to_dev(batch)
             # the reference rebuilds Trie(all_items - positive) per user (hence its eval_batch_size == 1); here the shared
             # device trie is used with one excluded-node bitmap per user, so any batch size works
@@ -371,7 +371,7 @@ class DistributedRunner:
                 seq2idx = {tuple(q[1:]): i for i, q in enumerate(self._item_sequences(ds, items))}
                 self._seq2idx_cache[ds.dataset] = seq2idx
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
-        for batch in testloader:
+        for batch in Prefetcher(testloader, pin=self.device.type == "cuda"):      # collation overlaps the previous generate()
             batch = self._to_dev(batch)
             if self.id_metrics:
                 pred = self.model.generate(input_ids=batch[0], attention_mask=batch[1], whole_word_ids=batch[2], max_length=30, trie=ct,
