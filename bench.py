@@ -6,13 +6,22 @@ dropout 0.1, V=32100), one process per GPU.
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = forward + runner masked loss + backward (+ gradient all-reduce overlapped with it when N > 1) + global-norm
-clip + AdamW + schedule + zero_grad, i.e. DistributedRunner.py:56-93 minus the Python collator (inputs are resident
-in HBM before the timed region).  Prints ONE JSON line on rank 0.
+A "step" = forward + runner masked-mean loss + backward (+ gradient all-reduce overlapped with it when N > 1) +
+global-norm clip + AdamW + schedule + zero_grad, i.e. DistributedRunner.py:56-93 minus the Python collator (inputs are
+resident in HBM before the timed region).  Prints ONE JSON line on rank 0.
+
+Besides the headline (C2) the line carries, at N = 1 only (`--legs none` drops them):
+  * `roofline` (dominant kernel of the step by time, profiles/README.md), `roofline_fwd`, `roofline_generation`;
+    `traffic` fields are read from profiles/pmc_traffic.json (written by profiles/collect_pmc.sh on the GPU box; null if
+    that file has no entry for the kernel + shape);
+  * `cpu_baseline` (training, oracle port) and `cpu_baseline_generation` (oracle beam search), bounded samples;
+  * `legs`: single-GPU measurements of the other BASELINE.json configs -- C3 per-GPU (T5-base, B=64), C4 (T5-base,
+    beam 20, 20 users, V=32600), C5 per-GPU (T5-large, L=512) -- and `task_mix`, the real alternation of sequential
+    (L~130) and straightforward (L~16) batches through datasets + sampler + collator + prefetch thread
+    (SingleMultiDataTaskSampler.py:55-71).
 """
 import argparse
 import json
-import math
 import os
 import random
 import sys
@@ -27,6 +36,12 @@ V = 32100
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
+DIMS = {  # d_model, d_ff, heads, layers
+    "t5-small": (512, 2048, 8, 6),
+    "t5-base": (768, 3072, 12, 12),
+    "t5-large": (1024, 4096, 16, 24),
+}
+
 
 def train_flops_per_sample(d, inner, F, H, NL, L, T, Vv, dk=64):
     """algorithmic FLOPs of one training sample (fwd x3), padding tokens counted."""
@@ -36,16 +51,26 @@ def train_flops_per_sample(d, inner, F, H, NL, L, T, Vv, dk=64):
     return 3.0 * (enc + dec + head)
 
 
-def synth_batch(B, L, T, device, seed):
+def gen_bytes_per_step(d, inner, F, NL, Vv, B, K, L, t, sz=2):
+    """HBM bytes one decode step must move at least (weights once + shared cross-KV + self-KV so far)."""
+    return NL * (6 * d * inner + 2 * d * F) * sz + d * Vv * sz + B * NL * 2 * L * inner * sz + B * K * NL * 2 * t * inner * sz
+
+
+def gen_flops_per_user(d, inner, F, H, NL, L, K, S, Vv, dk=64):
+    enc = NL * L * 2 * (4 * d * inner + 2 * d * F) + NL * H * 4 * L * L * dk
+    return enc + NL * L * 2 * (2 * d * inner) + S * K * (NL * 2 * (6 * d * inner + 2 * d * F) + 2 * d * Vv)
+
+
+def synth_batch(B, L, T, device, seed, vocab=V):
     g = torch.Generator().manual_seed(seed)
-    ids = torch.randint(3, V, (B, L), generator=g)
+    ids = torch.randint(3, vocab, (B, L), generator=g)
     lens = torch.randint(int(0.7 * L), L + 1, (B,), generator=g)
     lens[0] = L
     mask = (torch.arange(L)[None, :] < lens[:, None]).long()
     ids = ids * mask
     ww = torch.cumsum((torch.rand(B, L, generator=g) < 0.35).long(), 1) * mask
     ww = ww.clamp(max=511)
-    labels = torch.randint(3, V, (B, T), generator=g)
+    labels = torch.randint(3, vocab, (B, T), generator=g)
     tl = torch.randint(max(2, T - 2), T + 1, (B,), generator=g)
     out_attn = (torch.arange(T)[None, :] < tl[:, None]).long()
     labels = labels * out_attn
@@ -53,27 +78,89 @@ def synth_batch(B, L, T, device, seed):
     return [t.to(device) for t in (ids, ww, mask, labels, out_attn)]
 
 
-def synth_item_trie(n_items, seed):
+def synth_item_trie(n_items, seed, lo=3000, hi=3999, pieces=(2, 2, 3)):
     """ML1M-like item ids: "<dataset> item_ <digits>" -> shared 4-piece prefix + 2-3 number pieces + </s>."""
     from openp5_amd.trie import Trie
     rnd = random.Random(seed)
     items = set()
     while len(items) < n_items:
-        n = rnd.choice((2, 2, 3))
-        items.add(tuple([0, 2000, 2001, 2002, 2003] + [rnd.randint(3000, 3999) for _ in range(n)] + [1]))
+        n = rnd.choice(pieces)
+        items.add(tuple([0, 2000, 2001, 2002, 2003] + [rnd.randint(lo, hi) for _ in range(n)] + [1]))
     return Trie(sorted(items))
 
 
-def runner_loss(nll, out_attn):
-    B, T = out_attn.shape
-    m = (out_attn != 0).float()
-    loss = nll.view(B, T) * m
-    return (loss.sum(dim=1) / m.sum(dim=1).clamp(min=1)).mean()
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def barrier(world):
+    if world > 1:
+        _dist().barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(dt, world, device):
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def build_model(backbone, dtype, device, be, world, rank, vocab=V, dropout=0.1, total_steps=1000):
+    from openp5_amd.model import P5ModelConfig, P5T5Native
+    from openp5_amd.optim import FusedAdamW
+    cfg = P5ModelConfig.from_backbone(backbone, vocab_size=vocab, dropout_rate=dropout)
+    model = P5T5Native(cfg, dtype=dtype, device=device, backend=be, seed=2023)
+    model.ddp_world = world
+    opt = FusedAdamW(model, lr=1e-3, eps=1e-6, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=int(0.05 * total_steps), total_steps=total_steps)
+    model.set_dropout_seed(2023 + rank, 0)
+    return cfg, model, opt
+
+
+def train_step(model, opt, batch):
+    """One runner step (openp5_amd/runner.py train loop body == DistributedRunner.py:56-93 without barriers)."""
+    from openp5_amd.runner import training_step
+    return training_step(model, opt, batch, alpha=2)
+
+
+def time_training(model, opt, batch, steps, warmup, world, device):
+    model.train()
+    last = None
+    for _ in range(warmup):
+        train_step(model, opt, batch)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = train_step(model, opt, batch)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    return dt, float(last.detach())
+
+
+def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, seed, vocab=V):
+    from openp5_amd.trie import prefix_allowed_tokens_fn
+    model.eval()
+    fn = prefix_allowed_tokens_fn(trie)
+    gids, gww, gmask, _, _ = synth_batch(gB, L, 8, device, seed, vocab)
+    kw = dict(input_ids=gids, attention_mask=gmask, whole_word_ids=gww, max_length=max_length, prefix_allowed_tokens_fn=fn,
+              num_beams=gK, num_return_sequences=gK, output_scores=True, return_dict_in_generate=True)
+    for _ in range(2):
+        o = model.generate(**kw)
+    barrier(world)
+    g0 = time.perf_counter()
+    for _ in range(batches):
+        o = model.generate(**kw)
+    barrier(world)
+    gdt = max_over_ranks(time.perf_counter() - g0, world, device)
+    timing = model.last_generate_timing() if hasattr(model, "last_generate_timing") else None
+    return gdt, int(o["sequences"].shape[1]), timing
 
 
 def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
     """average duration of a GEMM kernel measured with HIP events on the stream the kernel is launched on.
-    wgrad=False: forward bf16 GEMM y = x W^T (both operands K-contiguous, 128x128 tile);
+    wgrad=False: forward bf16 GEMM y = x W^T (both operands K-contiguous);
     wgrad=True : weight gradient dW[M,N] += dy^T x over K tokens (both operands K-strided, ring kernel, split-K atomics)."""
     import ctypes
     P = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
@@ -99,7 +186,22 @@ def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def cpu_baseline(seconds_budget=20.0):
+def pmc_traffic(kernel, shape):
+    """HBM bytes per launch of `kernel` at `shape` from profiles/pmc_traffic.json (profiles/collect_pmc.sh: separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- None when not collected."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        ent = tab.get(f"{kernel}|{'x'.join(str(int(s)) for s in shape)}")
+        return float(ent["traffic_bytes"]) if ent else None
+    except Exception:
+        return None
+
+
+def cpu_baseline_train(seconds_budget=15.0):
     """The CPU path timed on this box's host cores: the oracle restatement of the reference step (HF-equivalent
     fp32 T5-small, B=4, L=128, T=8: BASELINE.json configs[0]) -- forward + backward + clip + HF-AdamW."""
     from oracle import t5_oracle as O
@@ -132,6 +234,119 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{len(times)} train steps of oracle/t5_oracle.py (fp32 T5-small, B=4, L=128, T=8), median of all but the first"}
 
 
+def cpu_baseline_generation(seconds_budget=15.0):
+    """items/s of the CPU path: the oracle's restatement of HF beam search + per-row Python trie callbacks
+    (DistributedRunner.py:361-371 semantics) on the host cores: 4 users x beam 10 over the same 3416-item trie."""
+    from oracle import t5_oracle as O
+    ncores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(ncores)
+    cfg = O.T5Cfg.named("t5-small", dropout=0.0)
+    P = O.init_params(cfg, 2023)
+    trie = synth_item_trie(3416, 7)
+    ids, ww, mask, _, _ = synth_batch(4, 128, 8, "cpu", 500)
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        while True:
+            t0 = time.time()
+            O.beam_search(P, cfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), 10, 30)
+            times.append(time.time() - t0)
+            if (time.time() - t_start > seconds_budget and len(times) >= 2) or len(times) >= 6 or time.time() - t_start > 3 * seconds_budget:
+                break
+    rest = times[1:] if len(times) > 1 else times
+    med = sorted(rest)[len(rest) // 2]
+    return {"value": 4 * 10 / med, "unit": "items/s", "cores": ncores, "kind": "port",
+            "sample": f"{len(times)} calls of oracle beam_search (fp32 T5-small, 4 users x beam 10, L=128, 3416-item trie, max_length 30), "
+                      "median of all but the first"}
+
+
+def task_mix_leg(be, device, steps=60, warmup=10):
+    """The real task mix: ML1M-style prompts (max_his 20) from a synthetic 400-user dataset through MultiTaskDataset ->
+    SingleMultiDataTaskSampler (alternating sequential / straightforward batches of 64) -> Collator in the prefetch thread ->
+    pinned H2D -> training step.  Collation is INSIDE the timed region here."""
+    import tempfile
+    from torch.utils.data import ConcatDataset, DataLoader
+    from openp5_amd.collator import Collator
+    from openp5_amd.data import MultiTaskDataset
+    from openp5_amd.runner import Prefetcher, build_arg_parser
+    from openp5_amd.sampler import SingleMultiDataTaskSampler
+    from openp5_amd.synth import write_dataset, write_prompt_file
+    from openp5_amd.tokenizer import build_offline_tokenizer
+    tmp = tempfile.mkdtemp(prefix="p5bench_")
+    write_dataset(os.path.join(tmp, "data"), "ML1M", n_users=400, n_items=3416, n_inter=400 * 60)
+    prompt = write_prompt_file(os.path.join(tmp, "prompt.txt"))
+    args = build_arg_parser().parse_args(["--data_path", os.path.join(tmp, "data"), "--datasets", "ML1M", "--tasks", "sequential,straightforward",
+                                          "--item_indexing", "sequential", "--prompt_file", prompt, "--sample_prompt", "1", "--sample_num", "1,1",
+                                          "--max_his", "20", "--distributed", "0", "--batch_size", "64"])
+    args.rank = 0
+    random.seed(0)
+    tok = build_offline_tokenizer()
+    train = ConcatDataset([MultiTaskDataset(args, "ML1M", "train")])
+    loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, 64, args.seed), batch_size=64, collate_fn=Collator(tok))
+    _, model, opt = build_model("t5-small", "bf16", device, be, 1, 0)
+    model.train()
+    n, lens, t0 = 0, [], None
+    for i, b in enumerate(Prefetcher(loader, pin=True)):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if i >= warmup + steps:
+            break
+        b = [t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in b]
+        train_step(model, opt, (b[0], b[2], b[1], b[3], b[4]))
+        if i >= warmup:
+            n += b[0].shape[0]
+            lens.append(int(b[0].shape[1]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_s": n / dt, "ms_per_step": dt / max(1, len(lens)) * 1e3, "steps": len(lens), "batch": 64,
+            "L_sequential_mean": sum(x for x in lens if x > 40) / max(1, sum(1 for x in lens if x > 40)),
+            "L_straightforward_mean": sum(x for x in lens if x <= 40) / max(1, sum(1 for x in lens if x <= 40)),
+            "note": "collator + H2D inside the timed region; alternating sequential/straightforward batches (SingleMultiDataTaskSampler.py:55-71)"}
+
+
+def config_legs(be, device, dtype):
+    """Single-GPU measurements of BASELINE.json configs[2..4]."""
+    legs = {}
+    # C3 per GPU: T5-base, B=64, L=128, T=8
+    for key, backbone, B, L, T, steps, warm in (("c3_t5base_b64_per_gpu", "t5-base", 64, 128, 8, 8, 3),
+                                                ("c5_t5large_b64_l512_per_gpu", "t5-large", 64, 512, 10, 4, 2)):
+        try:
+            cfg, model, opt = build_model(backbone, dtype, device, be, 1, 0)
+            batch = synth_batch(B, L, T, device, 100)
+            dt, loss = time_training(model, opt, batch, steps, warm, 1, device)
+            d, F, H, NL = DIMS[backbone]
+            fl = train_flops_per_sample(d, H * 64, F, H, NL, L, T, V)
+            sps = B * steps / dt
+            legs[key] = {"samples_per_s": sps, "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B, "seq_len": L, "tgt_len": T,
+                         "model_tflops": sps * fl / 1e12, "frac_of_bf16_peak": sps * fl / 1e12 / BF16_PEAK_TFLOPS, "final_loss": loss}
+            if backbone == "t5-base":
+                # C4: Beauty collaborative indexing, T5-base, beam 20, eval batch 20, vocabulary grown by 500 <CIk> tokens
+                pass
+            del model, opt
+            torch.cuda.empty_cache()
+        except Exception as ex:      # a leg must never take the headline down
+            legs[key] = {"error": repr(ex)[:300]}
+    try:
+        Vc = V + 500
+        cfg, model, _ = build_model("t5-base", dtype, device, be, 1, 0, vocab=Vc)
+        trie = synth_item_trie(12101, 11, lo=V, hi=Vc - 1, pieces=(2, 3, 3, 4))       # Beauty: 12,101 items, <CIk> token paths
+        gB, gK, L = 20, 20, 128
+        gdt, dec_len, timing = time_generation(model, gB, gK, L, trie, 30, 5, 1, device, 700, vocab=Vc)
+        d, F, H, NL = DIMS["t5-base"]
+        S = dec_len - 1
+        ms = gdt / 5 * 1e3
+        legs["c4_t5base_beam20_b20"] = {"items_per_s": gB * gK * 5 / gdt, "ms_per_batch": ms, "users_per_batch": gB, "num_beams": gK, "vocab": Vc,
+                                        "trie_items": 12101, "decoded_len": dec_len, "timing_ms": timing,
+                                        "hbm_bytes_per_step_min": gen_bytes_per_step(d, H * 64, F, NL, Vc, gB, gK, L, S // 2 + 1),
+                                        "gflop_per_batch": gB * gen_flops_per_user(d, H * 64, F, H, NL, L, gK, S, Vc) / 1e9}
+        del model
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        legs["c4_t5base_beam20_b20"] = {"error": repr(ex)[:300]}
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +359,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-gen", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--legs", default="all", help="all | none | comma list of: configs,task_mix")
     ap.add_argument("--gen-batches", type=int, default=10)
     args = ap.parse_args()
 
@@ -153,93 +369,35 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        _dist().init_process_group("nccl", device_id=device)
 
     from openp5_amd._lib import hip_backend
-    from openp5_amd.model import P5ModelConfig, P5T5Native
-    from openp5_amd.optim import FusedAdamW
-    from openp5_amd.trie import prefix_allowed_tokens_fn
-
     be = hip_backend(device)
-    cfg = P5ModelConfig.from_backbone(args.backbone, vocab_size=V, dropout_rate=0.1)
-    model = P5T5Native(cfg, dtype=args.dtype, device=device, backend=be, seed=2023)
-    model.ddp_world = world
     B, L, T = args.batch, args.seq_len, args.tgt_len
-    total_steps = max(1000, args.steps + args.warmup)
-    opt = FusedAdamW(model, lr=1e-3, eps=1e-6, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=int(0.05 * total_steps), total_steps=total_steps)
+    cfg, model, opt = build_model(args.backbone, args.dtype, device, be, world, rank, total_steps=max(1000, args.steps + args.warmup))
     batch = synth_batch(B, L, T, device, 100 + rank)
-    ids, ww, mask, labels, out_attn = batch
-    model.train()
-    model.set_dropout_seed(2023 + rank, 0)
-
-    def step():
-        out = model(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels, alpha=2, return_dict=True)
-        loss = runner_loss(out["loss"], out_attn)
-        loss.backward()
-        opt.step()
-        model.zero_grad()
-        return loss
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, final_loss = time_training(model, opt, batch, args.steps, args.warmup, world, device)
     samples_per_s = world * B * args.steps / dt
-    final_loss = float(last)
 
     # ---- beam-10 constrained generation: items/s (B=20 users/GPU, K=10, ML1M-sized trie of 3416 items) ----
     gen = None
     if not args.no_gen:
-        model.eval()
-        trie = synth_item_trie(3416, 7)
-        fn = prefix_allowed_tokens_fn(trie)
         gB, gK = 20, 10
-        gids, gww, gmask, _, _ = synth_batch(gB, L, T, device, 500 + rank)
-        for _ in range(2):
-            model.generate(input_ids=gids, attention_mask=gmask, whole_word_ids=gww, max_length=30, prefix_allowed_tokens_fn=fn,
-                           num_beams=gK, num_return_sequences=gK, output_scores=True, return_dict_in_generate=True)
-        barrier()
-        g0 = time.perf_counter()
-        for _ in range(args.gen_batches):
-            o = model.generate(input_ids=gids, attention_mask=gmask, whole_word_ids=gww, max_length=30, prefix_allowed_tokens_fn=fn,
-                               num_beams=gK, num_return_sequences=gK, output_scores=True, return_dict_in_generate=True)
-        barrier()
-        gdt = time.perf_counter() - g0
-        if world > 1:
-            import torch.distributed as dist
-            tmax = torch.tensor([gdt], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            gdt = float(tmax.item())
+        gdt, dec_len, timing = time_generation(model, gB, gK, L, synth_item_trie(3416, 7), 30, args.gen_batches, world, device, 500 + rank)
         gen = {"items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3,
-               "users_per_batch": gB, "num_beams": gK, "max_length": 30, "trie_items": 3416,
-               "decoded_len": int(o["sequences"].shape[1])}
+               "users_per_batch": gB, "num_beams": gK, "max_length": 30, "trie_items": 3416, "decoded_len": dec_len, "timing_ms": timing}
 
     if rank == 0:
         c = cfg
         inner = c.num_heads * c.d_kv
         flops = train_flops_per_sample(c.d_model, inner, c.d_ff, c.num_heads, c.num_layers, L, T, V)
-        # dominant kernel: forward/dgrad/wgrad bf16 GEMMs; time the FFN up-projection shape [B*L, d] x [d, F] live
         Mg, Ng, Kg = B * L, c.d_ff, c.d_model
         t_k = time_gemm_kernel(be, Mg, Ng, Kg)
         ach = 2.0 * Mg * Ng * Kg / t_k / 1e12
         t_w = time_gemm_kernel(be, Ng, Kg, Mg, wgrad=True)          # dW_i[F, d] over B*L tokens
         ach_w = 2.0 * Mg * Ng * Kg / t_w / 1e12
+        k_fwd = "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>"
+        k_wg = "p5_gemm2_kernel<128,128,ring4,KS,KS>"
         line = {
             "metric": "train_samples_per_sec", "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -252,27 +410,47 @@ def main():
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
-            # dominant kernel family = the bf16 MFMA GEMMs (p5_gemm_kernel forward/dgrad instantiations + the ring kernels are
-            # ~70 % of the kernel time, profiles/r01_train_t5small_b64_kernel_stats.md); `roofline` times the largest forward
-            # shape live, `roofline_wgrad` the same FLOPs as a weight gradient on the ring kernel (in the step that kernel
-            # shares the GPU with the main stream, so its in-step launches are longer; profiles/README.md).  `traffic` is
-            # the PMC-measured HBM bytes per launch of exactly this kernel+shape (2 x FETCH_SIZE + WRITE_SIZE with the gfx950
-            # correction, profiles/r01_pmc_gemm.md) -- a recorded measurement, not collected inside this run.
-            "roofline": {"bound": "mfma", "kernel": "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>", "shape": [Mg, Ng, Kg],
-                         "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                         "traffic": 75.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None, "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
-                         "avg_launch_us": t_k * 1e6},
-            "roofline_wgrad": {"bound": "mfma", "kernel": "p5_gemm2_kernel<128,128,ring4,KS,KS>", "shape": [Ng, Kg, Mg], "achieved": ach_w,
-                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS,
-                               "traffic": 112.0e6 if (Mg, Ng, Kg) == (8192, 2048, 512) else None,   # PMC, profiles/r01_pmc_gemm.md
-                               "algorithmic_bytes": 2.0 * (Mg * Kg + Mg * Ng) + 4.0 * Ng * Kg, "avg_launch_us": t_w * 1e6},
+            # dominant kernel of the step by time (profiles/README.md): the ring weight-gradient GEMM; `roofline_fwd` times the
+            # same FLOPs as the forward FFN up-projection.  Both are timed live with HIP events on the launch stream; inside the
+            # step the ring kernel shares the GPU with the main stream, so its in-step launches are longer (profiles/).
+            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [Ng, Kg, Mg], "achieved": ach_w, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_w / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(k_wg, (Ng, Kg, Mg)),
+                         "algorithmic_bytes": 2.0 * (Mg * Kg + Mg * Ng) + 4.0 * Ng * Kg, "avg_launch_us": t_w * 1e6},
+            "roofline_fwd": {"bound": "mfma", "kernel": k_fwd, "shape": [Mg, Ng, Kg], "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(k_fwd, (Mg, Ng, Kg)),
+                             "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng), "avg_launch_us": t_k * 1e6},
         }
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+        if gen:
+            S = gen["decoded_len"] - 1
+            step_ms = (timing or {}).get("decode_ms")
+            step_ms = step_ms / max(1, S) if step_ms else gen["ms_per_batch"] / max(1, S)
+            byts = gen_bytes_per_step(c.d_model, inner, c.d_ff, c.num_decoder_layers, V, 20, 10, L, S // 2 + 1)
+            gbs = byts / (step_ms * 1e-3) / 1e9
+            line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": byts, "ms_per_step": step_ms,
+                                           "steps": S, "traffic": None,
+                                           "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d)); "
+                                                   "time = device time of the decode loop / steps when the engine reports it, else whole generate() / steps"}
+        legs_on = [] if args.legs == "none" else (["configs", "task_mix"] if args.legs == "all" else args.legs.split(","))
+        if world == 1:
+            del model, opt
+            torch.cuda.empty_cache()
+            legs = {}
+            if "task_mix" in legs_on:
+                try:
+                    legs["task_mix"] = task_mix_leg(be, device)
+                except Exception as ex:
+                    legs["task_mix"] = {"error": repr(ex)[:300]}
+            if "configs" in legs_on:
+                legs.update(config_legs(be, device, args.dtype))
+            if legs:
+                line["legs"] = legs
+            if not args.no_cpu:
+                line["cpu_baseline"] = cpu_baseline_train()
+                line["cpu_baseline_generation"] = cpu_baseline_generation()
         print(json.dumps(line), flush=True)
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        _dist().destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@
  *
  *   p5_forward            <- P5_T5.forward(input_ids, whole_word_ids, attention_mask, labels) -> per-token NLL
  *                            (model/P5_T5.py:275-386, called at runner/DistributedRunner.py:63-70)
+ *   p5_forward_loss       <- the same + the runner's masked-mean loss       (DistributedRunner.py:72-77)
  *   p5_backward           <- loss.backward()                               (DistributedRunner.py:80)
  *   p5_grad_sumsq +
  *   p5_adamw_step         <- clip_grad_norm_ + AdamW.step + scheduler      (DistributedRunner.py:81,85-86;
@@ -71,6 +72,12 @@ int64_t p5_train_workspace_bytes(const P5Engine* e, int B, int L, int T);
 int p5_forward(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
                const int64_t* labels, int B, int L, int T, int training, float* nll_out, void* ws, int64_t ws_bytes,
                void* stream);
+/* p5_forward + the runner's masked-mean loss (DistributedRunner.py:72-77) in one call: loss_out[0] = mean_b(sum_t nll*m / max(sum_t m, 1)),
+ * m = (output_attention != 0), computed behind the cross-entropy kernel.  A following p5_backward / p5_backward_stage with
+ * dnll == NULL back-propagates d(loss) = 1 (the CE backward derives the per-token weights from the mask itself). */
+int p5_forward_loss(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+                    const int64_t* labels, const int64_t* output_attention /* [B,T] */, int B, int L, int T, int training,
+                    float* nll_out /* [B*T] */, float* loss_out /* [1] */, void* ws, int64_t ws_bytes, void* stream);
 /* stages: 0 = head + decoder-final, 1..n_dec = decoder layers (top first), then decoder embedding,
  * then encoder-final + encoder layers (top first), last = encoder embedding.  p5_backward runs them all. */
 int p5_backward_num_stages(const P5Engine* e);

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "p5_engine_set_side_stream": (i32, [vp, vp]),
     "p5_train_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "p5_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp]),
+    "p5_forward_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
     "p5_backward_num_stages": (i32, [vp]),
     "p5_backward_stage": (i32, [vp, vp, i32, vp]),
     "p5_backward": (i32, [vp, vp, vp]),

@@ -350,17 +350,49 @@ __global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll,
   }
 }
 
-// dlogits[row, j] = (softmax_j - [j == label]) * dnll[row]   -> T, padded columns (V..ldd) zeroed
+// Runner loss behind the CE kernel (DistributedRunner.py:72-77):
+//   loss = mean_b( sum_t nll[b,t] * m[b,t] / max(sum_t m[b,t], 1) ),  m = (output_attention != 0)
+// one workgroup, fixed summation order (deterministic): thread i owns batch rows i, i+256, ...
+__global__ __launch_bounds__(256) void p5_masked_mean_kernel(float* __restrict__ loss, const float* __restrict__ nll,
+                                                            const int64_t* __restrict__ out_attn, int B, int T) {
+  __shared__ float sred[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float num = 0.f, cnt = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float m = out_attn[(size_t)b * T + t] != 0 ? 1.f : 0.f;
+      num += nll[(size_t)b * T + t] * m;
+      cnt += m;
+    }
+    s += num / fmaxf(cnt, 1.f);
+  }
+  s = block_reduce(s, false, sred);
+  if (threadIdx.x == 0) loss[0] = s / (float)B;
+}
+
+// dlogits[row, j] = (softmax_j - [j == label]) * g[row]   -> T, padded columns (V..ldd) zeroed.
+// g = dnll[row] (gradient of the per-token NLL handed in by autograd), or -- when dnll is null -- the gradient of the runner's
+// masked-mean loss itself: g[b,t] = m[b,t] / (max(sum_t m[b,:], 1) * B) * gscale, recomputed from the label mask (a8).
 template <class T>
 __global__ __launch_bounds__(256) void p5_ce_bwd_kernel(T* __restrict__ dlogits, const float* __restrict__ logits,
                                                        const float* __restrict__ lse, const int64_t* __restrict__ labels,
-                                                       const float* __restrict__ dnll, int V, int ldl, int ldd) {
+                                                       const float* __restrict__ dnll, int V, int ldl, int ldd,
+                                                       const int64_t* __restrict__ out_attn, int Tlen, float gscale) {
   // grid (rows, column slices); one 16-byte store per lane (ldl, ldd are multiples of 64: the lm_head GEMM pads V)
   constexpr int EPF = TT<T>::EPF;
   const int row = blockIdx.x;
   const float* lr = logits + (size_t)row * ldl;
   const int64_t lab = labels[row];
-  const float g = (lab == -100) ? 0.f : dnll[row];
+  float g;
+  if (dnll) {
+    g = dnll[row];
+  } else {
+    const int b = row / Tlen;
+    float cnt = 0.f;
+    for (int t = 0; t < Tlen; ++t) cnt += out_attn[(size_t)b * Tlen + t] != 0 ? 1.f : 0.f;
+    g = out_attn[row] != 0 ? gscale / fmaxf(cnt, 1.f) : 0.f;
+  }
+  if (lab == -100) g = 0.f;
   const float l = lse[row];
   for (int j = (blockIdx.y * 256 + threadIdx.x) * EPF; j < ldd; j += gridDim.y * 256 * EPF) {
     float v[8], o[8];

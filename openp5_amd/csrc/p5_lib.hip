@@ -245,7 +245,7 @@ struct P5Engine {
   uint32_t* rng = nullptr;
   // ---- saved state of the last forward ----
   int B = 0, L = 0, T = 0, training = 0, M = 0, Md = 0, Vp = 0;
-  const int64_t *ids = nullptr, *ww = nullptr, *mask = nullptr, *labels = nullptr;
+  const int64_t *ids = nullptr, *ww = nullptr, *mask = nullptr, *labels = nullptr, *out_attn = nullptr;
   std::vector<LayerSave> es, ds;
   void *enc_x0 = nullptr, *enc_xf = nullptr, *enc_out = nullptr; float* enc_rstd_f = nullptr;
   int64_t* dec_ids = nullptr; void *dec_x0 = nullptr, *dec_xf = nullptr, *dec_hn = nullptr; float* dec_rstd_f = nullptr;
@@ -768,8 +768,9 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     e->side_done_valid[0] = e->side_done_valid[1] = false;
 #endif
     begin_sublayer(e);
+    if (!dnll) P5_REQUIRE(e->out_attn, "backward without dnll needs p5_forward_loss (output_attention mask)");
     P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
-              e->labels, dnll, c.vocab_size, e->Vp, e->Vp);
+              e->labels, dnll, c.vocab_size, e->Vp, e->Vp, e->out_attn, e->T, 1.0f / (float)e->B);
     P5_TRY(P5_KCHECK());
     const float alpha = 1.0f / sqrtf((float)d);
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
@@ -1192,9 +1193,18 @@ int p5_forward(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_
   P5_REQUIRE(((uintptr_t)ws % 256) == 0, "workspace must be 256-byte aligned");
   e->B = B; e->L = L; e->T = T; e->M = B * L; e->Md = B * T; e->training = training;
   e->Vp = (e->c.vocab_size + 63) / 64 * 64;
-  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = labels;
+  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = labels; e->out_attn = nullptr;
   if (training && e->c.dropout > 0.f) P5_REQUIRE(e->rng, "training with dropout needs rng_state");
   return e->c.dtype == 1 ? forward_impl<bf16>(e, nll_out, (hipStream_t)stream) : forward_impl<float>(e, nll_out, (hipStream_t)stream);
+}
+int p5_forward_loss(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, const int64_t* labels,
+                    const int64_t* output_attention, int B, int L, int T, int training, float* nll_out, float* loss_out, void* ws, int64_t ws_bytes,
+                    void* stream) {
+  P5_REQUIRE(output_attention && loss_out, "null argument");
+  P5_TRY(p5_forward(e, input_ids, whole_word_ids, attention_mask, labels, B, L, T, training, nll_out, ws, ws_bytes, stream));
+  e->out_attn = output_attention;
+  P5_LAUNCH(p5_masked_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_out, (const float*)nll_out, output_attention, B, T);
+  return P5_KCHECK();
 }
 int p5_backward_num_stages(const P5Engine* e) { return e->c.n_dec_layers + e->c.n_enc_layers + 4; }
 int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {

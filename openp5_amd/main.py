@@ -26,12 +26,8 @@ from .utils.initialization import random_initialization
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="OpenP5 (MI355X-native T5 path)")
-    utils.parse_global_args(parser)
-    MultiTaskDataset.parse_dataset_args(parser)
-    parse_sampler_args(parser)
-    DistributedRunner.parse_runner_args(parser)
-    return parser
+    from .runner import build_arg_parser
+    return build_arg_parser()
 
 
 def get_dataset(args):

@@ -417,15 +417,17 @@ class P5T5Native(nn.Module):
         nll = torch.empty(B * T, dtype=torch.float32, device=dev)
         training = 1 if (self.training and self.config.dropout_rate > 0) else 0
         if training:
-            self._rng_cpu[1] = (self._rng_cpu[1] + 1) & 0xFFFFFFFF
-            self._rng[1] = self._rng_cpu[1] if self._rng_cpu[1] < 2 ** 31 else self._rng_cpu[1] - 2 ** 32
+            self._advance_dropout_step()
         self._saved_inputs = (input_ids, whole_word_ids, attention_mask, labels)   # keep device buffers alive
         self._be.check(self._lib.p5_forward(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), _ptr(labels), B, L, T,
                                             training, _ptr(nll), _ptr(ws), ws.numel(), self._be.stream_ptr()), "p5_forward")
         return nll
 
     def _engine_backward(self, dnll):
-        dnll = dnll.to(torch.float32).contiguous()
+        """dnll = gradient of the per-token NLL (autograd path), or None after `p5_forward_loss`: the engine then seeds
+        the backward with the gradient of the runner's masked-mean loss itself."""
+        if dnll is not None:
+            dnll = dnll.to(torch.float32).contiguous()
         lib, eng, sp = self._lib, self._engine, self._be.stream_ptr()
         if self.ddp_world > 1:
             import torch.distributed as dist
@@ -454,6 +456,36 @@ class P5T5Native(nn.Module):
             if p.grad is None:
                 off, n, shape = self._views[name]
                 p.grad = self._grads[off:off + n].view(shape)
+
+    def loss_and_backward(self, input_ids, whole_word_ids, attention_mask, labels, output_attention):
+        """Fused form of the reference loop body DistributedRunner.py:63-80: forward, masked-mean loss
+        (`(nll.view(B,T) * m).sum(1) / m.sum(1).clamp(min=1)).mean()`) and backward, all inside the engine -- the loss is
+        reduced behind the cross-entropy kernel and the backward is seeded from the label mask, so no torch autograd graph and
+        none of the ~10 elementwise launches of the generic path.  Returns the loss as a 0-dim tensor; gradients are in `.grad`."""
+        dev = self._be.device
+        input_ids = self._i64(input_ids, dev)
+        B, L = input_ids.shape
+        whole_word_ids = self._i64(whole_word_ids if whole_word_ids is not None else torch.zeros_like(input_ids), dev)
+        attention_mask = self._i64(attention_mask if attention_mask is not None else (input_ids != self.config.pad_token_id).long(), dev)
+        labels = self._i64(labels, dev)
+        output_attention = self._i64(output_attention, dev)
+        T = labels.shape[1]
+        self._sync_shadow()
+        ws = self._workspace(self._lib.p5_train_workspace_bytes(self._engine, B, L, T))
+        out = torch.empty(B * T + 1, dtype=torch.float32, device=dev)
+        training = 1 if (self.training and self.config.dropout_rate > 0) else 0
+        if training:
+            self._advance_dropout_step()
+        self._saved_inputs = (input_ids, whole_word_ids, attention_mask, labels, output_attention)
+        self._be.check(self._lib.p5_forward_loss(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), _ptr(labels),
+                                                 _ptr(output_attention), B, L, T, training, _ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * B * T),
+                                                 _ptr(ws), ws.numel(), self._be.stream_ptr()), "p5_forward_loss")
+        self._engine_backward(None)
+        return out[B * T]
+
+    def _advance_dropout_step(self):
+        self._rng_cpu[1] = (self._rng_cpu[1] + 1) & 0xFFFFFFFF
+        self._rng[1] = self._rng_cpu[1] if self._rng_cpu[1] < 2 ** 31 else self._rng_cpu[1] - 2 ** 32
 
     def forward(self, input_ids=None, whole_word_ids=None, attention_mask=None, labels=None, alpha=None, return_dict=True, **unused):
         """P5_T5.forward (P5_T5.py:275-386): returns {"loss": flat [B*T] per-token NLL}; `alpha` is accepted and ignored

@@ -53,12 +53,45 @@ def parse_runner_args(parser):
     return parser
 
 
+def build_arg_parser(description="OpenP5 (MI355X-native T5 path)"):
+    """The reference's four flag groups merged (main.py:24-232: global, dataset, sampler, runner)."""
+    import argparse
+    from .data import MultiTaskDataset
+    from .sampler import parse_sampler_args
+    from .utils import utils
+    parser = argparse.ArgumentParser(description=description)
+    utils.parse_global_args(parser)
+    MultiTaskDataset.parse_dataset_args(parser)
+    parse_sampler_args(parser)
+    parse_runner_args(parser)
+    return parser
+
+
 def masked_mean_loss(nll, output_attention):
     """DistributedRunner.py:72-77."""
     B, T = output_attention.shape
     m = (output_attention != 0).float()
     loss = nll.view(B, T) * m
     return (loss.sum(dim=1) / m.sum(dim=1).clamp(min=1)).mean()
+
+
+def training_step(model, optimizer, batch, alpha=2):
+    """One optimisation step of the reference loop (DistributedRunner.py:63-87): forward, masked-mean loss, backward,
+    clip + AdamW + scheduler (fused), zero_grad.  `batch` = (input_ids, whole_word_ids, attention_mask, labels,
+    output_attention) on the device.  With the native model the loss and its gradient seed are computed by the engine
+    (`P5T5Native.loss_and_backward`: masked mean folded behind the CE kernel, no torch autograd graph); any other model
+    goes through the generic torch path."""
+    input_ids, whole_ids, attn, output_ids, output_attention = batch[:5]
+    fused = getattr(model, "loss_and_backward", None)
+    if fused is not None:
+        loss = fused(input_ids, whole_ids, attn, output_ids, output_attention)
+    else:
+        out = model(input_ids=input_ids, whole_word_ids=whole_ids, attention_mask=attn, labels=output_ids, alpha=alpha, return_dict=True)
+        loss = masked_mean_loss(out["loss"], output_attention)
+        loss.backward()
+    optimizer.step()          # clip_grad_norm_ + AdamW + scheduler.step, fused
+    model.zero_grad()
+    return loss.detach()
 
 
 class Prefetcher:
@@ -173,13 +206,8 @@ class DistributedRunner:
             t0 = time.perf_counter()
             for batch in Prefetcher(self.train_loader, pin=torch.cuda.is_available()):
                 input_ids, attn, whole_ids, output_ids, output_attention = self._to_dev(batch)[:5]
-                out = self.model(input_ids=input_ids, whole_word_ids=whole_ids, attention_mask=attn, labels=output_ids,
-                                 alpha=self.args.alpha, return_dict=True)
-                loss = masked_mean_loss(out["loss"], output_attention)
-                loss.backward()
-                self.optimizer.step()          # clip_grad_norm_ + AdamW + scheduler.step, fused
-                self.model.zero_grad()
-                losses.append(loss.detach())
+                loss = training_step(self.model, self.optimizer, (input_ids, whole_ids, attn, output_ids, output_attention), self.args.alpha)
+                losses.append(loss)
                 n_samples += input_ids.shape[0]
             if torch.cuda.is_available():
                 torch.cuda.synchronize()

@@ -469,3 +469,134 @@ def bf16_training_converges_case(be, steps=40):
         last = v
     assert last < 0.6 * first, (first, last)
     return first, last
+
+
+def fused_loss_case(be, ocfg, B, L, T, dtype="fp32", dropout=0.0, seed=9, tol=1e-6):
+    """`P5T5Native.loss_and_backward` (p5_forward_loss + mask-seeded backward, DistributedRunner.py:63-80 in one engine call)
+    == forward() -> torch masked-mean -> autograd backward on the same inputs: same loss, same gradient arena."""
+    ocfg = O.T5Cfg(**{**ocfg.__dict__, "dropout": dropout})
+    params = O.init_params(ocfg, 7)
+    ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, seed)
+    out_attn[0, :] = 0          # a row with an empty label mask exercises clamp(min=1)
+    res = []
+    for fused in (False, True):
+        m = build_model(be, ocfg, params, dtype, dropout)
+        if dropout > 0:
+            m.train()
+            m.set_dropout_seed(77, 0)
+        else:
+            m.eval()
+        if fused:
+            loss = m.loss_and_backward(ids, ww, mask, labels, out_attn)
+        else:
+            nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"]
+            loss = O.runner_loss(nll, out_attn.to(nll.device))
+            loss.backward()
+        sync(be)
+        res.append((float(loss.detach()), m._grads.detach().cpu().clone()))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= tol * max(1.0, abs(l0)), (l0, l1)
+    err = (g0 - g1).abs().max().item() / max(1e-12, g0.abs().max().item())
+    assert err <= (tol if dtype == "fp32" else 2e-2), f"fused-loss gradient differs: {err}"
+    return l1, err
+
+
+# ---------------------------------------------------------------------------------------------------------
+# dataset-level evaluation parity (north_star: "ranked Hit@k identical")
+# ---------------------------------------------------------------------------------------------------------
+def make_pipeline(be, tmp, dtype, dataset="ML100K", n_users=120, n_items=150, n_inter=2400, flags=(), seed=2023, dropout=0.1, model_cfg=None,
+                  vocab=None):
+    """synthetic user sequences -> datasets -> sampler -> collator -> P5T5Native (T5-small dims) -> runner, as main.py wires it."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    from openp5_amd.collator import Collator
+    from openp5_amd.data import MultiTaskDataset
+    from openp5_amd.runner import DistributedRunner, build_arg_parser
+    from openp5_amd.sampler import SingleMultiDataTaskSampler
+    from openp5_amd.synth import write_dataset, write_prompt_file
+    from openp5_amd.tokenizer import build_offline_tokenizer
+    from openp5_amd.utils.initialization import random_initialization
+    write_dataset(os.path.join(tmp, "data"), dataset, n_users=n_users, n_items=n_items, n_inter=n_inter)
+    prompt = write_prompt_file(os.path.join(tmp, "prompt.txt"))
+    args = build_arg_parser().parse_args(["--data_path", os.path.join(tmp, "data"), "--datasets", dataset, "--tasks", "sequential,straightforward",
+                                          "--item_indexing", "sequential", "--prompt_file", prompt, "--sample_prompt", "1", "--sample_num", "2,2",
+                                          "--max_his", "10", "--distributed", "0", "--batch_size", "32", "--eval_batch_size", "10",
+                                          "--test_before_train", "0", "--test_epoch", "0", "--compute_dtype", dtype] + list(flags))
+    args.rank = 0
+    args.model_path = os.path.join(tmp, "model.pt")
+    random.seed(0)
+    tok = build_offline_tokenizer(vocab) if vocab else build_offline_tokenizer()
+    train = ConcatDataset([MultiTaskDataset(args, dataset, "train")])
+    loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                        collate_fn=Collator(tok))
+    cfg = model_cfg or P5ModelConfig.from_backbone("t5-small", dropout_rate=dropout)
+    model = P5T5Native(cfg, dtype=dtype, backend=be, seed=seed)
+    model.resize_token_embeddings(len(tok))
+    random_initialization(model, tok, "t5-small")
+    return DistributedRunner(model, tok, loader, None, be.device, args, 0), model, tok, args
+
+
+def collect_rankings(runner, gen_fn, K, max_length=50):
+    """Per test loader, per user: (gold token tuple, K ranked item token tuples, K scores) -- the inputs of
+    evaluate.rel_results (DistributedRunner.py:376-387) before they are collapsed into Hit/NDCG sums."""
+    out = []
+    for loader in runner.testloaders:
+        ds = loader.dataset
+        trie, ct, _ = runner._dataset_trie(ds)
+        users = []
+        for batch in loader:
+            seq, score = gen_fn(batch, trie, ct, K, max_length)
+            seq, score = seq.cpu(), score.cpu().float()
+            B = batch[0].shape[0]
+            seq = seq.view(B, K, -1)
+            score = score.view(B, K)
+            order = torch.sort(score, dim=1, descending=True, stable=True).indices
+            for b in range(B):
+                gold = tuple(t for t in batch[3][b].tolist() if t != 0)
+                ranked = [tuple(t for t in seq[b, j].tolist()[1:] if t != 0) for j in order[b].tolist()]
+                users.append((gold, ranked, score[b][order[b]].tolist()))
+        out.append(users)
+    return out
+
+
+def rankings_metrics(rankings, metrics=("hit@5", "hit@10", "ndcg@5", "ndcg@10")):
+    from openp5_amd import evaluate
+    res = []
+    for users in rankings:
+        rel = [[1 if r == gold else 0 for r in ranked] for gold, ranked, _ in users]
+        res.append(dict(zip(metrics, (evaluate.get_metrics_results(rel, list(metrics)) / max(1, len(rel))).tolist())))
+    return res
+
+
+def engine_gen_fn(model):
+    def fn(batch, trie, ct, K, max_length):
+        dev_ = model._be.device
+        o = model.generate(input_ids=batch[0].to(dev_), attention_mask=batch[1].to(dev_), whole_word_ids=batch[2].to(dev_), max_length=max_length,
+                           trie=ct, num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True)
+        return o["sequences"], o["sequences_scores"]
+    return fn
+
+
+def oracle_gen_fn(params, ocfg):
+    def fn(batch, trie, ct, K, max_length):
+        with torch.no_grad():
+            return O.beam_search(params, ocfg, batch[0], batch[2], batch[1], lambda b, s: trie.get(s.tolist()), K, max_length)
+    return fn
+
+
+def compare_rankings(a, b, K_list=(5, 10)):
+    """users whose ranked lists / gold ranks differ between two evaluations of the same loaders."""
+    stats = {"users": 0, "identical_lists": 0, "same_topk_set": {k: 0 for k in K_list}, "same_gold_rank": 0, "max_score_diff": 0.0, "diff_users": []}
+    for la, lb in zip(a, b):
+        for i, ((ga, ra, sa), (gb, rb, sb)) in enumerate(zip(la, lb)):
+            assert ga == gb
+            stats["users"] += 1
+            stats["identical_lists"] += int(ra == rb)
+            for k in K_list:
+                stats["same_topk_set"][k] += int(set(ra[:k]) == set(rb[:k]))
+            rka = ra.index(ga) if ga in ra else -1
+            rkb = rb.index(gb) if gb in rb else -1
+            stats["same_gold_rank"] += int(rka == rkb)
+            if rka != rkb:
+                stats["diff_users"].append((i, rka, rkb))
+            stats["max_score_diff"] = max(stats["max_score_diff"], max(abs(x - y) for x, y in zip(sorted(sa), sorted(sb))))
+    return stats

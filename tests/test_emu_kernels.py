@@ -145,3 +145,8 @@ def test_model_edge_shapes(emu, B, L, T):
 def test_generate_truncated_by_max_length(emu):
     """max_length shorter than the item ids: every beam 'finishes' by length, exactly as HF's MaxLengthCriteria."""
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 9, 4, 5, 30, seed=13)
+
+
+def test_fused_loss_matches_autograd_path(emu):
+    cases.fused_loss_case(emu, O.T5Cfg.named("tiny"), 3, 11, 5, "fp32", 0.0)
+    cases.fused_loss_case(emu, O.T5Cfg.named("tiny"), 2, 9, 4, "fp32", 0.1)

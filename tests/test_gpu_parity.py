@@ -68,6 +68,13 @@ def test_model_fp32(hip):
     cases.model_train_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6, "fp32", 0.0)
 
 
+def test_fused_loss_matches_autograd_path(hip):
+    """a8: masked-mean loss behind the CE kernel + mask-seeded backward == forward() + torch loss + autograd."""
+    cases.fused_loss_case(hip, O.T5Cfg.named("tiny"), 3, 11, 5, "fp32", 0.0)
+    cases.fused_loss_case(hip, O.T5Cfg.named("tiny"), 2, 9, 4, "fp32", 0.1)
+    cases.fused_loss_case(hip, O.T5Cfg.named("t5-small"), 8, 64, 8, "bf16", 0.1)
+
+
 def test_model_fp32_dropout(hip):
     cases.model_train_case(hip, O.T5Cfg.named("tiny"), 2, 17, 5, "fp32", 0.1)
 
