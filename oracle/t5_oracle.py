@@ -256,10 +256,14 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def ffn(x: Tensor, P: Dict[str, Tensor], prefix: str, cfg: T5Cfg, drop: Optional[DropoutPlan], site_h: int) -> Tensor:
-    """HF:modeling_t5.py:75-123."""
+def ffn(x: Tensor, P: Dict[str, Tensor], prefix: str, cfg: T5Cfg, drop: Optional[DropoutPlan], site_h: int,
+        taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """HF:modeling_t5.py:75-123.  taps[prefix + ".pre"] = ReLU pre-activations (for mask-flip audits of fp32 comparisons)."""
     if cfg.ff_act == "relu":
-        h = torch.relu(x @ P[prefix + ".DenseReluDense.wi.weight"].T)
+        pre = x @ P[prefix + ".DenseReluDense.wi.weight"].T
+        if taps is not None:
+            taps[prefix + ".pre"] = pre.detach()
+        h = torch.relu(pre)
     else:
         h = gelu_new(x @ P[prefix + ".DenseReluDense.wi_0.weight"].T) * (x @ P[prefix + ".DenseReluDense.wi_1.weight"].T)
     if drop is not None:
@@ -291,7 +295,7 @@ def encoder_forward(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_w
         a = attention(n, n, P, p + ".layer.0.SelfAttention", bias, cfg, drop, site_id(0, i, 1))
         x = x + (drop.apply(a, site_id(0, i, 2)) if drop is not None else a)
         n = rmsnorm(x, P[p + ".layer.1.layer_norm.weight"], cfg.eps)
-        f = ffn(n, P, p + ".layer.1", cfg, drop, site_id(0, i, 5))
+        f = ffn(n, P, p + ".layer.1", cfg, drop, site_id(0, i, 5), taps)
         x = x + (drop.apply(f, site_id(0, i, 6)) if drop is not None else f)
         if taps is not None:
             taps[f"enc.block{i}"] = x
@@ -319,7 +323,7 @@ def decoder_forward(P: Dict[str, Tensor], cfg: T5Cfg, dec_ids: Tensor, enc: Tens
         x = drop.apply(x, site_id(1, 0, 0))
     B, T = dec_ids.shape
     causal = torch.ones(T, T, dtype=torch.bool).tril()
-    cmask = torch.where(causal, 0.0, _neg(x.dtype)).to(x.dtype)[None, None]
+    cmask = torch.where(causal, torch.zeros((), dtype=x.dtype), torch.full((), _neg(x.dtype), dtype=x.dtype))[None, None]
     sbias = compute_bias(P["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"],
                          T, T, False, cfg) + cmask
     xbias = (1.0 - enc_mask[:, None, None, :].to(x.dtype)) * _neg(x.dtype)            # zero position bias + enc mask
@@ -332,7 +336,7 @@ def decoder_forward(P: Dict[str, Tensor], cfg: T5Cfg, dec_ids: Tensor, enc: Tens
         a = attention(n, enc, P, p + ".layer.1.EncDecAttention", xbias, cfg, drop, site_id(1, i, 3))
         x = x + (drop.apply(a, site_id(1, i, 4)) if drop is not None else a)
         n = rmsnorm(x, P[p + ".layer.2.layer_norm.weight"], cfg.eps)
-        f = ffn(n, P, p + ".layer.2", cfg, drop, site_id(1, i, 5))
+        f = ffn(n, P, p + ".layer.2", cfg, drop, site_id(1, i, 5), taps)
         x = x + (drop.apply(f, site_id(1, i, 6)) if drop is not None else f)
         if taps is not None:
             taps[f"dec.block{i}"] = x

@@ -2,6 +2,8 @@
 run in the build container -- the third-party code that holds this path's arithmetic.
 The fixtures pin (a) the restated oracle (tests/test_oracle_vs_hf.py) and (b) the HIP path (-m gpu tests) on the GPU
 box, where /root/reference and HF-vs-oracle cross-checks are not assumed.
+NOTE: the installed transformers is 5.15, the reference pins 4.26.0 (src/src_t5/environment_t5.txt:2), whose source is not on
+this box; SURVEY.md 8(c) lists the known behavioural deltas (vectorised beam search, pad fill after </s>).
 
     python tests/golden/make_golden.py
 """
@@ -51,6 +53,9 @@ def main():
     for name, cfgname, kw, (B, L, T), K, ML in [
         ("tiny_relu", "tiny", dict(), (3, 20, 6), 5, 12),
         ("tiny_gated", "tiny", dict(ff_act="gated-gelu"), (2, 17, 5), 4, 10),
+        # full T5-small dims (d=512, F=2048, H=8, 6+6 layers, V=32100): the oracle and the HIP path are pinned to HF at the
+        # size BASELINE.json's headline config uses, not only at toy dims (parameters are regenerated from the seed)
+        ("t5small_relu", "t5-small", dict(), (2, 48, 8), 6, 12),
     ]:
         cfg = O.T5Cfg.named(cfgname, dropout=0.0, **kw)
         P = O.init_params(cfg, 11)
@@ -64,7 +69,7 @@ def main():
         loss.backward()
         grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
         grads["encoder.whole_word_embeddings.weight"] = wwe.weight.grad.detach().clone()
-        items = make_items(40, 3)
+        items = make_items(40, 3) if cfgname == "tiny" else make_items(200, 3, lo=3000, hi=3200)
         fn = prefix_allowed_tokens_fn(Trie(items))
         seqs, scores = hf_generate(m, wwe, ids, ww, mask, fn, K, ML)
         fx = dict(cfg=cfg.__dict__, params_seed=11, input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels,

@@ -101,6 +101,11 @@ def test_golden(hip, name):
     cases.golden_case(hip, name)
 
 
+def test_golden_t5_small_dims(hip):
+    """fixture made by stock HF T5 at full T5-small dims, V=32100 (transformers 5.15; the reference pins 4.26.0)."""
+    cases.golden_case(hip, "t5small_relu", nll_tol=1e-4, grad_tol=1e-3, score_tol=1e-4)
+
+
 @pytest.mark.parametrize("via", ["ours", "closure", "opaque"])
 def test_generate(hip, via):
     cases.generate_case(hip, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
@@ -169,10 +174,34 @@ def test_generate_large_fanout_and_batch(hip):
 @pytest.mark.parametrize("name,B,L,T", [("t5-base", 2, 96, 8), ("t5-large", 1, 512, 10)])
 def test_model_base_large_dims_fp32(hip, name, B, L, T):
     """BASELINE.json configs[2] / configs[4] dims (d=768/H=12/F=3072 and d=1024/H=16/F=4096, L up to 512), two layers per
-    stack so the CPU oracle stays fast; V = 32100."""
-    cfg = O.T5Cfg.named(name, num_layers=2, num_decoder_layers=2)
-    # (ReLU masks of pre-activations within fp32 rounding of zero may flip between summation orders at F = 4096)
-    cases.model_train_case(hip, cfg, B, L, T, "fp32", 0.0, nll_tol=2e-4, grad_tol=1e-2)
+    stack, V = 32100, against the oracle evaluated in fp64.  Round 1 relaxed the T5-large tolerance to 1e-2 on the guess that
+    ReLU masks flip at F = 4096; round 2 measured it (tools/diag_r2.py: engine-vs-fp64 4.2e-3 on ONE tensor, the last encoder
+    layer's wi.weight, every other tensor <= 3.5e-4; fp32-oracle-vs-fp64 1.2e-5) and audits it: only wi rows of hidden units
+    whose fp64 pre-activation lies within 1e-5 of zero at some token may exceed the restored 1e-3 tolerance."""
+    cfg = O.T5Cfg.named(name, num_layers=2, num_decoder_layers=2, dropout=0.0)
+    worst, excused, near = cases.fp32_vs_fp64_case(hip, cfg, B, L, T, tol=1e-3, audit_eps=1e-5)
+    print(f"[{name} 2+2] worst {worst}, excused {excused}, near-zero units per layer {near}")
+
+
+@pytest.mark.parametrize("name,B,L,T", [("t5-base", 2, 64, 6), ("t5-large", 1, 64, 6)])
+def test_model_full_depth_fp32(hip, name, B, L, T):
+    """FULL depth (T5-base 12+12, T5-large 24+24 layers, V = 32100): one training step's loss and every gradient, fp32 engine
+    against the fp64 oracle, same audited 1e-3 tolerance."""
+    cfg = O.T5Cfg.named(name, dropout=0.0)
+    worst, excused, near = cases.fp32_vs_fp64_case(hip, cfg, B, L, T, tol=1e-3, audit_eps=1e-5)
+    print(f"[{name} full depth] worst {worst}, excused {excused}")
+
+
+def test_bf16_gradients_at_benchmark_shape(hip):
+    """The mode and shape bench.py reports (BASELINE.json configs[1]: T5-small, B=64, L=128, T=8, bf16 engine) against the fp32
+    oracle.  Bounds = 2-3x what bf16 storage of activations/weights with fp32 accumulation measures here (tools/diag_r2.py on
+    MI355X: NLL max 0.028 / mean 0.0068 at a mean NLL of 9.5; worst tensor relL2 5.3e-2, cosine 0.9986; whole gradient relL2
+    1.3e-2, cosine 0.99991) -- i.e. every parameter tensor's update direction agrees to better than 0.3 degrees of arc cosine."""
+    r = cases.bf16_c2_gradient_case(hip)
+    print("[bf16 C2]", r)
+    assert r["nll_max"] <= 0.08 and r["nll_mean"] <= 0.02 and r["loss_err"] <= 0.02, r
+    assert r["worst_rel"][0] <= 0.12 and r["worst_cos"][0] >= 0.995, r
+    assert r["whole_rel"] <= 0.03 and r["whole_cos"] >= 0.9995, r
 
 
 def test_generate_base_beam20_collaborative_vocab(hip):

@@ -11,8 +11,9 @@ from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
 from tests import cases
 
 
-@pytest.mark.parametrize("name", ["tiny_relu", "tiny_gated"])
+@pytest.mark.parametrize("name", ["tiny_relu", "tiny_gated", "t5small_relu"])
 def test_oracle_vs_golden(name):
+    """fixtures come from stock HF T5 (transformers 5.15 installed here; the reference pins 4.26.0)."""
     fx = torch.load(os.path.join(cases.GOLDEN, name + ".pt"), weights_only=False)
     cfg = O.T5Cfg(**fx["cfg"])
     P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, fx["params_seed"]).items()}
@@ -47,6 +48,26 @@ def test_oracle_vs_hf_live():
         s1, sc1 = O.beam_search(P, cfg, ids, ww, mask, fn, 6, 11)
     s2, sc2 = hf_generate(m, wwe, ids, ww, mask, fn, 6, 11)
     cases.compare_generation(s1, sc1, s2, sc2, 1e-5)
+
+
+def test_oracle_vs_hf_live_t5_small_dims():
+    """the same live cross-check at full T5-small dims and V=32100 (transformers 5.15; the reference pins 4.26.0)."""
+    pytest.importorskip("transformers")
+    from oracle.hf_ref import build_hf, hf_forward_nll, hf_generate
+    cfg = O.T5Cfg.named("t5-small", dropout=0.0)
+    P = O.init_params(cfg, 23)
+    m, wwe = build_hf(cfg, P)
+    ids, ww, mask, labels, out_attn = cases.synth_batch(cfg, 2, 40, 7, 9)
+    with torch.no_grad():
+        nll_hf, _ = hf_forward_nll(m, wwe, ids, ww, mask, labels)
+        nll = O.p5_forward_nll(P, cfg, ids, ww, mask, labels)
+    assert (nll - nll_hf).abs().max() < 2e-5
+    trie = Trie(cases.make_items(120, 4, lo=3000, hi=3100))
+    fn = lambda b, s: trie.get(s.tolist())   # noqa: E731
+    with torch.no_grad():
+        s1, sc1 = O.beam_search(P, cfg, ids, ww, mask, fn, 5, 10)
+    s2, sc2 = hf_generate(m, wwe, ids, ww, mask, fn, 5, 10)
+    cases.compare_generation(s1, sc1, s2, sc2, 2e-5)
 
 
 def test_bucket_lut_matches_oracle():
