@@ -131,6 +131,11 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
                    int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
                    void* stream);
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream);
+/* decode-step projection over a few hundred rows (p5_decode2.h): C = A W^T, W = T [N, ldw].  amode 0: A = T [M, lda];
+ * amode 1: A = fp32 residual stream [M, K], normalised with T5LayerNorm weight `ln` by the kernel itself.
+ * epi: 0 store T (alpha), 1 relu store T, 2 fp32 atomic accumulate (split-K), 3 store fp32 (alpha) */
+int p5_op_skinny_gemm(int dtype, int amode, const void* A, int lda, const float* ln, const void* W, int ldw, void* C, int ldc,
+                      int M, int N, int K, int epi, float alpha, float eps, void* stream);
 int p5_op_tr_probe(void* out64x4_u16, const void* in256_u16, void* stream);  /* ds_read_b64_tr_b16 semantics probe */
 
 #ifdef __cplusplus

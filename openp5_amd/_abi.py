@@ -51,6 +51,7 @@ PROTOTYPES = {
     "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                             i32, i32, i32, i32, vp, u32, f32, vp]),
     "p5_op_ce_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "p5_op_skinny_gemm": (i32, [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "p5_op_tr_probe": (i32, [vp, vp, vp]),
 }
 

@@ -248,7 +248,7 @@ struct P5BeamState {
   int* unsat;                        // [B]
   int* anc; int* anc_next;           // [max_len, R]
   int64_t* last_tok;                 // [R] decoder input for the next step
-  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len, [3] arrivals
+  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len, [3] arrivals, [4] done
 };
 
 // ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
@@ -460,5 +460,5 @@ __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const
     st.last_tok[i] = start_id;
   }
   if (i < B) st.unsat[i] = 1;
-  if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; st.flags[3] = 0; }
+  if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; st.flags[3] = 0; st.flags[4] = 0; }
 }

@@ -18,6 +18,7 @@
 #include "p5_attn.h"
 #include "p5_elem.h"
 #include "p5_decode.h"
+#include "p5_decode2.h"
 #include "../../include/p5hip.h"
 
 static thread_local std::string g_err;
@@ -48,6 +49,10 @@ static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv(
 static int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING_WGS")) : 160;      // target tiles x splits (in-step sweep: 96..192 equal, 256 +1.5 %)
 static int g_opt_decode_fused = getenv("P5_DECODE_FUSED") ? atoi(getenv("P5_DECODE_FUSED")) : 1;   // RMSNorm folded into the decode-step GEMMs
 static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
+static int g_opt_decode_v2 = getenv("P5_DECODE_V2") ? atoi(getenv("P5_DECODE_V2")) : 1;   // latency-shaped decode step (p5_decode2.h)
+static int g_opt_dec_nb = getenv("P5_DEC_NB") ? atoi(getenv("P5_DEC_NB")) : 0;           // skinny GEMM: forced column-tile width (0 = auto)
+static int g_opt_dec_kw = getenv("P5_DEC_KW") ? atoi(getenv("P5_DEC_KW")) : 0;           // skinny GEMM: forced K range per workgroup (0 = auto)
+static int g_opt_dec_fuseq = getenv("P5_DEC_FUSEQ") ? atoi(getenv("P5_DEC_FUSEQ")) : 1;   // cross-attention computes its own q projection
 
 template <class T, int BM, int BN>
 static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
@@ -875,6 +880,7 @@ struct GenWs {
   void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
   void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
+  float* x32;             // [R, d] fp32 residual stream of the decode step (v2: updated in place with atomics)
   float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
   int64_t* mask_copy;
   float* ssq;             // [3 * n_dec_layers + 1][R] row sums of squares of the residual stream entering each norm (fused path)
@@ -899,6 +905,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.xa = b.take(R * d * sz); w.xb = b.take(R * d * sz); w.n = b.take(R * d * sz);
   w.qkv = b.take(R * 3 * in * sz); w.q = b.take(R * in * sz); w.o = b.take(R * in * sz);
   w.h = b.take(R * (c.gated_gelu ? 3 : 1) * F * sz); w.hn = b.take(R * d * sz);
+  w.x32 = (float*)b.take(R * d * 4);
   w.logits = (float*)b.take(R * Vp * 4);
   w.ssq = (float*)b.take((size_t)(3 * c.n_dec_layers + 1) * R * 4);
   w.cand = (float*)b.take(R * (size_t)max_c * 4);
@@ -998,6 +1005,112 @@ static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, 
   return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, 1.0f / sqrtf((float)d), 1);
 }
 
+// ---- latency-shaped decode step (p5_decode2.h) ------------------------------------------------------------
+template <class T, int NB, int AMODE>
+static int launch_skinny_nb(const P5SkinnyArgs& g, int splits, int need_bytes, hipStream_t s) {
+  dim3 grid((g.N + NB - 1) / NB, (g.M + 15) / 16, splits), block(256);
+  if (need_bytes <= 44 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 44>), grid, block, 0, s, g);
+  else if (need_bytes <= 100 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 100>), grid, block, 0, s, g);
+  else if (need_bytes <= 140 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 140>), grid, block, 0, s, g);
+  else return fail("skinny gemm: tile does not fit the LDS");
+  return P5_KCHECK();
+}
+// C = A W^T over M <= a few hundred rows.  amode 1: A is the fp32 residual stream, normalised (T5LayerNorm, weight `ln`) by the
+// consumer itself (K = d_model, no split); amode 0: A is a T matrix, K may be split over workgroups (atomic epilogue only).
+template <class T>
+static int skinny(hipStream_t s, int amode, const void* A, int lda, const float* ln, const T* W, int ldw, void* C, int ldc, int M, int N, int K,
+                  int epi, float alpha, float eps, const int* done) {
+  constexpr int EPS = SkT<T>::EPS;
+  P5_REQUIRE(K % EPS == 0 && ldw % TT<T>::EPF == 0 && (amode == 1 || lda % TT<T>::EPF == 0), "skinny gemm: K / leading dims");
+  P5SkinnyArgs g;
+  g.A = A; g.ln = ln; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.epi = epi; g.alpha = alpha; g.eps = eps;
+  g.done = done;
+  auto need = [&](int nb, int kw) { return (kw / EPS) * (2048 + nb * 128) + 3072; };
+  int nb = g_opt_dec_nb, kw = K, splits = 1;
+  if (amode == 1) {
+    if (!nb) nb = need(64, K) <= 100 * 1024 ? 64 : (need(32, K) <= 100 * 1024 ? 32 : 16);
+  } else {
+    if (!nb) nb = 64;
+    // K range per workgroup: at most 512 (bf16) / 256 (fp32) elements -- one 80 KiB burst -- and enough splits for >= ~200 workgroups
+    int cap = g_opt_dec_kw ? g_opt_dec_kw : (sizeof(T) == 2 ? 512 : 256);
+    const int tiles = ((N + nb - 1) / nb) * ((M + 15) / 16);
+    if (!g_opt_dec_kw && epi == P5_SK_ATOMIC)
+      while (cap > 2 * EPS && tiles * ((K + cap - 1) / cap) < 192) cap /= 2;
+    if (epi != P5_SK_ATOMIC) cap = K;
+    kw = cap < K ? (cap / EPS) * EPS : K;
+    splits = (K + kw - 1) / kw;
+  }
+  g.kw = kw;
+  const int nbytes = need(nb, kw);
+  if (amode == 1) {
+    if (nb == 64) return launch_skinny_nb<T, 64, 1>(g, 1, nbytes, s);
+    if (nb == 32) return launch_skinny_nb<T, 32, 1>(g, 1, nbytes, s);
+    return launch_skinny_nb<T, 16, 1>(g, 1, nbytes, s);
+  }
+  if (nb == 64) return launch_skinny_nb<T, 64, 0>(g, splits, nbytes, s);
+  if (nb == 32) return launch_skinny_nb<T, 32, 0>(g, splits, nbytes, s);
+  return launch_skinny_nb<T, 16, 0>(g, splits, nbytes, s);
+}
+
+template <class T>
+static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, R = B * K;
+  const int* done = w.st.flags + 4;
+  float* x = w.x32;
+  P5_LAUNCH(p5_embed_f32_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, (const float*)(e->P + e->off_E), (const int64_t*)w.st.last_tok, R, d, done);
+  P5_TRY(P5_KCHECK());
+  constexpr int EPS = SkT<T>::EPS;
+  const bool fuseq = g_opt_dec_fuseq && sizeof(T) == 2 && (d / EPS) * (2048 + 64 * 128) + 3072 + 12544 + 2 * 16384 <= 128 * 1024;
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const LayerOff& lo = e->dec[i];
+    // ---- self-attention: qkv = norm(x) Wqkv^T ; attention over the ancestry-indexed cache ; x += o Wo^T ----
+    P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.sa.ln, Wc<T>(e, lo.sa.q), d, w.qkv, 3 * in, R, 3 * in, d, P5_SK_STORE, 1.f, c.eps, done));
+    if (getenv("P5_DBG_OLD_SELF"))
+    P5_LAUNCH((p5_dec_self_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i],
+              (const int*)w.st.anc, (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H,
+              (const int*)(w.st.flags + 2), max_len);
+    else
+    P5_LAUNCH((p5_dec_self_attn2_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
+              (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
+    P5_TRY(P5_KCHECK());
+    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.sa.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
+    // ---- cross-attention ----
+    P5CrossArgs a;
+    a.out = w.o; a.q = w.q; a.x = x; a.ln = e->P + lo.ca.ln; a.Wq = Wc<T>(e, lo.ca.q); a.kv = w.kv_cross[i]; a.mask = w.mask_copy;
+    a.R = R; a.H = H; a.Kb = K; a.L = L; a.d = d; a.eps = c.eps; a.done = done;
+    const dim3 cgrid(B * ((K + 15) / 16), H);
+    if (fuseq) {
+      if constexpr (sizeof(T) == 2) P5_LAUNCH((p5_dec_cross_attn2_kernel<T, true, 128>), cgrid, dim3(256), 0, s, a);
+    } else {
+      P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.ca.ln, Wc<T>(e, lo.ca.q), d, w.q, in, R, in, d, P5_SK_STORE, 1.f, c.eps, done));
+      if (getenv("P5_DBG_OLD_CROSS"))
+      P5_LAUNCH((p5_dec_cross_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.q, (const T*)w.kv_cross[i],
+              (const int64_t*)w.mask_copy, R, H, K, L);
+      else
+      P5_LAUNCH((p5_dec_cross_attn2_kernel<T, false, sizeof(T) == 2 ? 48 : 80>), cgrid, dim3(256), 0, s, a);
+    }
+    P5_TRY(P5_KCHECK());
+    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.ca.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
+    // ---- feed-forward ----
+    if (c.gated_gelu) {
+      T* u = (T*)w.h + (size_t)R * F;
+      P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.ff_ln, Wc<T>(e, lo.wi), d, u, 2 * F, R, 2 * F, d, P5_SK_STORE, 1.f, c.eps, done));
+      const size_t n = (size_t)R * F;
+      P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (T*)w.h, (const T*)u, R, F, no_drop());
+      P5_TRY(P5_KCHECK());
+    } else {
+      P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.ff_ln, Wc<T>(e, lo.wi), d, w.h, F, R, F, d, P5_SK_RELU, 1.f, c.eps, done));
+    }
+    P5_TRY(skinny<T>(s, 0, w.h, F, nullptr, Wc<T>(e, lo.wo), F, x, d, R, d, F, P5_SK_ATOMIC, 1.f, 0.f, done));
+  }
+  // logits = (norm(x) * d^-0.5) E^T   (P5_T5.py:352-361)
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  P5_LAUNCH((p5_rmsnorm_f32in_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.hn, (const float*)x, (const float*)(e->P + e->off_dec_fln), R, d, c.eps, done);
+  P5_TRY(P5_KCHECK());
+  return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, 1.0f / sqrtf((float)d), 1);
+}
+
 template <class T>
 static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                          const int* roots, const uint32_t* excluded, int excl_words, int max_c, int* out_seq, float* out_score, int* out_len,
@@ -1020,7 +1133,8 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   const uint32_t* excl = excl_words > 0 ? w.excluded : nullptr;
   auto step_body = [&]() -> int {
     hipMemsetAsync(w.st.flags, 0, 8, s);
-    P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
+    if (g_opt_decode_v2) P5_TRY(decode_step2<T>(e, w, B, L, K, max_len, s));
+    else P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
     P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_cand, (const float*)w.logits, Vp,
               c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, child_node, excl, excl_words, K, max_c, 2 * K);
     P5_TRY(P5_KCHECK());
@@ -1034,7 +1148,7 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   GraphKey key;
   memset(&key, 0, sizeof(key));
   key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.excl_words = excl_words; key.ws = ws; key.trie = child_off; key.trie_tok = child_tok; key.trie_node = child_node; key.roots = roots;
-  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.fused = g_opt_decode_fused;
+  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.fused = g_opt_decode_fused + 2 * g_opt_decode_v2 + 4 * g_opt_dec_fuseq + 8 * g_opt_dec_nb + 4096 * g_opt_dec_kw;
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
   auto capture = [&]() {
     // (never during the very first step: the first launch of a kernel loads its code object, which is not allowed
@@ -1121,6 +1235,10 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "decode_fused")) g_opt_decode_fused = value;
   else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
+  else if (!strcmp(name, "decode_v2")) g_opt_decode_v2 = value;
+  else if (!strcmp(name, "dec_nb")) g_opt_dec_nb = value;
+  else if (!strcmp(name, "dec_kw")) g_opt_dec_kw = value;
+  else if (!strcmp(name, "dec_fuseq")) g_opt_dec_fuseq = value;
   else return fail("p5_set_option: unknown option");
   return 0;
 }
@@ -1355,6 +1473,11 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream) {
   P5_LAUNCH(p5_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, nll, lse, logits, labels, V, ldl);
   return P5_KCHECK();
+}
+int p5_op_skinny_gemm(int dtype, int amode, const void* A, int lda, const float* ln, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                      int epi, float alpha, float eps, void* stream) {
+  return dtype == 1 ? skinny<bf16>((hipStream_t)stream, amode, A, lda, ln, (const bf16*)W, ldw, C, ldc, M, N, K, epi, alpha, eps, nullptr)
+                    : skinny<float>((hipStream_t)stream, amode, A, lda, ln, (const float*)W, ldw, C, ldc, M, N, K, epi, alpha, eps, nullptr);
 }
 int p5_op_tr_probe(void* out, const void* in, void* stream) {
   P5_LAUNCH(p5_tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned short*)out, (const unsigned short*)in);

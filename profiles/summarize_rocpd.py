@@ -1,5 +1,6 @@
 """Turn a rocprofv3 (rocpd sqlite) kernel trace into a per-kernel stats table (what `--stats` prints as CSV).
-usage: python profiles/summarize_rocpd.py gpurun_out/prof/x_results.db [out.md] [--skip-first N_dispatches]"""
+usage: python profiles/summarize_rocpd.py gpurun_out/prof/x_results.db [out.md] [--by-grid]
+--by-grid keys the table by (kernel, grid) so that every shape a kernel runs at gets its own row (per-shape durations)."""
 import re
 import sqlite3
 import sys
@@ -20,6 +21,8 @@ def main():
     stats = {}
     for name, st, en, gx, gy, gz, wx, vg, ag, lds in rows:
         k = short(name)
+        if "--by-grid" in sys.argv:
+            k = f"{k} grid=({gx // max(1, wx)},{gy},{gz})"
         a = stats.setdefault(k, [0, 0, 1 << 62, 0, vg, ag, lds])
         dur = en - st
         a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)

@@ -649,8 +649,12 @@ def relu_flip_audit(taps, eps):
 def fp32_vs_fp64_case(be, ocfg, B, L, T, tol=1e-3, audit_eps=2e-6, seed=3):
     """fp32 engine against the oracle evaluated in fp64 (the ground truth both fp32 evaluations approximate).  An fp32 ReLU
     pre-activation within rounding noise of zero may land on either side of it -- a different, equally valid fp32 evaluation
-    whose gradient differs by O(1) in that element.  Those hidden units are identified from the fp64 pre-activations
-    (|pre| < audit_eps) and only the wi rows / wo columns of such units may exceed `tol`; everything else must meet it."""
+    whose gradient differs by O(1) in that element.  Audit: hidden units with |fp64 pre-activation| < audit_eps at some token are
+    listed per layer; a wi row of such a unit may exceed `tol` (an evidenced, explained flip).  A flip perturbs one token's
+    gradient in everything it back-propagates into (the same sub-layer's norm weight, every earlier layer of the stack, the
+    whole encoder for a decoder flip, the embeddings), so those tensors are held to a relative-L2 bound of 2 * tol (robust to
+    a single token's contribution) and a max-abs bound of 20 * tol; every tensor that no evidenced flip reaches must meet the
+    max-abs `tol` itself.  Without flips (T5-small/base dims in practice) the check is the plain max-abs one."""
     params = O.init_params(ocfg, 7)
     ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, seed)
     P64 = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
@@ -662,23 +666,71 @@ def fp32_vs_fp64_case(be, ocfg, B, L, T, tol=1e-3, audit_eps=2e-6, seed=3):
     sync(be)
     near = relu_flip_audit(taps, audit_eps)
     gmax = max(float(v.grad.abs().max()) for v in P64.values())
-    worst, excused = (0.0, ""), []
+    errs, excused, flip = {}, [], {"encoder": -1, "decoder": -1}
     for name, p in m.named_parameters():
         g, g64 = p.grad.detach().cpu().double(), P64[name].grad
         err = (g - g64).abs() / (float(g64.abs().max()) + 1e-2 * gmax)
-        if ".DenseReluDense.wi" in name or ".DenseReluDense.wo" in name:
+        if ".DenseReluDense.wi" in name:
             parts = name.split(".")
             units = sorted(near.get((parts[0], int(parts[2])), ()))
-            if units:
-                sel = err[units, :] if ".wi" in name else err[:, units]
-                if float(sel.max()) > tol:
-                    excused.append((name, len(units), float(sel.max())))
-                if ".wi" in name:
-                    err[units, :] = 0
-                else:
-                    err[:, units] = 0
-        e = float(err.max())
-        if e > worst[0]:
-            worst = (e, name)
-    assert worst[0] <= tol, f"fp32 gradient mismatch outside audited ReLU near-zero units: {worst}; excused {excused}"
-    return worst, excused, {k: len(v) for k, v in near.items()}
+            if units and float(err[units, :].max()) > tol:
+                excused.append((name, len(units), float(err[units, :].max())))
+                flip[parts[0]] = max(flip[parts[0]], int(parts[2]))
+                err[units, :] = 0
+        errs[name] = (float(err.max()), float((g - g64).norm() / (g64.norm() + 1e-30)))
+
+    def reached(name):      # can an evidenced flip have perturbed this tensor's gradient?
+        parts = name.split(".")
+        if name.startswith("encoder.block."):
+            return int(parts[2]) <= flip["encoder"] or flip["decoder"] >= 0
+        if name.startswith("decoder.block."):
+            return int(parts[2]) <= flip["decoder"]
+        if name == "decoder.final_layer_norm.weight":
+            return False
+        if name == "encoder.final_layer_norm.weight":
+            return flip["decoder"] >= 0
+        return flip["encoder"] >= 0 or flip["decoder"] >= 0
+
+    worst = (0.0, "")
+    for name, (emax, erel) in errs.items():
+        if reached(name):
+            assert erel <= 2 * tol and emax <= 20 * tol, f"{name}: relL2 {erel:.3e} max {emax:.3e} (reached by an audited ReLU flip; excused {excused})"
+        else:
+            assert emax <= tol, f"fp32 gradient mismatch {name}: {emax:.3e} > {tol} (no audited flip reaches it; excused {excused})"
+        worst = max(worst, (emax, name))
+    return worst, excused, {k: len(v) for k, v in near.items() if v}
+
+
+def skinny_gemm_case(be, dtype, amode, M, N, K, epi, seed=0):
+    """decode-step projection kernel (p5_decode2.h) against torch: plain / ReLU / fp32-atomic-accumulate epilogues, optional
+    fused T5LayerNorm of the fp32 A rows."""
+    g = torch.Generator().manual_seed(seed)
+    tt = TT[dtype]
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(tt)
+    if amode == 1:
+        x = torch.randn(M, K, generator=g) * 3.0
+        ln = 1.0 + 0.1 * torch.randn(K, generator=g)
+        xn = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)).to(tt).float()
+        A_ref = (ln * xn).to(tt).float()
+        A_dev, lda = x, K
+    else:
+        A = torch.randn(M, K, generator=g).to(tt)
+        A_ref, A_dev, lda, ln = A.float(), A, K, None
+    ref = A_ref @ W.float().t()
+    base = torch.randn(M, N, generator=g)
+    if epi == 1:
+        ref = torch.relu(ref)
+    if epi == 2:
+        ref = base + ref
+    out_f32 = epi in (2, 3)
+    C = base.clone() if epi == 2 else torch.zeros(M, N, dtype=torch.float32 if out_f32 else tt)
+    Ad, Wd, Cd = dev(be, A_dev), dev(be, W), dev(be, C)
+    lnd = dev(be, ln) if ln is not None else None
+    be.check(be.lib.p5_op_skinny_gemm(dtype, amode, P(Ad), lda, P(lnd), P(Wd), K, P(Cd), N, M, N, K, epi, 1.0, 1e-6, be.stream_ptr()), "skinny")
+    sync(be)
+    err = (Cd.cpu().float() - ref).abs().max().item()
+    tol = 2e-4 * max(1.0, K ** 0.5) if (dtype == 0 or out_f32) else 3e-2 * max(1.0, float(ref.abs().max()))
+    if dtype == 1 and out_f32:
+        tol = 2e-3 * max(1.0, K ** 0.5)
+    assert err <= tol, f"skinny dtype={dtype} amode={amode} M={M} N={N} K={K} epi={epi}: err {err} > {tol}"
+    return err

@@ -150,3 +150,12 @@ def test_generate_truncated_by_max_length(emu):
 def test_fused_loss_matches_autograd_path(emu):
     cases.fused_loss_case(emu, O.T5Cfg.named("tiny"), 3, 11, 5, "fp32", 0.0)
     cases.fused_loss_case(emu, O.T5Cfg.named("tiny"), 2, 9, 4, "fp32", 0.1)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(0, 15, 128, 128, 0), (1, 15, 384, 128, 0), (1, 15, 256, 128, 1), (0, 15, 128, 256, 2), (0, 40, 96, 512, 2), (1, 40, 100, 512, 3), (1, 20, 40, 768, 0), (1, 18, 32, 1024, 0)])
+def test_skinny_gemm(emu, dtype, shape):
+    """decode-step projections (p5_decode2.h): plain / ReLU / atomic-accumulate epilogues, fused T5LayerNorm prologue, split-K,
+    column-tile widths 64 / 32 / 16 as d_model grows."""
+    amode, M, N, K, epi = shape
+    cases.skinny_gemm_case(emu, dtype, amode, M, N, K, epi)

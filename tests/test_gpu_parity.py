@@ -239,3 +239,12 @@ def test_bf16_large_L512_runs(hip):
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(nll).all() and torch.isfinite(m._grads).all() and float(m._grads.abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(0, 15, 128, 128, 0), (1, 15, 384, 128, 0), (1, 15, 256, 128, 1), (0, 15, 128, 256, 2), (0, 200, 512, 512, 2), (1, 40, 100, 512, 3), (0, 200, 512, 2048, 2), (1, 200, 2048, 512, 1), (1, 50, 72, 768, 0), (1, 30, 64, 1024, 0), (0, 37, 1024, 4096, 2)])
+def test_skinny_gemm(hip, dtype, shape):
+    """decode-step projections (p5_decode2.h): plain / ReLU / atomic-accumulate epilogues, fused T5LayerNorm prologue, split-K,
+    column-tile widths 64 / 32 / 16 as d_model grows."""
+    amode, M, N, K, epi = shape
+    cases.skinny_gemm_case(hip, dtype, amode, M, N, K, epi)
