@@ -78,7 +78,9 @@ def worker(local_rank, args, world_size, spawned):
     model = P5T5Native.from_pretrained(args.backbone, config=cfg, dtype=args.compute_dtype, device=device, seed=args.seed)
     if args.item_indexing == "collaborative":
         for ds in TrainSet.datasets:
-            tokenizer.add_tokens(sorted(set(ds.new_token)))
+            # first-occurrence order, duplicates dropped by add_tokens itself: the <CIk> token ids -- and so the rows of the
+            # embedding table -- are the reference's (main.py:190-192), which keeps collaborative checkpoints interchangeable
+            tokenizer.add_tokens(list(ds.new_token))
     model.resize_token_embeddings(len(tokenizer))
     if args.random_initialize == 1:
         random_initialization(model, tokenizer, args.backbone)
@@ -87,8 +89,13 @@ def worker(local_rank, args, world_size, spawned):
     runner = DistributedRunner(model, tokenizer, train_loader, valid_loader, device, args, rank)
     if args.train:
         runner.train()
-    else:
-        runner.test(args.model_path)
+    if world_size > 1:
+        dist.barrier()
+    # the reference always evaluates the SERIALISED checkpoint after training (main.py:143-147,221-225): with --valid_select 1
+    # that is the best-validation model, and the state-dict round trip is exercised either way
+    if rank == 0:
+        logging.info(f"Load model from {args.model_path}")
+    runner.test(args.model_path)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -100,6 +107,10 @@ def main(argv=None):
         worker(int(os.environ.get("LOCAL_RANK", 0)), args, int(os.environ["WORLD_SIZE"]), spawned=False)
         return
     gpus = [g for g in str(args.gpu).split(",") if g != ""]
+    # the reference exports CUDA_VISIBLE_DEVICES = --gpu before any device is touched (main.py:226-228); the ROCm runtime reads
+    # the same variable (and HIP_VISIBLE_DEVICES), so local rank r runs on the r-th id listed in --gpu
+    if gpus and not torch.cuda.is_initialized():
+        os.environ["CUDA_VISIBLE_DEVICES"] = ",".join(gpus if args.distributed else gpus[:1])
     n = min(len(gpus), torch.cuda.device_count()) if args.distributed else 1
     if n <= 1:
         worker(0, args, 1, spawned=True)

@@ -140,6 +140,7 @@ class P5T5Native(nn.Module):
         self._anchor = torch.zeros(1, device=backend.device, requires_grad=True)
         self.ddp_world = 1          # set by the runner: gradient all-reduce across ranks during backward
         self.ddp_group = None
+        self._ddp_sync = True       # False on all but the last micro-batch of a gradient-accumulation group
         self._pending = []
         self._side = None
         self._fold = None
@@ -389,6 +390,15 @@ class P5T5Native(nn.Module):
     def tie_weights(self):
         return None
 
+    def begin_micro_batch(self, first: bool, sync: bool):
+        """Gradient accumulation (--gradient_accumulation_steps > 1): every gradient kernel of the engine ADDS into the
+        arena (split-K atomics, partial-sum reductions, `+=`), the only overwrite is the clear at the start of a backward --
+        so a micro-batch other than the first tells the engine to skip that clear; `sync` = exchange gradients across ranks
+        in this backward (only the last micro-batch of a group does)."""
+        if not first:
+            self._lib.p5_engine_grads_zeroed(self._engine)
+        self._ddp_sync = bool(sync)
+
     # ------------------------------------------------------------------ RNG for dropout
     def set_dropout_seed(self, seed: int, step: int = 0):
         self._rng_cpu = [int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF]
@@ -429,7 +439,7 @@ class P5T5Native(nn.Module):
         if dnll is not None:
             dnll = dnll.to(torch.float32).contiguous()
         lib, eng, sp = self._lib, self._engine, self._be.stream_ptr()
-        if self.ddp_world > 1:
+        if self.ddp_world > 1 and self._ddp_sync:
             import torch.distributed as dist
             nst = lib.p5_backward_num_stages(eng)
             b, e = ctypes.c_int64(), ctypes.c_int64()

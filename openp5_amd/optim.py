@@ -38,7 +38,9 @@ class FusedAdamW:
             return self.lr
         return self.lr * linear_schedule_with_warmup(self.sched_steps, self.warmup_steps, self.total_steps)
 
-    def step(self):
+    def step(self, grad_accum: int = 1):
+        """`grad_accum`: the arena holds the SUM over that many micro-batches (and, after the all-reduce, over ranks); the
+        mean is taken by the update kernel's gradient scale."""
         mdl = self.model
         be, lib = mdl._be, mdl._lib
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
@@ -49,7 +51,7 @@ class FusedAdamW:
         if use_clip:
             be.check(lib.p5_grad_sumsq(P(mdl._grads), mdl._n, P(self.sumsq), sp), "p5_grad_sumsq")
         be.check(lib.p5_adamw_step(P(mdl._flat), P(mdl._grads), P(self.m), P(self.v), P(mdl._shadow), mdl._n,
-                                   P(self.sumsq) if use_clip else None, float(self.max_grad_norm or 0.0), 1.0 / world,
+                                   P(self.sumsq) if use_clip else None, float(self.max_grad_norm or 0.0), 1.0 / (world * max(1, int(grad_accum))),
                                    float(self.current_lr()), self.betas[0], self.betas[1], self.eps, self.wd, self.t, sp), "p5_adamw_step")
         mdl.mark_params_updated(shadow_fresh=mdl._shadow is not None)
         self.sched_steps += 1   # scheduler.step() (DistributedRunner.py:86)
@@ -61,7 +63,10 @@ class FusedAdamW:
         return math.sqrt(float(self.sumsq.double().sum().item())) / max(1, int(getattr(self.model, "ddp_world", 1)))
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t, "sched_steps": self.sched_steps}
+        return {"m": self.m, "v": self.v, "t": self.t, "sched_steps": self.sched_steps, "warmup_steps": self.warmup_steps,
+                "total_steps": self.total_steps}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = sd["t"]; self.sched_steps = sd["sched_steps"]
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        self.t, self.sched_steps = int(sd["t"]), int(sd["sched_steps"])

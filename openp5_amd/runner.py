@@ -50,6 +50,10 @@ def parse_runner_args(parser):
     parser.add_argument("--id_metrics", type=int, default=1, help="compare generated token ids with the gold ids on the device "
                         "instead of decoding to strings (same Hit/NDCG; 0 = the reference's string path).")
     parser.add_argument("--compute_dtype", type=str, default="bf16", help="bf16 (fast) or fp32 (parity) engine arithmetic")
+    parser.add_argument("--resume", type=int, default=0, help="continue from <model_path>.resume when it exists (weights + optimizer "
+                        "moments + schedule position + epoch/step + dropout and data-order state; the reference saves weights only).")
+    parser.add_argument("--save_steps", type=int, default=0, help="with --resume: also write the resume file every N optimizer steps "
+                        "(0 = at epoch ends only).")
     return parser
 
 
@@ -75,22 +79,35 @@ def masked_mean_loss(nll, output_attention):
     return (loss.sum(dim=1) / m.sum(dim=1).clamp(min=1)).mean()
 
 
-def training_step(model, optimizer, batch, alpha=2):
-    """One optimisation step of the reference loop (DistributedRunner.py:63-87): forward, masked-mean loss, backward,
-    clip + AdamW + scheduler (fused), zero_grad.  `batch` = (input_ids, whole_word_ids, attention_mask, labels,
-    output_attention) on the device.  With the native model the loss and its gradient seed are computed by the engine
+def training_step(model, optimizer, batch, alpha=2, micro=0, accum=1):
+    """One pass of the reference loop body (DistributedRunner.py:63-87): forward, masked-mean loss, backward, clip + AdamW +
+    scheduler (fused), zero_grad.  `batch` = (input_ids, whole_word_ids, attention_mask, labels, output_attention) on the
+    device.  With the native model the loss and its gradient seed are computed by the engine
     (`P5T5Native.loss_and_backward`: masked mean folded behind the CE kernel, no torch autograd graph); any other model
-    goes through the generic torch path."""
+    goes through the generic torch path.
+
+    `accum` > 1 = --gradient_accumulation_steps: micro-batch `micro` (0-based, within a group of `accum`) adds its gradients
+    to the arena (every gradient kernel accumulates; the arena clear at the start of a backward is skipped), ranks exchange
+    gradients on the LAST micro-batch only, and the optimizer steps once per group on the group mean (1/accum folded into the
+    AdamW gradient scale).  The reference only divides total_steps by this flag and still steps every batch
+    (SingleRunner.py:182), which drives its schedule to lr = 0 after 1/accum of the run; this is the intended behaviour."""
     input_ids, whole_ids, attn, output_ids, output_attention = batch[:5]
     fused = getattr(model, "loss_and_backward", None)
+    last = micro == accum - 1
+    if accum > 1 and fused is not None:
+        model.begin_micro_batch(first=micro == 0, sync=last)
     if fused is not None:
         loss = fused(input_ids, whole_ids, attn, output_ids, output_attention)
     else:
         out = model(input_ids=input_ids, whole_word_ids=whole_ids, attention_mask=attn, labels=output_ids, alpha=alpha, return_dict=True)
         loss = masked_mean_loss(out["loss"], output_attention)
-        loss.backward()
-    optimizer.step()          # clip_grad_norm_ + AdamW + scheduler.step, fused
-    model.zero_grad()
+        (loss / accum if accum > 1 else loss).backward()
+    if last:
+        if accum > 1 and fused is not None:
+            optimizer.step(grad_accum=accum)
+        else:
+            optimizer.step()          # clip_grad_norm_ + AdamW + scheduler.step, fused
+        model.zero_grad()
     return loss.detach()
 
 
@@ -128,6 +145,9 @@ class Prefetcher:
                     raise self.err
                 return
             yield item
+
+
+MAX_DEVICE_BEAMS = 64      # include/p5hip.h: p5_generate keeps <= 64 beams per batch item
 
 
 def _world():
@@ -185,15 +205,75 @@ class DistributedRunner:
     def _to_dev(self, batch):
         return [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in batch]
 
+    # ------------------------------------------------------------------ resume state
+    def _resume_path(self):
+        return str(self.args.model_path) + ".resume"
+
+    def _epoch_start_state(self):
+        """Everything the data order of an epoch is derived from, captured BEFORE the epoch's prompt re-sampling and in-place
+        cumulative shuffle (MultiTaskDataset.py:189-195): restoring it and replaying the epoch's setup reproduces the batch
+        stream exactly, so a mid-epoch resume only has to skip the batches already consumed."""
+        import random
+        state = {"py_random": random.getstate(), "np_random": np.random.get_state(), "torch_rng": torch.get_rng_state()}
+        if self.train_loader is not None:
+            state["task_data"] = [{t: list(v) for t, v in ds.task_data.items()} for ds in self.train_loader.dataset.datasets]
+        return state
+
+    def _restore_epoch_start(self, state):
+        import random
+        random.setstate(state["py_random"])
+        np.random.set_state(state["np_random"])
+        torch.set_rng_state(state["torch_rng"])
+        for ds, td in zip(self.train_loader.dataset.datasets, state.get("task_data", [])):
+            ds.task_data = {t: list(v) for t, v in td.items()}
+
+    def save_checkpoint(self, path, epoch, step_in_epoch, epoch_start, extra=None):
+        """Weights (HF key layout, as utils.save_model) + optimizer moments / step / schedule position + epoch, step inside
+        the epoch, dropout counter and the epoch-start data state.  Written by rank 0 (all ranks hold identical state)."""
+        if self.rank != 0:
+            return
+        ck = {"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+              "optimizer": {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
+              "epoch": int(epoch), "step_in_epoch": int(step_in_epoch), "epoch_start": epoch_start,
+              "dropout_rng": list(getattr(self.model, "_rng_cpu", [0, 0])), "world": self.world}
+        ck.update(extra or {})
+        tmp = str(path) + ".tmp"
+        torch.save(ck, tmp)
+        import os
+        os.replace(tmp, path)
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["model"], strict=False)
+        self.optimizer.load_state_dict(ck["optimizer"])
+        if hasattr(self.model, "set_dropout_seed"):
+            self.model.set_dropout_seed(*ck["dropout_rng"])
+        return ck
+
     # ------------------------------------------------------------------ training
     def train(self):
+        import os
         self.model.zero_grad()
         train_losses, valid_losses, best_epoch = [], [], -1
-        if self.test_before_train > 0:
+        accum = max(1, int(self.args.gradient_accumulation_steps))
+        resume = int(getattr(self.args, "resume", 0)) > 0
+        save_steps = int(getattr(self.args, "save_steps", 0))
+        start_epoch, skip_batches, pending_start = 0, 0, None
+        if resume and os.path.exists(self._resume_path()):
+            ck = self.load_checkpoint(self._resume_path())
+            start_epoch, skip_batches, pending_start = ck["epoch"], ck["step_in_epoch"], ck["epoch_start"]
+            train_losses, valid_losses, best_epoch = ck.get("train_losses", []), ck.get("valid_losses", []), ck.get("best_epoch", -1)
+            if self.rank == 0:
+                logging.info(f"Resume from {self._resume_path()}: epoch {start_epoch + 1}, batch {skip_batches}, optimizer step {self.optimizer.t}")
+        elif self.test_before_train > 0:
             self.test()
-        for epoch in range(self.args.epochs):
+        for epoch in range(start_epoch, self.args.epochs):
             if self.rank == 0:
                 logging.info(f"Start training for epoch {epoch + 1}")
+            if pending_start is not None:
+                self._restore_epoch_start(pending_start)
+            epoch_start = self._epoch_start_state() if resume else None
+            pending_start = None
             if self.regenerate_candidate or self.reconstruct_data:
                 for ds in self.train_loader.dataset.datasets:
                     if self.regenerate_candidate and hasattr(ds, "generate_candidates"):
@@ -202,13 +282,25 @@ class DistributedRunner:
             if hasattr(self.train_loader.sampler, "set_epoch"):
                 self.train_loader.sampler.set_epoch(epoch)
             self.model.train()
-            losses, n_samples = [], 0
+            losses, n_samples, n_batches = [], 0, 0
             t0 = time.perf_counter()
             for batch in Prefetcher(self.train_loader, pin=torch.cuda.is_available()):
+                n_batches += 1
+                if n_batches <= skip_batches:         # already consumed before the checkpoint was written
+                    continue
                 input_ids, attn, whole_ids, output_ids, output_attention = self._to_dev(batch)[:5]
-                loss = training_step(self.model, self.optimizer, (input_ids, whole_ids, attn, output_ids, output_attention), self.args.alpha)
+                micro = (n_batches - 1) % accum
+                loss = training_step(self.model, self.optimizer, (input_ids, whole_ids, attn, output_ids, output_attention), self.args.alpha,
+                                     micro=micro, accum=accum)
                 losses.append(loss)
                 n_samples += input_ids.shape[0]
+                if resume and save_steps > 0 and micro == accum - 1 and self.optimizer.t % save_steps == 0:
+                    self.save_checkpoint(self._resume_path(), epoch, n_batches, epoch_start,
+                                         {"train_losses": train_losses, "valid_losses": valid_losses, "best_epoch": best_epoch})
+            skip_batches = 0
+            if n_batches % accum:                    # a trailing partial group: step on what was accumulated
+                self.optimizer.step(grad_accum=n_batches % accum)
+                self.model.zero_grad()
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -232,6 +324,10 @@ class DistributedRunner:
             if self.test_epoch > 0 and (epoch + 1) % self.test_epoch == 0:
                 self.model.eval()
                 self.test()
+            if resume:
+                # the next epoch starts from the data state as it is NOW (prompts re-sampled, lists permuted cumulatively)
+                self.save_checkpoint(self._resume_path(), epoch + 1, 0, self._epoch_start_state(),
+                                     {"train_losses": train_losses, "valid_losses": valid_losses, "best_epoch": best_epoch})
             if self.world > 1:
                 dist.barrier()
         if self.rank == 0:
@@ -387,10 +483,15 @@ class DistributedRunner:
         trie, ct, index = self._dataset_trie(ds)
         fn = prefix_allowed_tokens_fn(trie)
         width = self.generate_num + ds.max_positive
-        if width > 64:
-            raise ValueError(f"--test_filtered_batch 1 needs num_beams = {self.generate_num} + max history {ds.max_positive} = {width} > 64 "
-                             "(the device beam search keeps <= 64 beams per user); use --test_filtered_batch 0, which excludes each "
-                             "user's history inside the constrained search and works at any batch size")
+        if width > MAX_DEVICE_BEAMS:
+            # the reference's DEFAULT flag (SingleRunner.py:39) must keep working on real histories (ML-1M: hundreds of items):
+            # instead of a beam of generate_num + max_history, exclude each user's history INSIDE the constrained search
+            # (shared device trie + per-user excluded-node bitmap) -- history never appears, the top generate_num are kept
+            if self.rank == 0:
+                logging.warning(f"--test_filtered_batch 1 would need num_beams = {self.generate_num} + max history {ds.max_positive} = "
+                                f"{width} > {MAX_DEVICE_BEAMS} (device beam limit); excluding each user's history inside the search instead "
+                                "(the --test_filtered_batch 0 protocol, batched)")
+            return self.test_dataset_task_filtered(testloader)
         seq2idx = None
         if self.id_metrics:     # item token tuple (without the decoder start) -> item index: no batch_decode, no string sets
             seq2idx = self.__dict__.setdefault("_seq2idx_cache", {}).get(ds.dataset)

@@ -413,8 +413,14 @@ def adamw_hf_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, t: int, lr: float,
 def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_ids: Tensor,
                 attention_mask: Tensor, allowed_fn: Callable[[int, Tensor], List[int]], num_beams: int,
                 max_length: int, num_return_sequences: Optional[int] = None,
-                length_penalty: float = 1.0) -> Tuple[Tensor, Tensor]:
+                length_penalty: float = 1.0, decision_margins: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """Returns (sequences [B*K, <=max_length] int64 starting with pad(0), sequences_scores [B*K]).
+
+    decision_margins (test instrumentation, optional dict, filled in place): for every batch item the smallest score margin by
+    which this search took any of its discrete decisions -- "set" [B]: membership of the top-2K candidates, the K running beams,
+    the rank < K condition on EOS candidates, the top-K merge of finished hypotheses, the early-stop comparison;
+    "order" [B, nret-1]: gaps between consecutive final scores.  A lower-precision search whose scores stay within half of a
+    margin of these cannot decide differently; where it does differ, the margin says whether it was allowed to.
 
     Per step: log_softmax over the FULL vocab, then -inf outside allowed_fn(batch_id, prefix)
     (not renormalised), + running score, top-2K over K*V, EOS candidates ranked < K finish with
@@ -442,6 +448,17 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
     run_len_dummy = None
     cur_len = 1
     neg_inf = float("-inf")
+    LIVE = -1.0e8                                            # scores above this are real candidates (dead ones carry <= -1e9)
+    set_margin = torch.full((B,), float("inf"), dtype=torch.float64)
+
+    def _gap(hi: Tensor, lo: Tensor, cond: Optional[Tensor] = None):
+        nonlocal set_margin
+        ok = (hi > LIVE) & (lo > LIVE)
+        if cond is not None:
+            ok = ok & cond
+        g = torch.where(ok, (hi - lo).abs().to(torch.float64), torch.full_like(hi, float("inf"), dtype=torch.float64))
+        set_margin = torch.minimum(set_margin, g)
+
     while True:
         flat = running[:, :, :cur_len].reshape(B * K, cur_len)
         dec = decoder_forward(P, cfg, flat, enc_k, mask_k)
@@ -456,6 +473,10 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         lp = (lp + maskv).to(enc.dtype)
         lp = lp.view(B, K, V) + running_scores[:, :, None]
         lp = lp.view(B, K * V)
+        if decision_margins is not None:
+            wide = torch.topk(lp, k=min(beams_to_keep + 1, lp.shape[1]))[0]
+            if wide.shape[1] > beams_to_keep:
+                _gap(wide[:, beams_to_keep - 1], wide[:, beams_to_keep], unsat[:, 0])               # membership of the top-2K
         topk_lp, topk_idx = torch.topk(lp, k=beams_to_keep)
         topk_beam = topk_idx // V
         topk_tok = topk_idx % V
@@ -465,6 +486,10 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         # e. running beams for next iteration
         run_lp = topk_lp + hits.to(topk_lp.dtype) * -1.0e9
         nxt = torch.topk(run_lp, k=K)[1]
+        if decision_margins is not None:
+            rs = torch.sort(run_lp, dim=1, descending=True)[0]
+            _gap(rs[:, K - 1], rs[:, K], unsat[:, 0])                                              # the K running beams
+            _gap(topk_lp[:, K - 1], topk_lp[:, K], unsat[:, 0] & (hits[:, K - 1] | hits[:, K]))    # EOS candidate ranked < K or not
         running = torch.take_along_dim(topk_seq, nxt[:, :, None], dim=1)
         running_scores = torch.take_along_dim(run_lp, nxt, dim=1)
         # f. finished beams
@@ -477,6 +502,9 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         m_fin = torch.cat([is_finished, just], dim=1)
         m_len = torch.cat([gen_len, torch.full((B, beams_to_keep), cur_len, dtype=torch.long)], dim=1)
         sel = torch.topk(m_sc, k=K)[1]
+        if decision_margins is not None:
+            ms = torch.sort(m_sc, dim=1, descending=True)[0]
+            _gap(ms[:, K - 1], ms[:, K])                                                           # top-K merge of finished hypotheses
         sequences = torch.take_along_dim(m_seq, sel[:, :, None], dim=1)
         beam_scores = torch.take_along_dim(m_sc, sel, dim=1)
         is_finished = torch.take_along_dim(m_fin, sel, dim=1)
@@ -485,10 +513,18 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         # g. early-stop heuristic (early_stopping=False)
         best_possible = running_scores[:, :1] / ((cur_len - 1) ** length_penalty)
         worst_fin = torch.where(is_finished, beam_scores.min(dim=1, keepdim=True)[0], torch.tensor(-1.0e9, dtype=beam_scores.dtype))
+        if decision_margins is not None:
+            _gap(best_possible[:, 0], worst_fin.min(dim=1)[0], unsat[:, 0])                        # early-stop comparison (all K finished)
         unsat = unsat & torch.any(best_possible > worst_fin, dim=-1, keepdim=True)
         if not (bool(unsat.any()) and not bool(hits.all())):
             break
     seqs = sequences[:, :nret, :].reshape(B * nret, max_length)
     scores = beam_scores[:, :nret].reshape(B * nret)
     out_len = 1 + int(gen_len[:, :nret].max())
+    if decision_margins is not None:
+        fs = beam_scores[:, :nret].to(torch.float64)
+        og = (fs[:, :-1] - fs[:, 1:]).abs()
+        og = torch.where((fs[:, :-1] > LIVE) & (fs[:, 1:] > LIVE), og, torch.full_like(og, float("inf")))
+        decision_margins["set"] = set_margin
+        decision_margins["order"] = og
     return seqs[:, :out_len], scores

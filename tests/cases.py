@@ -576,21 +576,64 @@ def engine_gen_fn(model):
     return fn
 
 
-def oracle_gen_fn(params, ocfg):
+def oracle_gen_fn(params, ocfg, margins=None):
+    """`margins` (optional list): receives, per user in evaluation order, (set_margin, [gaps between consecutive final scores])
+    -- the smallest score margins by which the oracle's beam search took its decisions for that user (oracle/t5_oracle.py)."""
     def fn(batch, trie, ct, K, max_length):
+        dm = {} if margins is not None else None
         with torch.no_grad():
-            return O.beam_search(params, ocfg, batch[0], batch[2], batch[1], lambda b, s: trie.get(s.tolist()), K, max_length)
+            out = O.beam_search(params, ocfg, batch[0], batch[2], batch[1], lambda b, s: trie.get(s.tolist()), K, max_length,
+                                decision_margins=dm)
+        if margins is not None:
+            for b in range(batch[0].shape[0]):
+                margins.append((float(dm["set"][b]), [float(x) for x in dm["order"][b]]))
+        return out
     return fn
 
 
-def compare_rankings(a, b, K_list=(5, 10)):
-    """users whose ranked lists / gold ranks differ between two evaluations of the same loaders."""
-    stats = {"users": 0, "identical_lists": 0, "same_topk_set": {k: 0 for k in K_list}, "same_gold_rank": 0, "max_score_diff": 0.0, "diff_users": []}
+def robust_users(rankings_oracle, margins, tol):
+    """Which users' results a lower-precision search MUST reproduce, given score errors below tol / 2.
+    list-robust: every decision of the oracle's search for the user (candidate sets AND final order) had margin > tol;
+    metric-robust: the candidate-set decisions had margin > tol and the gold item's final score is separated by > tol from its
+    neighbours in the list (or the gold item is absent), so Hit@k / NDCG@k of the user cannot move."""
+    flat = [u for users in rankings_oracle for u in users]
+    assert len(flat) == len(margins)
+    out = []
+    for (gold, ranked, scores), (set_m, gaps) in zip(flat, margins):
+        list_ok = set_m > tol and all(g > tol for g in gaps)
+        if gold in ranked:
+            k = ranked.index(gold)
+            near = [gaps[j] for j in (k - 1, k) if 0 <= j < len(gaps)]
+            metric_ok = set_m > tol and all(g > tol for g in near)
+        else:
+            metric_ok = set_m > tol
+        out.append((list_ok, metric_ok))
+    return out
+
+
+def lists_equal_up_to_ties(ra, rb, sb, tol):
+    """ranked list `ra` equals the reference list `rb` up to reordering items whose REFERENCE scores `sb` differ by <= tol:
+    wherever the two lists disagree, the item `ra` puts there must sit in `rb` at a position whose score is within tol."""
+    if len(ra) != len(rb):
+        return False
+    for i, (x, y) in enumerate(zip(ra, rb)):
+        if x == y:
+            continue
+        if x not in rb or abs(sb[rb.index(x)] - sb[i]) > tol:
+            return False
+    return True
+
+
+def compare_rankings(a, b, K_list=(5, 10), tie_tol=0.0):
+    """users whose ranked lists / gold ranks differ between two evaluations of the same loaders (`b` = the reference)."""
+    stats = {"users": 0, "identical_lists": 0, "identical_up_to_ties": 0, "same_topk_set": {k: 0 for k in K_list}, "same_gold_rank": 0,
+             "max_score_diff": 0.0, "diff_users": []}
     for la, lb in zip(a, b):
         for i, ((ga, ra, sa), (gb, rb, sb)) in enumerate(zip(la, lb)):
             assert ga == gb
             stats["users"] += 1
             stats["identical_lists"] += int(ra == rb)
+            stats["identical_up_to_ties"] += int(lists_equal_up_to_ties(list(ra), list(rb), list(sb), tie_tol))
             for k in K_list:
                 stats["same_topk_set"][k] += int(set(ra[:k]) == set(rb[:k]))
             rka = ra.index(ga) if ga in ra else -1

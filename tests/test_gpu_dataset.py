@@ -10,8 +10,10 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-TIE_TOL = 0.02     # log-prob score gap below which two items count as tied for the bf16 engine (5x the largest score
-                   # difference measured between the bf16 engine and the oracle on this set-up, 3.7e-3)
+FP32_TIE_TOL = 1e-4   # fp32 engine vs oracle: two items whose oracle scores differ by less than the fp32 score tolerance of the
+                      # generation tests (1e-4) may swap places (measured: 2 of 240 users, score gaps <= 1.2e-5)
+BF16_SCORE_TOL = 0.01   # bf16 engine: largest |score - oracle score| allowed (measured 2.4e-3 .. 3.7e-3 on this set-up)
+TIE_TOL = 0.02          # decision margin of the ORACLE below which the bf16 engine may decide differently (2 x BF16_SCORE_TOL)
 
 
 def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
@@ -28,30 +30,48 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     m32.eval()
     r_fp32 = cases.collect_rankings(runner, cases.engine_gen_fn(m32), K)
     ocfg = O.T5Cfg.named("t5-small", dropout=0.0, vocab_size=model.config.vocab_size)
-    r_or = cases.collect_rankings(runner, cases.oracle_gen_fn({k: sd[k] for k in O.param_shapes(ocfg)}, ocfg), K)
+    margins = []
+    r_or = cases.collect_rankings(runner, cases.oracle_gen_fn({k: sd[k] for k in O.param_shapes(ocfg)}, ocfg, margins), K)
     m_bf16, m_fp32, m_or = cases.rankings_metrics(r_bf16), cases.rankings_metrics(r_fp32), cases.rankings_metrics(r_or)
-    c32, c16 = cases.compare_rankings(r_fp32, r_or), cases.compare_rankings(r_bf16, r_or)
+    c32, c16 = cases.compare_rankings(r_fp32, r_or, tie_tol=FP32_TIE_TOL), cases.compare_rankings(r_bf16, r_or, tie_tol=TIE_TOL)
     print("[dataset] oracle metrics", m_or)
+    print("[dataset] bf16 metrics  ", m_bf16)
     print("[dataset] fp32 engine vs oracle", {k: v for k, v in c32.items()})
     print("[dataset] bf16 engine vs oracle", {k: v for k, v in c16.items()})
     assert sum(len(u) for u in r_or) >= 200 and any(v > 0 for m in m_or for v in m.values())
-    # fp32 engine: every user's ranked list and every metric identical to the oracle
-    assert c32["identical_lists"] == c32["users"] and c32["max_score_diff"] <= 1e-4
-    assert m_fp32 == m_or
-    # bf16 engine: Hit@5/10 and NDCG@5/10 equal to the oracle's; a user whose gold item sits at a different rank must be a
-    # near-tie in the ORACLE's own scores (tie report), and only such users may move a metric
-    tie_only = True
-    for la, lo in zip(r_bf16, r_or):
-        for (g, ra, sa), (_, ro, so) in zip(la, lo):
-            ka = ra.index(g) if g in ra else -1
-            ko = ro.index(g) if g in ro else -1
-            if ka == ko:
-                continue
-            lo_, hi_ = sorted((ka if ka >= 0 else K - 1, ko if ko >= 0 else K - 1))
-            gap = abs(so[lo_] - so[min(hi_, K - 1)])
-            print(f"[dataset] tie report: gold rank {ko} (oracle) vs {ka} (bf16), oracle score gap {gap:.4f}")
-            tie_only = tie_only and gap <= TIE_TOL
-    assert tie_only, "bf16 ranking moved a gold item across a score gap larger than the tie tolerance"
-    if c16["same_gold_rank"] == c16["users"]:
+    # fp32 engine: every user's ranked list identical to the oracle's up to swaps of items the ORACLE scores within 1e-4 of each
+    # other, the gold item at the same rank for every user, hence every Hit@k / NDCG@k identical
+    assert c32["identical_up_to_ties"] == c32["users"] and c32["max_score_diff"] <= 1e-4, c32
+    assert c32["identical_lists"] >= 0.98 * c32["users"], c32
+    assert c32["same_gold_rank"] == c32["users"] and m_fp32 == m_or
+    # bf16 engine.  Its scores are within BF16_SCORE_TOL of the oracle's; a beam search is a sequence of discrete decisions, so
+    # it must reproduce the oracle exactly wherever the oracle took every decision by a margin larger than TIE_TOL
+    # (= 2 x BF16_SCORE_TOL with head room) and may differ only where the oracle itself was that close to deciding otherwise:
+    #   * list-robust users   -> identical ranked lists;
+    #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
+    #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
+    assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
+    rob = cases.robust_users(r_or, margins, TIE_TOL)
+    flat_b, flat_o = [u for us in r_bf16 for u in us], [u for us in r_or for u in us]
+    n_list = n_metric = n_fragile_moved = 0
+    for (list_ok, metric_ok), (g, ra, sa), (_, ro, so), (set_m, gaps) in zip(rob, flat_b, flat_o, margins):
+        ka, ko = (ra.index(g) if g in ra else -1), (ro.index(g) if g in ro else -1)
+        if list_ok:
+            n_list += 1
+            assert ra == ro, ("list-robust user differs", set_m, gaps, ra, ro)
+        if metric_ok:
+            n_metric += 1
+            assert ka == ko, ("metric-robust user: gold rank moved", set_m, gaps, ka, ko)
+        elif ka != ko:
+            n_fragile_moved += 1
+            print(f"[dataset] tie report: gold rank {ko} (oracle) vs {ka} (bf16); oracle's smallest set margin {set_m:.4f}, "
+                  f"final-score gaps around the gold item {[round(x, 4) for x in gaps[max(0, ko - 1):ko + 1]] if ko >= 0 else '-'}")
+    n = len(rob)
+    print(f"[dataset] bf16: {n_list}/{n} users list-robust (all identical), {n_metric}/{n} metric-robust (gold rank identical), "
+          f"{n - n_metric} fragile of which {n_fragile_moved} moved")
+    assert n_metric >= 0.3 * n, "the robust population is too small for the assertion to mean anything"
+    for mb, mo in zip(m_bf16, m_or):      # dataset-level metrics: equal up to the fragile users that moved
+        for k in mo:
+            assert abs(mb[k] - mo[k]) <= n_fragile_moved / (n / len(m_or)) + 1e-12, (k, mb[k], mo[k])
+    if n_fragile_moved == 0:
         assert m_bf16 == m_or, (m_bf16, m_or)
-    assert c16["same_topk_set"][10] >= 0.95 * c16["users"] and c16["max_score_diff"] <= 0.05

@@ -164,3 +164,233 @@ def test_data_parallel_gloo(emu, tmp_path):
     m._grads.copy_(0.5 * (gs[0] + gs[1]))
     opt.step()
     assert torch.allclose(m._flat, r0["flat"], atol=1e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient accumulation, resume, filtered-batch fallback, world-2 runner, torch DDP wrapper
+# ---------------------------------------------------------------------------------------------------------------------
+def _fixed_batches(tok, n, B=4, L=10, T=4, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        ids = torch.randint(3, len(tok), (B, L), generator=g)
+        labels = torch.randint(3, len(tok), (B, T), generator=g)
+        oa = torch.ones_like(labels)
+        oa[0, -1] = 0
+        out.append((ids, torch.zeros_like(ids), torch.ones_like(ids), labels, oa))
+    return out
+
+
+def test_gradient_accumulation_equals_big_batch(emu):
+    """--gradient_accumulation_steps 2 over two micro-batches == one step on their concatenation (the masked-mean loss is a
+    mean over rows, both micro-batches have the same number of rows): same parameters after the step.  The reference only
+    rescales total_steps with this flag (SingleRunner.py:182); this is the intended behaviour."""
+    from openp5_amd.runner import training_step
+    tok = build_offline_tokenizer(VOCAB)
+    b0, b1 = _fixed_batches(tok, 2)
+    big = tuple(torch.cat([x, y]) for x, y in zip(b0, b1))
+    ma, mb = tiny_model(emu, len(tok), seed=5), tiny_model(emu, len(tok), seed=5)
+    oa, ob = FusedAdamW(ma, lr=1e-2, max_grad_norm=1.0), FusedAdamW(mb, lr=1e-2, max_grad_norm=1.0)
+    ma.eval(); mb.eval()
+    training_step(ma, oa, b0, micro=0, accum=2)
+    assert oa.t == 0 and float(ma._grads.abs().sum()) > 0          # no optimizer step, gradients kept
+    training_step(ma, oa, b1, micro=1, accum=2)
+    training_step(mb, ob, big)
+    assert oa.t == 1 and ob.t == 1
+    assert torch.allclose(ma._flat, mb._flat, atol=2e-6, rtol=1e-5), float((ma._flat - mb._flat).abs().max())
+    assert float(ma._grads.abs().sum()) == 0.0                      # zero_grad after the group
+
+
+def test_resume_is_exact(emu, tmp_path):
+    """train 2 epochs straight == train 1 epoch, save the resume file, build everything anew, --resume, train the 2nd epoch:
+    identical parameters and optimizer moments (weights + m/v/t + schedule position + dropout counter + data order)."""
+    tok = build_offline_tokenizer(VOCAB)
+
+    def build(epochs, extra=()):
+        args = make_args(str(tmp_path), ["--epochs", str(epochs), "--test_before_train", "0", "--test_epoch", "0", "--batch_size", "8",
+                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra))
+        args.model_path = str(tmp_path / "m.pt")
+        random.seed(0)
+        train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+        loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                            collate_fn=Collator(tok))
+        model = tiny_model(emu, len(tok), dropout=0.1, seed=9)
+        model.set_dropout_seed(77, 0)
+        return DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, 0)
+
+    straight = build(2)
+    straight.optimizer.total_steps = 2 * len(straight.train_loader)         # same schedule in all runs
+    l2 = straight.train()
+    first = build(1, ["--resume", "1"])
+    first.optimizer.total_steps = straight.optimizer.total_steps
+    first.optimizer.warmup_steps = straight.optimizer.warmup_steps
+    l1 = first.train()
+    assert os.path.exists(str(tmp_path / "m.pt") + ".resume")
+    second = build(2, ["--resume", "1"])
+    second.optimizer.total_steps = straight.optimizer.total_steps
+    second.optimizer.warmup_steps = straight.optimizer.warmup_steps
+    l12 = second.train()
+    assert second.optimizer.t == straight.optimizer.t and second.optimizer.sched_steps == straight.optimizer.sched_steps
+    assert torch.equal(second.model._flat, straight.model._flat)
+    assert torch.equal(second.optimizer.m, straight.optimizer.m) and torch.equal(second.optimizer.v, straight.optimizer.v)
+    assert l12 == l2 and l1 == l2[:1]
+
+
+def test_resume_mid_epoch_is_exact(emu, tmp_path):
+    """--save_steps: a resume file written in the MIDDLE of an epoch replays the epoch's data order and skips the batches
+    already consumed."""
+    tok = build_offline_tokenizer(VOCAB)
+
+    def build(extra=()):
+        args = make_args(str(tmp_path), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--batch_size", "8",
+                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra))
+        args.model_path = str(tmp_path / "m.pt")
+        random.seed(0)
+        train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+        loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                            collate_fn=Collator(tok))
+        model = tiny_model(emu, len(tok), dropout=0.1, seed=9)
+        model.set_dropout_seed(77, 0)
+        return DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, 0)
+
+    straight = build()
+    straight.train()
+    n = straight.optimizer.t
+    assert n >= 6
+
+    class Stop(Exception):
+        pass
+
+    part = build(["--resume", "1", "--save_steps", "3"])
+    orig = part.save_checkpoint
+
+    def save_then_die(path, epoch, step, start, extra=None):
+        orig(path, epoch, step, start, extra)
+        if step == 3:
+            raise Stop()
+    part.save_checkpoint = save_then_die
+    with pytest.raises(Stop):
+        part.train()
+    rest = build(["--resume", "1", "--save_steps", "1000"])
+    rest.train()
+    assert rest.optimizer.t == n
+    assert torch.equal(rest.model._flat, straight.model._flat)
+
+
+def test_filtered_batch_falls_back_beyond_device_beams(emu, tmp_path, monkeypatch):
+    """--test_filtered 1 --test_filtered_batch 1 (the reference's default, SingleRunner.py:39) with generate_num + max history
+    beyond the device beam limit must not raise: it evaluates with per-user history exclusion inside the search."""
+    import openp5_amd.runner as R
+    tok = build_offline_tokenizer(VOCAB)
+    flags = ["--test_filtered", "1", "--eval_batch_size", "6"]
+    monkeypatch.setattr(R, "MAX_DEVICE_BEAMS", 4)
+    a = _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "1"]).test()
+    monkeypatch.setattr(R, "MAX_DEVICE_BEAMS", 64)
+    # (the collator of the per-user protocol computes whole-word ids row by row; the fallback keeps the batch collator of the
+    #  widened-beam protocol, so compare against the same loaders run through the exclusion path)
+    r = _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "1"])
+    b = [r.test_dataset_task_filtered(loader) for loader in r.testloaders]
+    assert a == b and all(0.0 <= v <= 1.0 for res in a for v in res.values())
+
+
+def _world2_runner_worker(rank, world, port, tmp, _):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.emu.emu_backend import emu_backend
+    be = emu_backend()
+    tok = build_offline_tokenizer(VOCAB)
+    args = make_args(os.path.join(tmp, f"r{rank}"), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "1", "--metrics", "hit@5,ndcg@5",
+                                                    "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3",
+                                                    "--distributed", "1"])
+    args.rank = rank
+    args.model_path = os.path.join(tmp, f"m{rank}.pt")
+    random.seed(0)
+    train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+    sampler = DistMultiDataTaskSampler(train, args.batch_size, world, rank, args.seed, shuffle=True)
+    loader = DataLoader(train, sampler=sampler, batch_size=args.batch_size, collate_fn=Collator(tok))
+    model = tiny_model(be, len(tok), seed=3)
+    runner = DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, rank)
+    assert runner.world == 2 and all(l.sampler is not None and l.sampler.num_replicas == 2 for l in runner.testloaders)
+    losses = runner.train()                                  # DistMultiDataTaskSampler shards + gradient all-reduce + epoch-loss all-reduce
+    res = runner.test()                                      # DistributedSampler over the test users + metric all-reduce
+    n_local = [len(list(iter(l.sampler))) for l in runner.testloaders]
+    torch.save({"flat": model._flat.clone(), "res": res, "losses": losses, "n_local": n_local,
+                "idx": [list(iter(l.sampler)) for l in runner.testloaders]}, os.path.join(tmp, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_runner_train_and_test(emu, tmp_path):
+    """a12/a16/e2: `runner.train()` + `runner.test()` with world_size 2 over gloo -- DistMultiDataTaskSampler sharding
+    (DistMultiDataTaskSampler.py:30-33), gradient all-reduce, DistributedSampler evaluation (DistributedRunner.py:186) and the
+    metric all-reduce (:389-395).  Both ranks end with bit-identical parameters and identical (all-reduced) metrics, and the
+    metrics equal a single-process evaluation of the same weights over the union of the two ranks' user shards."""
+    world, port = 2, 31000 + random.randint(0, 2000)
+    for r in range(world):
+        os.makedirs(tmp_path / f"r{r}", exist_ok=True)
+    mp.spawn(_world2_runner_worker, args=(world, port, str(tmp_path), None), nprocs=world, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt", weights_only=False), torch.load(tmp_path / "w1.pt", weights_only=False)
+    assert torch.equal(w0["flat"], w1["flat"]), "ranks diverged during runner.train()"
+    assert w0["res"] == w1["res"] and len(w0["res"]) == 2
+    assert len(w0["losses"]) == 1 and w1["losses"] == []           # only rank 0 records the (all-reduced) epoch loss
+    for i0, i1, tl_n in zip(w0["idx"], w1["idx"], (30, 30)):
+        assert len(i0) == len(i1) == (tl_n + 1) // 2 and set(i0) | set(i1) == set(range(tl_n))     # DistributedSampler shards
+    # single-process evaluation of the same weights on the users rank 0 and rank 1 saw (DistributedSampler pads by repetition:
+    # a few users are counted twice, SURVEY.md App. B #11 -- reproduce exactly that multiset)
+    tok = build_offline_tokenizer(VOCAB)
+    args = make_args(str(tmp_path / "single"), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics", "hit@5,ndcg@5",
+                                                "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3"])
+    random.seed(0)
+    train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+    loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                        collate_fn=Collator(tok))
+    model = tiny_model(emu, len(tok), seed=3)
+    with torch.no_grad():
+        model._flat.copy_(w0["flat"])
+    model.mark_params_updated()
+    single = DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, 0)
+    from torch.utils.data import Subset
+    for li, tl in enumerate(single.testloaders):
+        sums, n = 0, 0
+        for idx in (w0["idx"][li], w1["idx"][li]):
+            sub = DataLoader(Subset(tl.dataset, idx), batch_size=4, collate_fn=tl.collate_fn, shuffle=False)
+            ds = tl.dataset
+            trie, ct, _ = single._dataset_trie(ds)
+            from openp5_amd import evaluate
+            for batch in sub:
+                rel = single._generate_ids(batch, single.generate_num, 50, trie=ct)
+                sums = sums + evaluate.get_metrics_results_ids(rel, single.metrics)
+                n += len(rel)
+        want = (torch.as_tensor(sums, dtype=torch.float64) / n).tolist()
+        got = [w0["res"][li][m] for m in single.metrics]
+        assert got == pytest.approx(want, abs=1e-12), (li, got, want)
+
+
+def test_torch_ddp_wrapper_is_inert(emu):
+    """the reference wraps the model in torch DDP and calls `.module(...)` (DistributedRunner.py:26,63).
+    Wrapping P5T5Native the same way must work -- the wrapper finds the parameters, `.module` is the native model and drives
+    the engine -- while the gradient exchange stays with the engine's staged backward (the wrapper's reducer never fires when
+    `.module` is called)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    port = 33000 + random.randint(0, 2000)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tok = build_offline_tokenizer(VOCAB)
+        model = tiny_model(emu, len(tok), seed=4)
+        ddp = DDP(model, find_unused_parameters=True)
+        assert ddp.module is model and len(list(ddp.parameters())) == len(list(model.parameters()))
+        (ids, ww, mask, labels, oa), = _fixed_batches(tok, 1)
+        model.eval()
+        nll = ddp.module(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels, alpha=2, return_dict=True)["loss"]
+        masked_mean_loss(nll, oa).backward()
+        g = model._grads.clone()
+        assert float(g.abs().sum()) > 0 and all(p.grad is not None for p in ddp.module.parameters())
+        ref = tiny_model(emu, len(tok), seed=4)
+        ref.eval()
+        masked_mean_loss(ref(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"], oa).backward()
+        assert torch.equal(g, ref._grads)
+        sd = ddp.module.state_dict()
+        assert "lm_head.weight" in sd
+    finally:
+        dist.destroy_process_group()
