@@ -328,6 +328,18 @@ def config_legs(be, device, dtype):
         except Exception as ex:      # a leg must never take the headline down
             legs[key] = {"error": repr(ex)[:300]}
     try:
+        # C2 generation in the fp32 parity mode: the mode whose ranked lists are identical to the fp32 oracle's for every user
+        # (tests/test_gpu_dataset.py); the bf16 headline number is the fast mode, whose lists may differ where the oracle's own
+        # decision margins are below the bf16 score tolerance
+        cfg, model, _ = build_model("t5-small", "fp32", device, be, 1, 0)
+        gdt, dec_len, _ = time_generation(model, 20, 10, 128, synth_item_trie(3416, 7), 30, 5, 1, device, 500)
+        legs["c2_generation_fp32_parity_mode"] = {"items_per_s": 20 * 10 * 5 / gdt, "ms_per_batch": gdt / 5 * 1e3, "users_per_batch": 20, "num_beams": 10,
+                                                  "decoded_len": dec_len, "dtype": "f32"}
+        del model
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        legs["c2_generation_fp32_parity_mode"] = {"error": repr(ex)[:300]}
+    try:
         Vc = V + 500
         cfg, model, _ = build_model("t5-base", dtype, device, be, 1, 0, vocab=Vc)
         trie = synth_item_trie(12101, 11, lo=V, hi=Vc - 1, pieces=(2, 3, 3, 4))       # Beauty: 12,101 items, <CIk> token paths

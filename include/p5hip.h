@@ -60,6 +60,14 @@ int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t
 int p5_engine_bind(P5Engine* e, float* params, float* grads, void* shadow, const int* lut_enc, const int* lut_dec,
                    int lut_half, uint32_t* rng_state);
 int p5_refresh_shadow(P5Engine* e, void* stream);
+/* Optional (bf16 mode): a caller-owned buffer of p5_transposed_bytes(e) bytes that holds W^T of every 2-D layer weight at the
+ * same arena offset.  When bound, the data gradients dx = dy W (the "autograd of nn.Linear" half of loss.backward(),
+ * DistributedRunner.py:80) read W^T as a K-contiguous operand and run on the forward GEMM kernel instead of the
+ * K-strided-operand variant.  p5_refresh_transposed after every parameter update (it runs on the side stream when one is bound
+ * and the next backward waits for it). */
+int64_t p5_transposed_bytes(const P5Engine* e);
+int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream);
+int p5_refresh_transposed(P5Engine* e, void* stream);
 /* The caller has just zero-filled the gradient arena on the stream the next backward will use (optimizer.zero_grad()):
  * that backward then skips its own clearing pass (243 MB for T5-small).  One-shot. */
 int p5_engine_grads_zeroed(P5Engine* e);
@@ -105,12 +113,33 @@ int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int 
  * out_seq int32 [B,K,max_len] (pad-filled, starts with pad=decoder start), out_score fp32 [B,K], out_len int32 [B,K].
  * excluded_nodes: optional uint32 bitmap [B, excluded_words] over trie node ids; bit n of row b set = node n does not
  * exist in item b's trie (the per-user history exclusion of the filtered protocol, DistributedRunner.py:286-297,
- * without building one trie per user).  NULL / 0 = nothing excluded. */
+ * without building one trie per user).  NULL / 0 = nothing excluded.
+ * Replaces P5_T5.generate(...) = HF beam search + PrefixConstrainedLogitsProcessor (DistributedRunner.py:361-371).
+ * Enqueues the whole search and returns WITHOUT synchronising: HF's stop test is taken on the device, so no step reads
+ * anything back.  max_len bounds the number of decode steps enqueued (max_len - 1): pass min(max_length, depth of the trie). */
 int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                 const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,
                 const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
-/* step-wise variant for arbitrary Python prefix_allowed_tokens_fn callables is built from the two calls below */
+/* The same search step by step (p5_generate = begin + (max_len - 1) x step + finish), for callers that interleave their own
+ * work with the steps or want to stop early:
+ *   p5_decode_begin   encoder, cross-attention K/V of every decoder layer, beam state (HF `_expand_inputs_for_generation`,
+ *                     P5_T5.py:542-578, without physically repeating the encoder states num_beams times);
+ *   p5_decode_step    one step: decoder over B*K rows with the KV cache, tied head, log-softmax over the full vocabulary,
+ *                     trie mask, top-2K, BeamSearchScorer bookkeeping (HF generation/utils.py:3384-3483).  A no-op once the
+ *                     search has stopped or max_len - 1 steps have run;
+ *   p5_decode_done_flag  device pointer to an int that becomes 1 when the search has stopped (poll it asynchronously if
+ *                     steps are enqueued one by one); NULL outside begin..finish;
+ *   p5_decode_finish  writes the K best finished hypotheses per item (same outputs as p5_generate).
+ * All arrays passed to p5_decode_begin must stay valid until p5_decode_finish; ws is p5_generate_workspace_bytes. */
+int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+                    int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                    const int* roots, const uint32_t* excluded_nodes, int excluded_words, int max_children, void* ws, int64_t ws_bytes,
+                    void* stream);
+int p5_decode_step(P5Engine* e, void* stream);
+const int* p5_decode_done_flag(const P5Engine* e);
+int p5_decode_finish(P5Engine* e, int* out_seq, float* out_score, int* out_len, void* stream);
+/* encoder only (JointEncoder.forward, P5_T5.py:74-204) */
 int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
               int B, int L, void* enc_out /* T [B*L, d] */, void* ws, int64_t ws_bytes, void* stream);
 
@@ -136,6 +165,10 @@ int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* lab
  * epi: 0 store T (alpha), 1 relu store T, 2 fp32 atomic accumulate (split-K), 3 store fp32 (alpha) */
 int p5_op_skinny_gemm(int dtype, int amode, const void* A, int lda, const float* ln, const void* W, int ldw, void* C, int ldc,
                       int M, int N, int K, int epi, float alpha, float eps, void* stream);
+/* decode-step cross-attention of the Kb beams of each of B items (p5_decode2.h): q T [B*Kb, H*64], kv T [B*L, 2*H*64] (K then V),
+ * mask int64 [B, L]; zero position bias (HF modeling_t5.py:336-343).  variant 3 = matrix-core kernel, 2 = scalar kernel */
+int p5_op_dec_cross_attn(int dtype, int variant, void* out, const void* q, const void* kv, const int64_t* mask, int B, int H, int Kb,
+                         int L, void* stream);
 int p5_op_tr_probe(void* out64x4_u16, const void* in256_u16, void* stream);  /* ds_read_b64_tr_b16 semantics probe */
 
 #ifdef __cplusplus

@@ -27,6 +27,9 @@ PROTOTYPES = {
     "p5_param_table": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "p5_engine_bind": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "p5_refresh_shadow": (i32, [vp, vp]),
+    "p5_transposed_bytes": (i64, [vp]),
+    "p5_engine_bind_transposed": (i32, [vp, vp, vp]),
+    "p5_refresh_transposed": (i32, [vp, vp]),
     "p5_engine_set_side_stream": (i32, [vp, vp]),
     "p5_train_workspace_bytes": (i64, [vp, i32, i32, i32]),
     "p5_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, vp]),
@@ -43,6 +46,10 @@ PROTOTYPES = {
     "p5_engine_grads_zeroed": (i32, [vp]),
     "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
     "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "p5_decode_begin": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+    "p5_decode_step": (i32, [vp, vp]),
+    "p5_decode_done_flag": (vp, [vp]),
+    "p5_decode_finish": (i32, [vp, vp, vp, vp, vp]),
     "p5_encode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i64, vp]),
     "p5_op_gemm": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, u32, f32, vp]),
     "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),
@@ -51,6 +58,7 @@ PROTOTYPES = {
     "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                             i32, i32, i32, i32, vp, u32, f32, vp]),
     "p5_op_ce_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "p5_op_dec_cross_attn": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p5_op_skinny_gemm": (i32, [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "p5_op_tr_probe": (i32, [vp, vp, vp]),
 }

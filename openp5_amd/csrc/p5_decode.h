@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
                                                           const int* __restrict__ node, const float* __restrict__ run_score,
                                                           const int* __restrict__ child_off, const int* __restrict__ child_tok,
                                                           const int* __restrict__ child_node, const uint32_t* __restrict__ excluded,
-                                                          int excl_words, int Kb, int max_c, int K2) {
+                                                          int excl_words, int Kb, int max_c, int K2, const int* __restrict__ done) {
   __shared__ float sm[4], ss[4];
+  if (done && *done) return;
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ float sc[P5_ROW_LDS_CAND];
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
   if (tid == 0) n_top[r] = want;
 }
 
+#define P5_MAX_K 64
+#define P5_MAX_K2 128
 struct P5BeamState {
   int* run_seq; int* run_seq_next;   // [B,K,max_len]
   float* run_score;                  // [B,K]
@@ -248,96 +251,29 @@ struct P5BeamState {
   int* unsat;                        // [B]
   int* anc; int* anc_next;           // [max_len, R]
   int64_t* last_tok;                 // [R] decoder input for the next step
-  int* flags;                        // [0] any_unsat, [1] not_all_hits (zeroed at the start of each step), [2] cur_len, [3] arrivals, [4] done
+  int* flags;                        // [0] any_unsat, [1] not_all_hits (reset by the last workgroup of each beam step), [2] cur_len, [3] arrivals, [4] done
+  float* x32;                        // optional [R, d] fp32 residual stream of the latency-shaped decode step: the beam step writes
+  const float* E32;                  //   the NEXT step's input embeddings E32[token] into it (one launch per step fewer)
+  int d;
 };
 
-// ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
-// (utils.py:3131-3204, 3008-3075) with rank-based stable selections done in parallel ----
-#define P5_MAX_K 64
-#define P5_MAX_K2 128
-__global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const float* __restrict__ row_top_score,
-                                                          const int* __restrict__ row_top_c, const int* __restrict__ row_n_top,
-                                                          const int* __restrict__ child_off, const int* __restrict__ child_tok,
-                                                          const int* __restrict__ child_node, int max_c, int Kb, int max_len,
-                                                          int eos_id, int R) {
-  const int cur_len = st.flags[2];
-  if ((cur_len & 1) == 0) {      // even step: the "next" buffers of the previous step are the current ones
-    int* t;
-    t = st.run_seq; st.run_seq = st.run_seq_next; st.run_seq_next = t;
-    t = st.fin_seq; st.fin_seq = st.fin_seq_next; st.fin_seq_next = t;
-    t = st.anc; st.anc = st.anc_next; st.anc_next = t;
-  }
-  __shared__ float s_val[4];
-  __shared__ int s_idx[4];
-  __shared__ float cs[P5_MAX_K * P5_MAX_K2];
-  __shared__ float top_lp[P5_MAX_K2], run_lp[P5_MAX_K2], msc[P5_MAX_K + P5_MAX_K2];
-  __shared__ int top_beam[P5_MAX_K2], top_tok[P5_MAX_K2], top_node[P5_MAX_K2], hit[P5_MAX_K2];
-  __shared__ int sel_run[P5_MAX_K], fin_src[P5_MAX_K], fin_fl[P5_MAX_K], fin_ln[P5_MAX_K];
-  __shared__ float fin_sc[P5_MAX_K], run_sc[P5_MAX_K];
-  __shared__ int s_nothit;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int K2 = 2 * Kb;
-  // candidate pool: Kb rows x (<= K2) entries, flat index j*K2 + i
-  for (int t = tid; t < Kb * K2; t += 256) {
-    const int j = t / K2, i = t % K2;
-    cs[t] = i < row_n_top[b * Kb + j] ? row_top_score[(size_t)(b * Kb + j) * K2 + i] : P5_NEG_INF;
-  }
-  if (tid == 0) s_nothit = 0;
-  __syncthreads();
-  __shared__ int ckey[1024];
-  const bool by_rank = Kb * K2 <= 1024;
-  if (by_rank) {
-    // every candidate computes its own rank in the (score desc, beam*max_c + child asc) order -- all in parallel instead of
-    // 2K rounds of block-wide arg-max; the 2K best land at their rank
-    for (int t = tid; t < Kb * K2; t += 256)
-      ckey[t] = (cs[t] == P5_NEG_INF) ? 0x7fffffff : (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2];
-    if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }   // fewer than 2K candidates
-    __syncthreads();
-    for (int t = tid; t < Kb * K2; t += 256) {
-      const float v = cs[t];
-      if (v == P5_NEG_INF) continue;
-      const int key = ckey[t];
-      int rank = 0;
-      for (int u = 0; u < Kb * K2; ++u) {
-        const float vu = cs[u];
-        rank += (vu > v || (vu == v && ckey[u] < key)) ? 1 : 0;
-      }
-      if (rank < K2) {
-        const int j = t / K2, c = key - j * max_c;
-        const int nd = st.run_node[b * Kb + j];
-        top_lp[rank] = v; top_beam[rank] = j;
-        top_tok[rank] = child_tok[child_off[nd] + c];
-        top_node[rank] = child_node[child_off[nd] + c];
-      }
-    }
-    __syncthreads();
-  }
-  for (int it = 0; it < (by_rank ? 0 : K2); ++it) {
-    float bv = P5_NEG_INF;
-    int bi = 0x7fffffff;          // tie-break key = beam * max_c + child  (== HF's flat beam*V + token order)
-    for (int t = tid; t < Kb * K2; t += 256) {
-      const float v = cs[t];
-      if (v == P5_NEG_INF) continue;
-      const int j = t / K2, i = t % K2;
-      const int key = j * max_c + row_top_c[(size_t)(b * Kb + j) * K2 + i];
-      if (v > bv || (v == bv && key < bi)) { bv = v; bi = key; }
-    }
-    block_argmax(bv, bi, s_val, s_idx);
-    if (tid == 0) {
-      if (bi != 0x7fffffff) {
-        const int j = bi / max_c, c = bi % max_c;
-        const int nd = st.run_node[b * Kb + j];
-        top_lp[it] = bv; top_beam[it] = j;
-        top_tok[it] = child_tok[child_off[nd] + c];
-        top_node[it] = child_node[child_off[nd] + c];
-        for (int i = 0; i < K2; ++i)        // mark taken (rows are short: <= K2 entries)
-          if (cs[j * K2 + i] != P5_NEG_INF && row_top_c[(size_t)(b * Kb + j) * K2 + i] == c) { cs[j * K2 + i] = P5_NEG_INF; break; }
-      } else {   // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries
-        top_lp[it] = P5_NEG_INF; top_beam[it] = 0; top_tok[it] = 0; top_node[it] = -1;
-      }
-    }
-    __syncthreads();
-  }
+// ---- shared tail of the beam step: HF steps d-g (utils.py:3131-3204, 3008-3075) from the item's top-2K candidate list in
+// `sh`, materialisation of the new finished / running sets, step counter + stop flag.  `st` is already parity-swapped. ----
+struct P5BeamSh {
+  float top_lp[P5_MAX_K2], run_lp[P5_MAX_K2], msc[P5_MAX_K + P5_MAX_K2];
+  int top_beam[P5_MAX_K2], top_tok[P5_MAX_K2], top_node[P5_MAX_K2], hit[P5_MAX_K2];
+  int sel_run[P5_MAX_K], fin_src[P5_MAX_K], fin_fl[P5_MAX_K], fin_ln[P5_MAX_K];
+  float fin_sc[P5_MAX_K], run_sc[P5_MAX_K];
+  int s_nothit;
+};
+
+__device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& sh, int b, int tid, int Kb, int K2, int max_len, int eos_id, int R,
+                                                    int cur_len) {
+  float* top_lp = sh.top_lp; float* run_lp = sh.run_lp; float* msc = sh.msc;
+  int* top_beam = sh.top_beam; int* top_tok = sh.top_tok; int* top_node = sh.top_node; int* hit = sh.hit;
+  int* sel_run = sh.sel_run; int* fin_src = sh.fin_src; int* fin_fl = sh.fin_fl; int* fin_ln = sh.fin_ln;
+  float* fin_sc = sh.fin_sc; float* run_sc = sh.run_sc;
+  int& s_nothit = sh.s_nothit;
   // ---- d/e: hits, running beams = stable top-K of run_lp ----
   const bool at_max = (cur_len + 1 >= max_len);
   if (tid < K2) {
@@ -423,6 +359,13 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
     st.last_tok[b * Kb + tid] = (int64_t)top_tok[i];
     st.run_score[b * Kb + tid] = run_sc[tid];
   }
+  if (st.x32) {      // decoder input of the next step: x32[row, :] = E32[token, :]  (fp32 master table, P5_T5.py:94-100 for the decoder)
+    const int d4 = st.d >> 2;
+    for (int t = tid; t < Kb * d4; t += 256) {
+      const int j = t / d4, c4 = t - j * d4;
+      *(f32x4*)(st.x32 + ((size_t)(b * Kb + j)) * st.d + c4 * 4) = *(const f32x4*)(st.E32 + (size_t)top_tok[sel_run[j]] * st.d + c4 * 4);
+    }
+  }
   // the step counter advances once every workgroup of this launch is done with it (they all read it on entry): the last one
   // to arrive bumps it -- this used to be a launch of its own
   __syncthreads();
@@ -431,8 +374,100 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
     if (atomicAdd(&st.flags[3], 1) == (int)gridDim.x - 1) {
       st.flags[3] = 0;
       st.flags[2] = cur_len + 1;
+      // HF's global stop condition (utils.py:3055-3075), decided on the device: every later launch of this generate call
+      // sees flags[4] and returns at once, so the host never has to read anything back between steps
+      const int any_unsat = atomicExch(&st.flags[0], 0), not_all_hits = atomicExch(&st.flags[1], 0);     // (reset for the next step)
+      if (!(any_unsat > 0 && not_all_hits > 0)) st.flags[4] = 1;
     }
   }
+}
+
+// ---- one workgroup per batch item: merge the rows' sorted top lists into the item's top-2K, then HF steps d-g
+// (utils.py:3131-3204, 3008-3075) with rank-based stable selections done in parallel ----
+__global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const float* __restrict__ row_top_score,
+                                                          const int* __restrict__ row_top_c, const int* __restrict__ row_n_top,
+                                                          const int* __restrict__ child_off, const int* __restrict__ child_tok,
+                                                          const int* __restrict__ child_node, int max_c, int Kb, int max_len,
+                                                          int eos_id, int R) {
+  if (st.flags[4]) return;       // the search stopped in an earlier step
+  const int cur_len = st.flags[2];
+  if ((cur_len & 1) == 0) {      // even step: the "next" buffers of the previous step are the current ones
+    int* t;
+    t = st.run_seq; st.run_seq = st.run_seq_next; st.run_seq_next = t;
+    t = st.fin_seq; st.fin_seq = st.fin_seq_next; st.fin_seq_next = t;
+    t = st.anc; st.anc = st.anc_next; st.anc_next = t;
+  }
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float cs[P5_MAX_K * P5_MAX_K2];
+  __shared__ P5BeamSh sh;
+  float* top_lp = sh.top_lp;
+  int* top_beam = sh.top_beam; int* top_tok = sh.top_tok; int* top_node = sh.top_node;
+  int& s_nothit = sh.s_nothit;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int K2 = 2 * Kb;
+  // candidate pool: Kb rows x (<= K2) entries, flat index j*K2 + i
+  for (int t = tid; t < Kb * K2; t += 256) {
+    const int j = t / K2, i = t % K2;
+    cs[t] = i < row_n_top[b * Kb + j] ? row_top_score[(size_t)(b * Kb + j) * K2 + i] : P5_NEG_INF;
+  }
+  if (tid == 0) s_nothit = 0;
+  __syncthreads();
+  __shared__ int ckey[1024];
+  const bool by_rank = Kb * K2 <= 1024;
+  if (by_rank) {
+    // every candidate computes its own rank in the (score desc, beam*max_c + child asc) order -- all in parallel instead of
+    // 2K rounds of block-wide arg-max; the 2K best land at their rank
+    for (int t = tid; t < Kb * K2; t += 256)
+      ckey[t] = (cs[t] == P5_NEG_INF) ? 0x7fffffff : (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2];
+    if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }   // fewer than 2K candidates
+    __syncthreads();
+    for (int t = tid; t < Kb * K2; t += 256) {
+      const float v = cs[t];
+      if (v == P5_NEG_INF) continue;
+      const int key = ckey[t];
+      int rank = 0;
+      for (int u = 0; u < Kb * K2; ++u) {
+        const float vu = cs[u];
+        rank += (vu > v || (vu == v && ckey[u] < key)) ? 1 : 0;
+      }
+      if (rank < K2) {
+        const int j = t / K2, c = key - j * max_c;
+        const int nd = st.run_node[b * Kb + j];
+        top_lp[rank] = v; top_beam[rank] = j;
+        top_tok[rank] = child_tok[child_off[nd] + c];
+        top_node[rank] = child_node[child_off[nd] + c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int it = 0; it < (by_rank ? 0 : K2); ++it) {
+    float bv = P5_NEG_INF;
+    int bi = 0x7fffffff;          // tie-break key = beam * max_c + child  (== HF's flat beam*V + token order)
+    for (int t = tid; t < Kb * K2; t += 256) {
+      const float v = cs[t];
+      if (v == P5_NEG_INF) continue;
+      const int j = t / K2, i = t % K2;
+      const int key = j * max_c + row_top_c[(size_t)(b * Kb + j) * K2 + i];
+      if (v > bv || (v == bv && key < bi)) { bv = v; bi = key; }
+    }
+    block_argmax(bv, bi, s_val, s_idx);
+    if (tid == 0) {
+      if (bi != 0x7fffffff) {
+        const int j = bi / max_c, c = bi % max_c;
+        const int nd = st.run_node[b * Kb + j];
+        top_lp[it] = bv; top_beam[it] = j;
+        top_tok[it] = child_tok[child_off[nd] + c];
+        top_node[it] = child_node[child_off[nd] + c];
+        for (int i = 0; i < K2; ++i)        // mark taken (rows are short: <= K2 entries)
+          if (cs[j * K2 + i] != P5_NEG_INF && row_top_c[(size_t)(b * Kb + j) * K2 + i] == c) { cs[j * K2 + i] = P5_NEG_INF; break; }
+      } else {   // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries
+        top_lp[it] = P5_NEG_INF; top_beam[it] = 0; top_tok[it] = 0; top_node[it] = -1;
+      }
+    }
+    __syncthreads();
+  }
+  p5_beam_tail(st, sh, b, tid, Kb, K2, max_len, eos_id, R, cur_len);
 }
 
 
@@ -459,6 +494,273 @@ __global__ __launch_bounds__(256) void p5_beam_init_kernel(P5BeamState st, const
     st.fin_len[i] = 0;
     st.last_tok[i] = start_id;
   }
+  if (st.x32) {      // decoder input of the first step: every row = E32[decoder start token]
+    const int d4 = st.d >> 2;
+    for (int t = i; t < R * d4; t += gridDim.x * 256)
+      *(f32x4*)(st.x32 + (size_t)t * 4) = *(const f32x4*)(st.E32 + (size_t)start_id * st.d + (t % d4) * 4);
+  }
   if (i < B) st.unsat[i] = 1;
   if (i == 0) { st.flags[0] = 0; st.flags[1] = 0; st.flags[2] = 1; st.flags[3] = 0; st.flags[4] = 0; }
+}
+
+
+// =====================================================================================================================
+// Candidate scores for the streaming head (p5_head_lse_kernel), one workgroup per decode row:
+//   1. log-sum-exp of the row from the per-tile (max, sum exp) partials;
+//   2. the logits the search needs -- the trie children of the row's beam -- recomputed as dot products hn[row] . E[token]
+//      (a handful, except at a high-fan-out trie level), minus lse, plus the running score; children whose subtree is excluded
+//      for this user (filtered evaluation, DistributedRunner.py:286-297) are dropped;
+//   3. the row's best K2 = 2K of them in (score desc, child asc) order: rank counting for small fan-outs, a 4-pass radix
+//      select of the K2-th score first for large ones (the global top-2K of an item is contained in the union of its rows'
+//      top-2K lists; p5_beam_step_kernel merges them).
+// This is "log_softmax over the full vocabulary, then mask to the allowed tokens" (HF generation/utils.py:3388-3389) without
+// ever holding a [R, V] tensor.
+// =====================================================================================================================
+#define P5_POOL 2048
+template <class T>
+__global__ __launch_bounds__(256) void p5_dec_score2_kernel(float* __restrict__ top_score, int* __restrict__ top_c, int* __restrict__ n_top,
+                                                           float* __restrict__ cand_scratch, const float* __restrict__ part_m,
+                                                           const float* __restrict__ part_s, int ntiles, const T* __restrict__ hn,
+                                                           const T* __restrict__ E, int d, float alpha, const int* __restrict__ node,
+                                                           const float* __restrict__ run_score, const int* __restrict__ child_off,
+                                                           const int* __restrict__ child_tok, const int* __restrict__ child_node,
+                                                           const uint32_t* __restrict__ excluded, int excl_words, int Kb, int max_c, int K2,
+                                                           const int* __restrict__ done) {
+  constexpr int EPF = TT<T>::EPF;
+  __shared__ float sm[4], ss[4];
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float pool_v[P5_POOL];
+  __shared__ float cmp_v[P5_MAX_K2];
+  __shared__ int cmp_k[P5_MAX_K2];
+  __shared__ int hist[256];
+  __shared__ unsigned s_sel[4];      // [0] selected bin, [1] count above it / compact count, [2] "take everything" flag, [3] placed
+  if (done && *done) return;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nd = node[r];
+  if (nd < 0) {  // dead beam: no candidates (uniform per block)
+    if (tid == 0) n_top[r] = 0;
+    return;
+  }
+  // the trie lookups do not depend on the reduction below: issue them first
+  const int c0 = child_off[nd];
+  int nc = child_off[nd + 1] - c0;
+  nc = nc < max_c ? nc : max_c;
+  const float rs = run_score[r];
+  // ---- 1. log-sum-exp over the vocabulary tiles ----
+  float m = P5_NEG_INF, sum = 0.f;
+  for (int t = tid; t < ntiles; t += 256) {
+    const float pm = part_m[(size_t)r * ntiles + t], ps = part_s[(size_t)r * ntiles + t];
+    if (pm > m) { sum = sum * expf(m - pm) + ps; m = pm; }
+    else if (pm != P5_NEG_INF) sum += ps * expf(pm - m);
+  }
+  {
+    const float wm_ = wave_max(m);
+    sum = wave_sum(m == P5_NEG_INF ? 0.f : sum * expf(m - wm_));
+    if (lane == 0) { sm[wave] = wm_; ss[wave] = sum; }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    sum = 0.f;
+    for (int w = 0; w < 4; ++w) sum += (sm[w] == P5_NEG_INF) ? 0.f : ss[w] * expf(sm[w] - m);
+  }
+  const float lse = m + logf(sum);
+  // ---- 2. children's scores: 8 lanes per candidate, 32 candidates per pass ----
+  const bool in_lds = nc <= P5_POOL;
+  float* pv = in_lds ? pool_v : cand_scratch + (size_t)r * max_c;
+  const uint32_t* ex = excluded ? excluded + (size_t)(r / Kb) * excl_words : nullptr;
+  {
+    // the row's hn stays in registers (this lane's 16-byte pieces: element offsets sub*EPF + k*8*EPF), every load of a
+    // candidate's E row is issued before the first FMA, and the next pass's token id is fetched a pass ahead
+    constexpr int MAXP = 1024 / (8 * EPF);          // d_model <= 1024
+    const int grp = tid >> 3, sub = tid & 7;
+    const T* hp = hn + (size_t)r * d;
+    const int np = d / (8 * EPF);
+    u32x4 hx[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) hx[k] = k < np ? ld16(hp + sub * EPF + k * 8 * EPF) : zero16();
+    int tok_next = grp < nc ? child_tok[c0 + grp] : 0;
+    for (int i0 = 0; i0 < nc; i0 += 32) {
+      const int i = i0 + grp;
+      const int tok = tok_next;
+      if (i + 32 < nc) tok_next = child_tok[c0 + i + 32];
+      float acc = 0.f;
+      if (i < nc) {
+        const T* ep = E + (size_t)tok * d + sub * EPF;
+#pragma unroll
+        for (int k0 = 0; k0 < MAXP; k0 += 8) {          // 8 x 16 bytes of the E row in flight per lane
+          if (k0 < np) {
+            u32x4 wr[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wr[k] = k0 + k < np ? ld16(ep + (k0 + k) * 8 * EPF) : zero16();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float x[8], w[8];
+              unpack16<T>(hx[k0 + k], x);
+              unpack16<T>(wr[k], w);
+#pragma unroll
+              for (int e = 0; e < EPF; ++e) acc += x[e] * w[e];
+            }
+          }
+        }
+      }
+      acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+      if (i < nc && sub == 0) {
+        float v = (acc * alpha - lse) + rs;
+        if (ex) {
+          const int cn = child_node[c0 + i];
+          if ((ex[cn >> 5] >> (cn & 31)) & 1u) v = P5_NEG_INF;
+        }
+        pv[i] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. the row's top-K2 ----
+  auto okey = [](float v) -> unsigned {           // order-preserving float -> uint
+    union { float f; unsigned u; } c; c.f = v;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+  };
+  const int want = K2 < nc ? K2 : nc;
+  if (in_lds) {
+    const float* rv = pool_v;
+    const int* rk = nullptr;            // nullptr: the candidate's child index is its position
+    int n = nc;
+    if (nc > 256) {
+      // radix select of the K2-th largest finite score: after the four passes `prefix` is its key and `remaining` the number of
+      // candidates needed from those TIED with it (dead beams carry -1e9 + log-prob, which fp32 rounds to the same value for
+      // every child: a thousand-way tie is the normal case there, and HF's order among ties is the child order)
+      unsigned prefix = 0, mask = 0;
+      int remaining = K2;
+      bool all = false;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < nc; i += 256) {
+          const float v = pool_v[i];
+          if (v == P5_NEG_INF) continue;
+          const unsigned k = okey(v);
+          if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {
+          // lane l owns bins 255-4l .. 252-4l (descending); `before` = candidates in strictly higher bins than this lane's
+          int h4[4], own = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { h4[q] = hist[255 - (lane * 4 + q)]; own += h4[q]; }
+          int before = 0, tot = 0;
+          for (int l2 = 0; l2 < 64; ++l2) {
+            const int o = __shfl(own, l2);
+            before += (l2 < lane) ? o : 0;
+            tot += o;
+          }
+          if (pass == 0 && lane == 0) s_sel[2] = (tot <= remaining) ? 1u : 0u;      // no more finite candidates than K2: take them all
+          if (before < remaining && before + own >= remaining) {
+            int cum = before;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (cum < remaining && cum + h4[q] >= remaining) { s_sel[0] = (unsigned)(255 - (lane * 4 + q)); s_sel[1] = (unsigned)cum; }
+              cum += h4[q];
+            }
+          }
+        }
+        __syncthreads();
+        if (s_sel[2]) { all = true; break; }
+        prefix |= s_sel[0] << shift;
+        mask |= 255u << shift;
+        remaining -= (int)s_sel[1];
+        __syncthreads();
+      }
+      // ordered compaction: everything above the threshold, plus the first `remaining` (in child order) of the ties.  Each
+      // thread owns a contiguous run of candidates so that an exclusive scan of the per-thread tie counts yields tie ranks.
+      const int per = (nc + 255) / 256, i_lo = tid * per, i_hi = (i_lo + per < nc) ? i_lo + per : nc;
+      int ties = 0;
+      if (!all)
+        for (int i = i_lo; i < i_hi; ++i) ties += (pool_v[i] != P5_NEG_INF && okey(pool_v[i]) == prefix) ? 1 : 0;
+      __syncthreads();
+      hist[tid] = ties;
+      if (tid == 0) s_sel[1] = 0u;
+      __syncthreads();
+      if (wave == 0) {
+        int h4[4], own = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h4[q] = hist[lane * 4 + q]; own += h4[q]; }
+        int before = 0;
+        for (int l2 = 0; l2 < 64; ++l2) {
+          const int o = __shfl(own, l2);
+          before += (l2 < lane) ? o : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hist[lane * 4 + q] = before; before += h4[q]; }
+      }
+      __syncthreads();
+      int tie_rank = hist[tid];
+      for (int i = i_lo; i < i_hi; ++i) {
+        const float v = pool_v[i];
+        if (v == P5_NEG_INF) continue;
+        const unsigned k = okey(v);
+        bool keep = all || k > prefix;
+        if (!all && k == prefix) { keep = tie_rank < remaining; ++tie_rank; }
+        if (keep) {
+          const unsigned at = atomicAdd(&s_sel[1], 1u);
+          if (at < (unsigned)P5_MAX_K2) { cmp_v[at] = v; cmp_k[at] = i; }
+        }
+      }
+      __syncthreads();
+      n = (int)s_sel[1];               // == min(K2, finite candidates)
+      rv = cmp_v; rk = cmp_k;
+    }
+    if (tid == 0) s_sel[3] = 0u;
+    __syncthreads();
+    for (int t = tid; t < n; t += 256) {
+      const float v = rv[t];
+      if (v == P5_NEG_INF) continue;
+      const int key = rk ? rk[t] : t;
+      int rank = 0;
+      for (int u = 0; u < n; ++u) {
+        const float vu = rv[u];
+        rank += (vu > v || (vu == v && (rk ? rk[u] : u) < key)) ? 1 : 0;
+      }
+      if (rank < K2) {
+        top_score[(size_t)r * K2 + rank] = v;
+        top_c[(size_t)r * K2 + rank] = key;
+        atomicAdd(&s_sel[3], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) n_top[r] = (int)s_sel[3];       // finite candidates placed (ranks 0 .. count-1 are exactly the ones written)
+    return;
+  }
+  // ---- fan-outs beyond the LDS pool: K2 rounds of block-wide arg-max over the global scratch ----
+  for (int it = 0; it < want; ++it) {
+    float bv = P5_NEG_INF;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < nc; c += 256) {
+      const float v = pv[c];
+      if (v == P5_NEG_INF) continue;
+      if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+    block_argmax(bv, bi, s_val, s_idx);
+    if (bi == 0x7fffffff) {            // only excluded children left; stop early
+      if (tid == 0) n_top[r] = it;
+      return;
+    }
+    if (tid == 0) {
+      top_score[(size_t)r * K2 + it] = bv;
+      top_c[(size_t)r * K2 + it] = bi;
+      pv[bi] = P5_NEG_INF;   // taken (a genuine -inf candidate is never selected above)
+    }
+    __syncthreads();
+  }
+  if (tid == 0) n_top[r] = want;
+}
+
+// results of the search: the finished set written by the last EXECUTED step lives in the "next" buffer of that step's parity
+__global__ __launch_bounds__(256) void p5_beam_finalize_kernel(int* __restrict__ out_seq, float* __restrict__ out_score, int* __restrict__ out_len,
+                                                              P5BeamState st, int R, int max_len) {
+  const int steps = st.flags[2] - 1;                       // beam steps executed (cur_len starts at 1)
+  const int* src = (steps & 1) ? st.fin_seq_next : st.fin_seq;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < R * max_len) out_seq[i] = src[i];
+  if (i < R) { out_score[i] = st.fin_score[i]; out_len[i] = st.fin_len[i]; }
 }

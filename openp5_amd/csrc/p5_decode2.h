@@ -177,17 +177,6 @@ __global__ __launch_bounds__(256) void p5_skinny_gemm_kernel(P5SkinnyArgs g) {
   }
 }
 
-// ---- x32[row,:] = E32[tok[row],:]  (decoder input embedding of the step, fp32 master table) ----
-__global__ __launch_bounds__(256) void p5_embed_f32_kernel(float* __restrict__ x, const float* __restrict__ E, const int64_t* __restrict__ tok, int rows,
-                                                          int d, const int* __restrict__ done) {
-  if (done && *done) return;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int64_t id = tok[row];
-  for (int c = lane; c < d / 4; c += 64) *(f32x4*)(x + (size_t)row * d + c * 4) = *(const f32x4*)(E + (size_t)id * d + c * 4);
-}
-
 // ---- hn(T) = T5LayerNorm(x32)  (input of the tied head) ----
 template <class T>
 __global__ __launch_bounds__(256) void p5_rmsnorm_f32in_kernel(T* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w, int rows, int d,
@@ -466,5 +455,244 @@ __global__ __launch_bounds__(256) void p5_dec_cross_attn2_kernel(P5CrossArgs a) 
     T* op = (T*)a.out + (size_t)(r0 + orow) * inner + h * 64 + od;
 #pragma unroll
     for (int e = 0; e < 4; ++e) op[e] = from_f<T>(o[e] * inv);
+  }
+}
+
+// =====================================================================================================================
+// Cross-attention of the beams of one batch item for one head on the matrix cores (replaces the scalar score / PV loops of
+// p5_dec_cross_attn2_kernel): S = q K^T and O = P V are MFMA tiles -- the <= 16 beams of an item are exactly one 16-row
+// tile, which is why the item's K/V are staged once and shared (the reference expands encoder states x num_beams,
+// P5_T5.py:571-576).  Zero position bias, encoder padding mask, fp32 online softmax over 128-key chunks
+// (HF modeling_t5.py:336-343,404-432).  FUSEQ: the beams' q projection (T5LayerNorm of the fp32 residual rows, then the head's
+// 64 rows of Wq) is computed here too, all operand bytes requested up front.
+//   LDS: q image [16][64] T (kc128 layout) | S fp32 [16][KC+4] | P (T) [16][KC*sizeof(T)+16 B] (x2 in bf16) | stats | K image | V image
+//        | (FUSEQ) normalised rows + Wq slice
+// =====================================================================================================================
+template <class T, bool FUSEQ, int LDSKB>
+__global__ __launch_bounds__(256) void p5_dec_cross_attn3_kernel(P5CrossArgs a) {
+  constexpr int KC = 128;                              // keys per chunk
+  constexpr int SZ = (int)sizeof(T), EPF = TT<T>::EPF, KCH = TT<T>::KCH;
+  constexpr int NSD = 64 * SZ / 128;                   // 128-byte steps per 64-dim K/V/q row (1 bf16, 2 fp32)
+  constexpr int KVB = KC * 128 * NSD;                  // bytes of one K (or V) chunk image
+  constexpr int PROW = KC * SZ + 16;                   // padded row pitch of the P image (bytes)
+  __shared__ __attribute__((aligned(16))) char lds[LDSKB * 1024];
+  if (a.done && *a.done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mt_per = (a.Kb + 15) / 16;
+  const int b = blockIdx.x / mt_per, mt = blockIdx.x % mt_per, h = blockIdx.y;
+  const int r0 = b * a.Kb + mt * 16;
+  const int nrow = (a.Kb - mt * 16) < 16 ? (a.Kb - mt * 16) : 16;
+  const int inner = a.H * 64;
+  char* qimg = lds;                                     // [NSD][16][128 B]
+  float* sS = (float*)(qimg + NSD * 2048);              // [16][KC + 4]
+  char* pimg = (char*)(sS + 16 * (KC + 4));             // [16][PROW]; bf16: a second image holds the rounding residual of P
+  constexpr int NPI = SZ == 2 ? 2 : 1;
+  float* sM = (float*)(pimg + NPI * 16 * PROW);         // [16] max, [16] sum, [16] rescale, [16] spare
+  char* kimg = (char*)(sM + 64);
+  char* vimg = kimg + KVB;
+  char* aimg = vimg + KVB;
+  const T* kvp = (const T*)a.kv + (size_t)b * a.L * 2 * inner + h * 64;
+  auto stage_kv = [&](int j0) {
+    sk_dma_rows<T>(kimg, kvp, 2 * inner, j0, a.L, 0, KC, NSD, tid);
+    sk_dma_rows<T>(vimg, kvp + inner, 2 * inner, j0, a.L, 0, KC, NSD, tid);
+  };
+  stage_kv(0);
+  // ---- q rows -> qimg (as the activation dtype stores them) ----
+  auto q_store = [&](int row, int col, float v) {
+    const int byte = col * SZ, step = byte / 128, slot = (byte % 128) >> 4, within = byte & 15;
+    *(T*)(qimg + step * 2048 + row * 128 + ((slot ^ (row & 7)) << 4) + within) = from_f<T>(v);
+  };
+  if constexpr (FUSEQ) {
+    constexpr int EPS = SkT<T>::EPS;
+    const int nsteps = a.d / EPS;
+    char* bimg = aimg + (size_t)nsteps * 2048;
+    float* red = (float*)(bimg + (size_t)nsteps * 64 * 128);
+    sk_dma_rows<T>(bimg, (const T*)a.Wq, a.d, h * 64, inner, 0, 64, nsteps, tid);
+    sk_norm_rows<T>(aimg, a.x, a.ln, r0, r0 + nrow, a.d, a.eps, tid);
+    __syncthreads();
+    const f32x4 acc = sk_mma<T, 64>(aimg, bimg, nsteps, red, tid);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q_store((lane >> 4) * 4 + r, wave * 16 + (lane & 15), acc[r]);
+  } else {
+    for (int i = tid; i < 16 * 64; i += 256) {
+      const int row = i >> 6;
+      q_store(row, i & 63, row < nrow ? to_f<T>(((const T*)a.q)[(size_t)(r0 + row) * inner + h * 64 + (i & 63)]) : 0.f);
+    }
+  }
+  if (tid < 16) { sM[tid] = P5_NEG_INF; sM[16 + tid] = 0.f; }
+  f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};               // wave w owns dims [16w, 16w+16): rows (lane>>4)*4 + r, dim 16w + (lane&15)
+  for (int j0 = 0; j0 < a.L; j0 += KC) {
+    if (j0 > 0) { __syncthreads(); stage_kv(j0); }
+    __syncthreads();                                     // K/V chunk landed (and q image / stats written)
+    // ---- S = q K^T : 8 key tiles of 16, two per wave ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int kt = wave * 2 + t;
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < NSD; ++st) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 fa = frag_load_kc128<T>(qimg + st * 2048, 0, c, lane);
+          const u32x4 fb = frag_load_kc128<T>(kimg + st * KC * 128, kt * 16, c, lane);
+          mma16<T>(s, fa, fb);
+        }
+      }
+      const int key = kt * 16 + (lane & 15);
+      const bool ok = (j0 + key) < a.L && a.mask[(size_t)b * a.L + j0 + key] != 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sS[((lane >> 4) * 4 + r) * (KC + 4) + key] = ok ? s[r] : P5_NEG_INF;
+    }
+    __syncthreads();
+    {
+      // online softmax: 16 threads per row, 8 keys each; probabilities go to the P image in the compute dtype
+      const int row = tid >> 4, sub = tid & 15;
+      float sv[KC / 16];
+      float cm = P5_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < KC / 16; ++i) { sv[i] = sS[row * (KC + 4) + sub + i * 16]; cm = fmaxf(cm, sv[i]); }
+      cm = row16_max(cm);
+      const float mo = sM[row];
+      const float mn = fmaxf(mo, cm);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < KC / 16; ++i) {
+        const float p = (sv[i] == P5_NEG_INF) ? 0.f : expf(sv[i] - mn);
+        const T pt = from_f<T>(p);
+        *(T*)(pimg + row * PROW + (sub + i * 16) * SZ) = pt;
+        // bf16: P = hi + lo keeps 16 mantissa bits of the probabilities (the scalar kernel multiplied fp32 P with V; a
+        // single bf16 P alone costs 2e-3 of score accuracy, as much as everything else in the bf16 decode step together)
+        if constexpr (SZ == 2) *(T*)(pimg + 16 * PROW + row * PROW + (sub + i * 16) * SZ) = from_f<T>(p - to_f<T>(pt));
+        sum += p;
+      }
+      sum = row16_sum(sum);
+      const float sc = (mo == P5_NEG_INF) ? 0.f : expf(mo - mn);
+      __syncthreads();       // every thread of the row has read sM[row]
+      if (sub == 0) { sM[row] = mn; sM[16 + row] = sM[16 + row] * sc + sum; sM[32 + row] = sc; }
+    }
+    __syncthreads();
+    // ---- O = O * rescale + P V : wave w -> dims [16w, 16w+16); V fragments gathered from the key-major image ----
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] *= sM[32 + (lane >> 4) * 4 + r];
+      const int dim = wave * 16 + (lane & 15);
+      const int byte = dim * SZ, vstep = byte / 128, vslot = (byte % 128) >> 4, vwithin = byte & 15;
+#pragma unroll
+      for (int kc = 0; kc < KC / KCH; ++kc) {
+        const u32x4 fa = ld16(pimg + (lane & 15) * PROW + (kc * KCH + (lane >> 4) * EPF) * SZ);
+        T vb[EPF];
+#pragma unroll
+        for (int e = 0; e < EPF; ++e) {
+          const int key = kc * KCH + (lane >> 4) * EPF + e;
+          vb[e] = *(const T*)(vimg + vstep * KC * 128 + key * 128 + ((vslot ^ (key & 7)) << 4) + vwithin);
+        }
+        u32x4 fb;
+        if constexpr (SZ == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fb[q] = (unsigned)((const unsigned short*)vb)[2 * q] | ((unsigned)((const unsigned short*)vb)[2 * q + 1] << 16);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fb[q] = ((const unsigned*)vb)[q];
+        }
+        mma16<T>(o, fa, fb);
+        if constexpr (SZ == 2) {
+          const u32x4 fl = ld16(pimg + 16 * PROW + (lane & 15) * PROW + (kc * KCH + (lane >> 4) * EPF) * SZ);
+          mma16<T>(o, fl, fb);
+        }
+      }
+    }
+  }
+  // masked keys carry P = 0 and clamped rows finite V, so nothing needs fixing up; rows >= nrow are not stored
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) * 4 + r;
+    if (row < nrow) {
+      const float l = sM[16 + row];
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      ((T*)a.out)[(size_t)(r0 + row) * inner + h * 64 + wave * 16 + (lane & 15)] = from_f<T>(o[r] * inv);
+    }
+  }
+}
+
+// =====================================================================================================================
+// Tied head as a streaming reduction (HF generation/utils.py:3388-3389 takes log_softmax over the FULL
+// vocabulary and only then masks to the trie children): every workgroup keeps NV rows of E in LDS (fetched once, direct to
+// LDS), multiplies ALL decode rows against them and reduces each row's NV logits to (max, sum exp) on the spot -- the
+// [R, V] logits are never written.  The few logits the search needs (the trie children of each beam) are recomputed as dot
+// products by p5_beam_step2_kernel.  Waves split the rows (m-tiles of 16), A fragments come straight from global memory
+// (hn is R x d, L2/L1 resident), so there is no barrier after the one that publishes the E tile.
+//   grid = ceil(V / NV), 256 threads.  part_m / part_s: [R][gridDim.x].
+// =====================================================================================================================
+template <class T, int NV, int LDSKB>
+__global__ __launch_bounds__(256) void p5_head_lse_kernel(float* __restrict__ part_m, float* __restrict__ part_s, const T* __restrict__ hn,
+                                                         const T* __restrict__ E, int R, int d, int V, float alpha,
+                                                         const int* __restrict__ done) {
+  constexpr int EPS = SkT<T>::EPS, EPF = TT<T>::EPF, KCH = TT<T>::KCH, NT = NV / 16;
+  __shared__ __attribute__((aligned(16))) char lds[LDSKB * 1024];
+  if (done && *done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v0 = blockIdx.x * NV;
+  const int nsteps = d / EPS;                                        // 128-byte steps per row
+  sk_dma_rows<T>(lds, E, d, v0, V, 0, NV, nsteps, tid);              // rows past V are clamped (masked below)
+  __syncthreads();
+  const int nmt = (R + 15) / 16;
+  const int nkc = d / KCH;                                           // 64-byte chunks per row; 2 per step
+  const int ngrp = (nkc + 7) / 8;                                    // A fragments are fetched 8 chunks at a time ...
+  auto load_a = [&](u32x4 (&f)[8], int mt_, int g_) {
+    int ar = mt_ * 16 + (lane & 15);
+    ar = ar < R ? ar : R - 1;
+    const T* ap = hn + (size_t)ar * d + (lane >> 4) * EPF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (g_ * 8 + i < nkc) ? ld16(ap + (size_t)(g_ * 8 + i) * KCH) : zero16();
+  };
+  u32x4 fa[8], fnx[8];
+  if (wave < nmt) load_a(fa, wave, 0);
+  for (int mt = wave; mt < nmt; mt += 4) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < ngrp; ++g) {
+      // ... and the next group (of this m-tile or of the wave's next one) is requested before this group's MFMAs are issued
+      const bool last = g + 1 == ngrp;
+      const int nmt_ = last ? mt + 4 : mt, ng = last ? 0 : g + 1;
+      const bool more = nmt_ < nmt;
+      if (more) load_a(fnx, nmt_, ng);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kc = g * 8 + i;
+        if (kc < nkc) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const u32x4 fb = frag_load_kc128<T>(lds + (size_t)(kc >> 1) * NV * 128, n * 16, kc & 1, lane);
+            mma16<T>(acc[n], fa[i], fb);
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = fnx[i];
+      }
+    }
+    // row-wise (max, sum exp) over this tile's NV columns: element (row (lane>>4)*4 + r, col n*16 + (lane&15))
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = P5_NEG_INF;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bool ok = v0 + n * 16 + (lane & 15) < V;
+        acc[n][r] = ok ? acc[n][r] * alpha : P5_NEG_INF;
+        m = fmaxf(m, acc[n][r]);
+      }
+      m = row16_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) s += (acc[n][r] == P5_NEG_INF) ? 0.f : expf(acc[n][r] - m);
+      s = row16_sum(s);
+      const int row = mt * 16 + (lane >> 4) * 4 + r;
+      if ((lane & 15) == 0 && row < R) {
+        part_m[(size_t)row * gridDim.x + blockIdx.x] = m;
+        part_s[(size_t)row * gridDim.x + blockIdx.x] = s;
+      }
+    }
   }
 }

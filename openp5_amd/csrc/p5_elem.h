@@ -123,70 +123,92 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_fwd_kernel(T* __restrict__ y, 
 //   dy_next  = dropmask_next(dres_out) cast to T                     (input to the PRECEDING sub-layer's dgrad)
 // drop_in masks the incoming dy (only for the final norms whose output is dropped).
 // Each workgroup walks rows with a grid stride and flushes its dw partials with one atomicAdd per column.
-template <class T>
+// NCH = 16-byte pieces per lane (d_model <= NCH * 64 * EPF): a compile-time bound keeps the per-row state in exactly as many
+// registers as the model needs (bf16 d_model 512: one piece), which is what lets a wave keep TWO rows in flight -- the kernel
+// is a chain of dependent HBM round trips per row, so rows in flight per wave is its throughput.
+template <class T, int NCH>
 __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__ dres_out, T* __restrict__ dy_next,
                                                             float* __restrict__ dw, const T* __restrict__ dy,
                                                             const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
                                                             int rows, int d, P5Drop drop_in, P5Drop drop_next, float* __restrict__ dw_partial) {
   constexpr int EPF = TT<T>::EPF;
-  __shared__ float sdw[4][1024];
+  constexpr int RU = NCH <= 2 ? 2 : 1;             // rows in flight per wave
+  __shared__ float sdw[4][NCH * 64 * EPF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int npc = d / EPF;
-  float dwacc[4][8];
+  float dwacc[NCH][8], wv[NCH][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
+    for (int e = 0; e < 8; ++e) { dwacc[i][e] = 0.f; wv[i][e] = 0.f; }
+    if (c < npc) ldf<EPF>(w + c * EPF, wv[i]);
+  }
   const bool din = drop_in.state != nullptr && drop_in.thr != 0;
   const bool dnx = drop_next.state != nullptr && drop_next.thr != 0;
   const uint32_t seed_in = p5_seed(drop_in), seed_nx = p5_seed(drop_next);
+  const int stride = gridDim.x * 4;
 
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float rstd = rstd_in[row];
-    float dyv[4][8], xh[4][8];
-    float dot = 0.f;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += stride * RU) {
+    float dyv[RU][NCH][8], xh[RU][NCH][8], rin[RU][NCH][8], rstd[RU];
+    // every load of the rows is issued before the first reduction
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = lane + i * 64;
-      if (c < npc) {
-        unpack16<T>(ld16(dy + (size_t)row * d + c * EPF), dyv[i]);
-        unpack16<T>(ld16(x + (size_t)row * d + c * EPF), xh[i]);
-        float wv[8];
-        ldf<EPF>(w + c * EPF, wv);
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * stride;
+      rstd[u] = row < rows ? rstd_in[row] : 0.f;
 #pragma unroll
-        for (int e = 0; e < EPF; ++e) {
-          if (din) dyv[i][e] = p5_keep(seed_in, drop_in.site_key, (uint32_t)(row * d + c * EPF + e), drop_in.thr) ? dyv[i][e] * drop_in.scale : 0.f;
-          xh[i][e] *= rstd;
-          dwacc[i][e] += dyv[i][e] * xh[i][e];
-          dyv[i][e] *= wv[e];
-          dot += dyv[i][e] * xh[i][e];
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < npc && row < rows) {
+          unpack16<T>(ld16(dy + (size_t)row * d + c * EPF), dyv[u][i]);
+          unpack16<T>(ld16(x + (size_t)row * d + c * EPF), xh[u][i]);
+          if (dres_in) ldf<EPF>(dres_in + (size_t)row * d + c * EPF, rin[u][i]);
         }
       }
     }
-    dot = wave_sum(dot) / (float)d;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = lane + i * 64;
-      if (c < npc) {
-        float o[8], rin[8], rout[8];
-        const size_t g0 = (size_t)row * d + c * EPF;
-        if (dres_in) ldf<EPF>(dres_in + g0, rin);
+    for (int u = 0; u < RU; ++u) {
+      const int row = row0 + u * stride;
+      if (row >= rows) continue;                    // (wave-uniform)
+      float dot = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPF; ++e) {
-          float v = rstd * (dyv[i][e] - xh[i][e] * dot);
-          if (dres_in) v += rin[e];
-          rout[e] = v;
-          o[e] = dnx ? (p5_keep(seed_nx, drop_next.site_key, (uint32_t)(g0 + e), drop_next.thr) ? v * drop_next.scale : 0.f) : v;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < npc) {
+#pragma unroll
+          for (int e = 0; e < EPF; ++e) {
+            if (din) dyv[u][i][e] = p5_keep(seed_in, drop_in.site_key, (uint32_t)(row * d + c * EPF + e), drop_in.thr) ? dyv[u][i][e] * drop_in.scale : 0.f;
+            xh[u][i][e] *= rstd[u];
+            dwacc[i][e] += dyv[u][i][e] * xh[u][i][e];
+            dyv[u][i][e] *= wv[i][e];
+            dot += dyv[u][i][e] * xh[u][i][e];
+          }
         }
-        stf<EPF>(dres_out + g0, rout);
-        if (dy_next) st16(dy_next + (size_t)row * d + c * EPF, pack16<T>(o));
+      }
+      dot = wave_sum(dot) / (float)d;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < npc) {
+          float o[8], rout[8];
+          const size_t g0 = (size_t)row * d + c * EPF;
+#pragma unroll
+          for (int e = 0; e < EPF; ++e) {
+            float v = rstd[u] * (dyv[u][i][e] - xh[u][i][e] * dot);
+            if (dres_in) v += rin[u][i][e];
+            rout[e] = v;
+            o[e] = dnx ? (p5_keep(seed_nx, drop_next.site_key, (uint32_t)(g0 + e), drop_next.thr) ? v * drop_next.scale : 0.f) : v;
+          }
+          stf<EPF>(dres_out + g0, rout);
+          if (dy_next) st16(dy_next + (size_t)row * d + c * EPF, pack16<T>(o));
+        }
       }
     }
   }
   // flush dw
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
     if (c < npc) {
 #pragma unroll

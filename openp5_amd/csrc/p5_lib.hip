@@ -53,6 +53,11 @@ static int g_opt_decode_v2 = getenv("P5_DECODE_V2") ? atoi(getenv("P5_DECODE_V2"
 static int g_opt_dec_nb = getenv("P5_DEC_NB") ? atoi(getenv("P5_DEC_NB")) : 0;           // skinny GEMM: forced column-tile width (0 = auto)
 static int g_opt_dec_kw = getenv("P5_DEC_KW") ? atoi(getenv("P5_DEC_KW")) : 0;           // skinny GEMM: forced K range per workgroup (0 = auto)
 static int g_opt_dec_fuseq = getenv("P5_DEC_FUSEQ") ? atoi(getenv("P5_DEC_FUSEQ")) : 1;   // cross-attention computes its own q projection
+static int g_opt_gemm_bigk = getenv("P5_GEMM_BIGK") ? atoi(getenv("P5_GEMM_BIGK")) : 0;   // 128x128 tiles at one full round when K >= this (0 = off)
+static int g_opt_dgrad_t = getenv("P5_DGRAD_T") ? atoi(getenv("P5_DGRAD_T")) : 1;       // data gradients on the transposed weight copy when one is bound
+static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS")) : 3;   // 3 = MFMA cross-attention, 2 = scalar score / PV loops
+static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
+static int g_opt_dec_head_nv = getenv("P5_DEC_HEAD_NV") ? atoi(getenv("P5_DEC_HEAD_NV")) : 0;   // streaming head: forced E rows per workgroup (0 = auto)
 
 template <class T, int BM, int BN>
 static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
@@ -128,6 +133,8 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
+  // one full round of 128x128 tiles with a long reduction (8192 x 512 x {1536, 2048}: FFN down-projection, wi / qkv data gradients)
+  if (!force_tile && g_opt_gemm_bigk > 0 && !g.a_ks && !g.b_ks && t128 >= 256 && g.K >= g_opt_gemm_bigk && g.epi != P5_EPI_ATOMIC) big = true;
   // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
   // split-K so that tiles x splits ~ 160: in isolation ~256 (every CU) is fastest, inside the step fewer, longer workgroups leave
   // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
@@ -239,6 +246,28 @@ struct Bump {
 
 struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S, *fold; int sz, fused; };
 
+struct GenWs {
+  void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
+  void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
+  void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
+  float* x32;             // [R, d] fp32 residual stream of the decode step (v2: updated in place with atomics)
+  float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
+  float *part_m, *part_s; int* cand_key;   // streaming head: per (row, vocabulary tile) max / sum exp; candidate keys of pools beyond the LDS budget
+  int64_t* mask_copy;
+  float* ssq;             // [3 * n_dec_layers + 1][R] row sums of squares of the residual stream entering each norm (fused path)
+  uint32_t* excluded;     // [B, excl_words] copy of the caller's per-item excluded-node bitmap (stable address for the graph)
+  P5BeamState st;
+};
+
+// state of the search between p5_decode_begin and p5_decode_finish (the workspace layout, the trie, the step counter)
+struct GenCtx {
+  bool active = false;
+  GenWs w;
+  int B = 0, L = 0, K = 0, max_len = 0, max_c = 0, excl_words = 0, steps = 0;
+  const int *child_off = nullptr, *child_tok = nullptr, *child_node = nullptr, *roots = nullptr;
+  char* ws = nullptr;
+};
+
 struct P5Engine {
   P5Config c;
   int inner;
@@ -273,7 +302,16 @@ struct P5Engine {
   void* fold = nullptr;
   std::vector<int64_t> fold_qkv, fold_q, fold_wi;
   int64_t fold_E = 0, fold_count = 0;
+  GenCtx gen;
+  // transposed bf16 copies of the 2-D layer weights (same arena offsets): the data gradients dx = dy W then read W^T as a
+  // K-contiguous operand, i.e. run on the forward kernel (p5_engine_bind_transposed; optional)
+  void* St = nullptr;
+  struct TrDesc { int64_t off; int rows, cols, tile0; };
+  std::vector<TrDesc> tr_list;
+  int tr_tiles = 0;
+  bool tr_pending = false;
 #ifndef P5_EMU
+  hipEvent_t tr_ev = nullptr;
   hipGraphExec_t gen_graph_exec = nullptr;
   bool gen_graph_failed = false;
   GraphKey gen_graph_key;
@@ -404,6 +442,25 @@ static void build_layout(P5Engine* e) {
   }
   add_param(e, "decoder.final_layer_norm.weight", 1, d, e->off_dec_fln);
   e->n_params = (e->n_params + 63) & ~(int64_t)63;
+  // weights whose data gradient runs on the transposed copy: (offset, rows, cols) of each [rows, cols] block
+  {
+    e->tr_list.clear();
+    int tiles = 0;
+    auto add = [&](int64_t off, int rows, int cols) {
+      e->tr_list.push_back({off, rows, cols, tiles});
+      tiles += ((rows + 63) / 64) * ((cols + 63) / 64);
+    };
+    const int wi_rows = (c.gated_gelu ? 2 : 1) * F;
+    for (int i = 0; i < c.n_enc_layers; ++i) {
+      add(e->enc[i].sa.q, 3 * e->inner, d); add(e->enc[i].sa.o, d, e->inner); add(e->enc[i].wi, wi_rows, d); add(e->enc[i].wo, d, F);
+    }
+    add(e->dec[0].ca.k, c.n_dec_layers * 2 * e->inner, d);
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      add(e->dec[i].sa.q, 3 * e->inner, d); add(e->dec[i].sa.o, d, e->inner); add(e->dec[i].ca.q, e->inner, d); add(e->dec[i].ca.o, d, e->inner);
+      add(e->dec[i].wi, wi_rows, d); add(e->dec[i].wo, d, F);
+    }
+    e->tr_tiles = tiles;
+  }
   // folded decode-step weights (element offsets into the fold buffer, 64-element aligned)
   {
     const int in = c.n_heads * c.d_kv;
@@ -467,6 +524,15 @@ static int linear_dgrad(hipStream_t s, const void* dy, int lddy, const T* W, voi
                         int epi = P5_EPI_STORE, const void* aux = nullptr, int ldaux = 0, float alpha = 1.f, int c_f32 = 0) {
   return gemm<T>(s, dy, lddy, 0, W, K_in, 1, dx, lddx, M, K_in, N_out, epi, aux, ldaux, alpha, c_f32, no_drop());
 }
+// dx = dy W with W given by its arena offset: when a transposed copy is bound (bf16), W^T [K_in, N_out] is a K-contiguous operand
+// and the product runs on the forward kernel (direct-to-LDS copies of both operands) instead of the K-strided-B variant
+template <class T>
+static int dgrad_w(P5Engine* e, hipStream_t s, const void* dy, int lddy, int64_t w_off, void* dx, int lddx, int M, int N_out, int K_in,
+                   int epi = P5_EPI_STORE, const void* aux = nullptr, int ldaux = 0, float alpha = 1.f, int c_f32 = 0) {
+  if (sizeof(T) == 2 && e->St && g_opt_dgrad_t && (N_out % 64) == 0)
+    return gemm<T>(s, dy, lddy, 0, (const T*)e->St + w_off, N_out, 0, dx, lddx, M, K_in, N_out, epi, aux, ldaux, alpha, c_f32, no_drop());
+  return linear_dgrad<T>(s, dy, lddy, Wc<T>(e, w_off), dx, lddx, M, N_out, K_in, epi, aux, ldaux, alpha, c_f32);
+}
 // dW += dy^T x   (fp32 atomics into the grad arena)
 template <class T>
 static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
@@ -494,8 +560,13 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   if (nblocks_out) *nblocks_out = blocks;
-  P5_LAUNCH((p5_rmsnorm_bwd_kernel<T>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd,
-            dres_in, rows, d, din, dnext, dw_partial);
+  const int nch = (d / TT<T>::EPF + 63) / 64;          // 16-byte pieces per lane
+#define P5_NBWD(N) P5_LAUNCH((p5_rmsnorm_bwd_kernel<T, N>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd, \
+                             dres_in, rows, d, din, dnext, dw_partial)
+  if (nch <= 1) P5_NBWD(1);
+  else if (nch == 2) P5_NBWD(2);
+  else P5_NBWD(4);
+#undef P5_NBWD
   return P5_KCHECK();
 }
 
@@ -700,17 +771,17 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
   const float hscale = (e->training && c.dropout > 0.f) ? 1.f / (1.f - c.dropout) : 1.f;
   P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
   if (c.gated_gelu) {
-    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F));
+    P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.wo, e->dh, F, rows, d, F));
     const size_t n = (size_t)rows * F;
     P5_LAUNCH((p5_gated_gelu_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
               (T*)e->du, (const T*)e->dh, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
     P5_TRY(P5_KCHECK());
     P5_TRY(linear_wgrad<T>(e, s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
-    P5_TRY(linear_dgrad<T>(s, e->du, 2 * F, Wc<T>(e, lo.wi), e->dn, d, rows, 2 * F, d));
+    P5_TRY(dgrad_w<T>(e, s, e->du, 2 * F, lo.wi, e->dn, d, rows, 2 * F, d));
   } else {
-    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.wo), e->dh, F, rows, d, F, P5_EPI_MASK_POS, l.h_ff, F, hscale));
+    P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.wo, e->dh, F, rows, d, F, P5_EPI_MASK_POS, l.h_ff, F, hscale));
     P5_TRY(linear_wgrad<T>(e, s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
-    P5_TRY(linear_dgrad<T>(s, e->dh, F, Wc<T>(e, lo.wi), e->dn, d, rows, F, d));
+    P5_TRY(dgrad_w<T>(e, s, e->dh, F, lo.wi, e->dn, d, rows, F, d));
   }
   return 0;
 }
@@ -738,7 +809,7 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads;
   P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_sa, in, e->G + lo.sa.o, rows, d, in));
-  P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.sa.o), e->dO, in, rows, d, in));
+  P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.sa.o, e->dO, in, rows, d, in));
   P5AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa; a.dO = e->dO;
@@ -753,7 +824,7 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.drop = mk_drop(e, is_dec ? 1 : 0, li, 1);
   P5_TRY(launch_attn_bwd<T>(a, s));
   P5_TRY(linear_wgrad<T>(e, s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
-  P5_TRY(linear_dgrad<T>(s, e->dqkv, 3 * in, Wc<T>(e, lo.sa.q), e->dn, d, rows, 3 * in, d));
+  P5_TRY(dgrad_w<T>(e, s, e->dqkv, 3 * in, lo.sa.q, e->dn, d, rows, 3 * in, d));
   return 0;
 }
 
@@ -773,6 +844,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     e->side_done_valid[0] = e->side_done_valid[1] = false;
 #endif
     begin_sublayer(e);
+#ifndef P5_EMU
+    if (e->tr_pending && e->tr_ev) { hipStreamWaitEvent(s, e->tr_ev, 0); hipStreamWaitEvent(e->side ? e->side : s, e->tr_ev, 0); }
+#endif
+    e->tr_pending = false;
     if (!dnll) P5_REQUIRE(e->out_attn, "backward without dnll needs p5_forward_loss (output_attention mask)");
     P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
               e->labels, dnll, c.vocab_size, e->Vp, e->Vp, e->out_attn, e->T, 1.0f / (float)e->B);
@@ -806,7 +881,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     // cross attention
     begin_sublayer(e);
     P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
-    P5_TRY(linear_dgrad<T>(s, e->dy, d, Wc<T>(e, lo.ca.o), e->dO, in, Md, d, in));
+    P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.ca.o, e->dO, in, Md, d, in));
     P5AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = l.q_ca; a.K = l.kv_ca; a.V = (const T*)l.kv_ca + in; a.O = l.o_ca; a.lse = l.lse_ca; a.dO = e->dO;
@@ -817,7 +892,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     a.lddq = in; a.lddk = a.lddv = ldkv; a.causal = 0; a.drop = mk_drop(e, 1, i, 3);
     P5_TRY(launch_attn_bwd<T>(a, s));
     P5_TRY(linear_wgrad<T>(e, s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
-    P5_TRY(linear_dgrad<T>(s, e->dqkv, in, Wc<T>(e, lo.ca.q), e->dn, d, Md, in, d));
+    P5_TRY(dgrad_w<T>(e, s, e->dqkv, in, lo.ca.q, e->dn, d, Md, in, d));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
     // self attention
     begin_sublayer(e);
@@ -831,7 +906,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       // (K = n_dec * 2 * inner), both off the critical path on the side stream; the encoder backward joins it (stage nd + 2)
       const int ldkv = nd * 2 * in;
       P5_TRY(linear_wgrad<T>(e, s, e->dkv_all, ldkv, e->enc_out, d, e->G + e->dec[0].ca.k, M, ldkv, d));
-      P5_TRY(linear_dgrad<T>(e->side ? e->side : s, e->dkv_all, ldkv, Wc<T>(e, e->dec[0].ca.k), e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
+      P5_TRY(dgrad_w<T>(e, e->side ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
                              nullptr, 0, 1.f, 1));
     }
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
@@ -876,17 +951,6 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
 }
 
 // ---- generation ------------------------------------------------------------------------------------------
-struct GenWs {
-  void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
-  void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
-  void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
-  float* x32;             // [R, d] fp32 residual stream of the decode step (v2: updated in place with atomics)
-  float *logits, *cand, *row_top_score; int *n_cand, *row_top_c;
-  int64_t* mask_copy;
-  float* ssq;             // [3 * n_dec_layers + 1][R] row sums of squares of the residual stream entering each norm (fused path)
-  uint32_t* excluded;     // [B, excl_words] copy of the caller's per-item excluded-node bitmap (stable address for the graph)
-  P5BeamState st;
-};
 
 static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_len, int max_c, int excl_words, GenWs* g) {
   const P5Config& c = e->c;
@@ -909,6 +973,9 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   w.logits = (float*)b.take(R * Vp * 4);
   w.ssq = (float*)b.take((size_t)(3 * c.n_dec_layers + 1) * R * 4);
   w.cand = (float*)b.take(R * (size_t)max_c * 4);
+  w.cand_key = (int*)b.take(R * (size_t)max_c * 4);
+  w.part_m = (float*)b.take(R * (size_t)((c.vocab_size + 15) / 16) * 4);
+  w.part_s = (float*)b.take(R * (size_t)((c.vocab_size + 15) / 16) * 4);
   w.n_cand = (int*)b.take(R * 4);
   w.row_top_score = (float*)b.take(R * (size_t)(2 * K) * 4);
   w.row_top_c = (int*)b.take(R * (size_t)(2 * K) * 4);
@@ -923,6 +990,10 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   st.unsat = (int*)b.take((size_t)B * 4);
   st.last_tok = (int64_t*)b.take(R * 8);
   st.flags = (int*)b.take(64);
+  // latency-shaped decode step: the beam step itself writes the next step's input embeddings into the fp32 residual stream
+  st.x32 = g_opt_decode_v2 ? w.x32 : nullptr;
+  st.E32 = e->P ? e->P + e->off_E : nullptr;
+  st.d = d;
   return (int64_t)((b.off + 255) & ~(size_t)255);
 }
 
@@ -1009,7 +1080,10 @@ static int decode_step(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, 
 template <class T, int NB, int AMODE>
 static int launch_skinny_nb(const P5SkinnyArgs& g, int splits, int need_bytes, hipStream_t s) {
   dim3 grid((g.N + NB - 1) / NB, (g.M + 15) / 16, splits), block(256);
+  // (the static LDS size is what bounds the workgroups per CU: 52 KiB -> 3, 80 KiB -> 2 of the 160 KiB)
   if (need_bytes <= 44 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 44>), grid, block, 0, s, g);
+  else if (need_bytes <= 52 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 52>), grid, block, 0, s, g);
+  else if (need_bytes <= 80 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 80>), grid, block, 0, s, g);
   else if (need_bytes <= 100 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 100>), grid, block, 0, s, g);
   else if (need_bytes <= 140 * 1024) P5_LAUNCH((p5_skinny_gemm_kernel<T, NB, AMODE, 140>), grid, block, 0, s, g);
   else return fail("skinny gemm: tile does not fit the LDS");
@@ -1025,10 +1099,10 @@ static int skinny(hipStream_t s, int amode, const void* A, int lda, const float*
   P5SkinnyArgs g;
   g.A = A; g.ln = ln; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.epi = epi; g.alpha = alpha; g.eps = eps;
   g.done = done;
-  auto need = [&](int nb, int kw) { return (kw / EPS) * (2048 + nb * 128) + 3072; };
+  auto need = [&](int nb, int kw) { return (kw / EPS) * (2048 + nb * 128) + (nb < 64 ? 3072 : 0); };   // (+ cross-wave reduction buffer when waves split K)
   int nb = g_opt_dec_nb, kw = K, splits = 1;
   if (amode == 1) {
-    if (!nb) nb = need(64, K) <= 100 * 1024 ? 64 : (need(32, K) <= 100 * 1024 ? 32 : 16);
+    if (!nb) nb = need(64, K) <= 80 * 1024 ? 64 : (need(32, K) <= 100 * 1024 ? 32 : 16);
   } else {
     if (!nb) nb = 64;
     // K range per workgroup: at most 512 (bf16) / 256 (fp32) elements -- one 80 KiB burst -- and enough splits for >= ~200 workgroups
@@ -1052,25 +1126,31 @@ static int skinny(hipStream_t s, int amode, const void* A, int lda, const float*
   return launch_skinny_nb<T, 16, 0>(g, splits, nbytes, s);
 }
 
+// streaming head: rows of E kept in LDS per workgroup (0 = materialised-logits path): the largest of 128/64/32/16 whose tile
+// fits 128 KiB (bf16 d_model 512 -> 128, 768/1024 -> 64; fp32 512 -> 64, 768/1024 -> 32)
+static int head_nv(const P5Engine* e) {
+  if (!g_opt_dec_head || !g_opt_decode_v2) return 0;
+  const size_t row = (size_t)e->c.d_model * (e->c.dtype == 1 ? 2 : 4);
+  if (g_opt_dec_head_nv) return (size_t)g_opt_dec_head_nv * row <= 128 * 1024 ? g_opt_dec_head_nv : 0;
+  for (int nv = 128; nv >= 16; nv >>= 1)
+    if ((size_t)nv * row <= 128 * 1024) return nv;
+  return 0;
+}
+
 template <class T>
 static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, R = B * K;
   const int* done = w.st.flags + 4;
-  float* x = w.x32;
-  P5_LAUNCH(p5_embed_f32_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, (const float*)(e->P + e->off_E), (const int64_t*)w.st.last_tok, R, d, done);
-  P5_TRY(P5_KCHECK());
+  float* x = w.x32;       // holds E32[last token] of every row: written by the previous beam step (or the initial state)
   constexpr int EPS = SkT<T>::EPS;
-  const bool fuseq = g_opt_dec_fuseq && sizeof(T) == 2 && (d / EPS) * (2048 + 64 * 128) + 3072 + 12544 + 2 * 16384 <= 128 * 1024;
+  // LDS of the fused kernel: q image 2 KiB + scores 8.25 + probabilities 2 x 4.25 + stats + K/V chunk images 2 x 16 KiB + normalised
+  // rows + the head's Wq slice + reduction buffer
+  const bool fuseq = g_opt_dec_fuseq && sizeof(T) == 2 && (d / EPS) * (2048 + 64 * 128) + 3072 + 19712 + 2 * 16384 <= 136 * 1024;
   for (int i = 0; i < c.n_dec_layers; ++i) {
     const LayerOff& lo = e->dec[i];
     // ---- self-attention: qkv = norm(x) Wqkv^T ; attention over the ancestry-indexed cache ; x += o Wo^T ----
     P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.sa.ln, Wc<T>(e, lo.sa.q), d, w.qkv, 3 * in, R, 3 * in, d, P5_SK_STORE, 1.f, c.eps, done));
-    if (getenv("P5_DBG_OLD_SELF"))
-    P5_LAUNCH((p5_dec_self_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i],
-              (const int*)w.st.anc, (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H,
-              (const int*)(w.st.flags + 2), max_len);
-    else
     P5_LAUNCH((p5_dec_self_attn2_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
               (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
     P5_TRY(P5_KCHECK());
@@ -1081,14 +1161,14 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
     a.R = R; a.H = H; a.Kb = K; a.L = L; a.d = d; a.eps = c.eps; a.done = done;
     const dim3 cgrid(B * ((K + 15) / 16), H);
     if (fuseq) {
-      if constexpr (sizeof(T) == 2) P5_LAUNCH((p5_dec_cross_attn2_kernel<T, true, 128>), cgrid, dim3(256), 0, s, a);
+      if constexpr (sizeof(T) == 2) {
+        if (g_opt_dec_cross == 3) P5_LAUNCH((p5_dec_cross_attn3_kernel<T, true, 136>), cgrid, dim3(256), 0, s, a);
+        else P5_LAUNCH((p5_dec_cross_attn2_kernel<T, true, 128>), cgrid, dim3(256), 0, s, a);
+      }
     } else {
       P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.ca.ln, Wc<T>(e, lo.ca.q), d, w.q, in, R, in, d, P5_SK_STORE, 1.f, c.eps, done));
-      if (getenv("P5_DBG_OLD_CROSS"))
-      P5_LAUNCH((p5_dec_cross_attn_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.q, (const T*)w.kv_cross[i],
-              (const int64_t*)w.mask_copy, R, H, K, L);
-      else
-      P5_LAUNCH((p5_dec_cross_attn2_kernel<T, false, sizeof(T) == 2 ? 48 : 80>), cgrid, dim3(256), 0, s, a);
+      if (g_opt_dec_cross == 3) P5_LAUNCH((p5_dec_cross_attn3_kernel<T, false, sizeof(T) == 2 ? 52 : 96>), cgrid, dim3(256), 0, s, a);
+      else P5_LAUNCH((p5_dec_cross_attn2_kernel<T, false, sizeof(T) == 2 ? 48 : 80>), cgrid, dim3(256), 0, s, a);
     }
     P5_TRY(P5_KCHECK());
     P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.ca.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
@@ -1108,17 +1188,34 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
   const int Vp = (c.vocab_size + 63) / 64 * 64;
   P5_LAUNCH((p5_rmsnorm_f32in_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.hn, (const float*)x, (const float*)(e->P + e->off_dec_fln), R, d, c.eps, done);
   P5_TRY(P5_KCHECK());
-  return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, 1.0f / sqrtf((float)d), 1);
+  const float alpha = 1.0f / sqrtf((float)d);
+  if (head_nv(e) > 0) {
+    // streaming head: per-tile (max, sum exp) only; the children's logits are recomputed by p5_beam_step2_kernel
+    const int nv = head_nv(e), V = c.vocab_size, nt = (V + nv - 1) / nv;
+    const size_t bytes = (size_t)nv * d * sizeof(T);
+#define P5_HEAD(NV, KB) P5_LAUNCH((p5_head_lse_kernel<T, NV, KB>), dim3(nt), dim3(256), 0, s, w.part_m, w.part_s, (const T*)w.hn, Wc<T>(e, e->off_E), R, d, V, alpha, done)
+    if (nv == 128) P5_HEAD(128, 128);
+    else if (nv == 64 && bytes <= 64 * 1024) P5_HEAD(64, 64);
+    else if (nv == 64) P5_HEAD(64, 128);
+    else if (nv == 32 && bytes <= 64 * 1024) P5_HEAD(32, 64);
+    else if (nv == 32) P5_HEAD(32, 128);
+    else P5_HEAD(16, 64);
+#undef P5_HEAD
+    return P5_KCHECK();
+  }
+  return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, alpha, 1);
 }
 
+// ---- the search as three calls (p5_decode_begin / p5_decode_step / p5_decode_finish); p5_generate strings them together ----
 template <class T>
-static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
-                         const int* roots, const uint32_t* excluded, int excl_words, int max_c, int* out_seq, float* out_score, int* out_len,
-                         char* ws, hipStream_t s) {
+static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                             const int* roots, const uint32_t* excluded, int excl_words, int max_c, char* ws, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, R = B * K;
-  GenWs w;
-  layout_gen(e, ws, B, L, K, max_len, max_c, excl_words, &w);
+  GenCtx& g = e->gen;
+  g.active = false;
+  layout_gen(e, ws, B, L, K, max_len, max_c, excl_words, &g.w);
+  GenWs& w = g.w;
   if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
   P5_TRY(encoder_fwd<T>(e, s));
@@ -1127,72 +1224,98 @@ static int generate_impl(P5Engine* e, int B, int L, int K, int max_len, const in
   P5_LAUNCH(p5_beam_init_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, child_off, child_tok, child_node, roots, B, K, max_len,
             c.pad_id);
   P5_TRY(P5_KCHECK());
-  const int Vp = (c.vocab_size + 63) / 64 * 64;
   hipMemcpyAsync(w.mask_copy, e->mask, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s);
   if (excl_words > 0) hipMemcpyAsync(w.excluded, excluded, (size_t)B * excl_words * 4, hipMemcpyDeviceToDevice, s);
+  g.B = B; g.L = L; g.K = K; g.max_len = max_len; g.max_c = max_c; g.excl_words = excl_words; g.ws = ws;
+  g.child_off = child_off; g.child_tok = child_tok; g.child_node = child_node; g.roots = roots;
+  g.steps = 0;
+  g.active = true;
+  return 0;
+}
+
+template <class T>
+static int decode_step_body(P5Engine* e, hipStream_t s) {
+  const P5Config& c = e->c;
+  GenCtx& g = e->gen;
+  GenWs& w = g.w;
+  const int d = c.d_model, B = g.B, L = g.L, K = g.K, R = B * K, max_len = g.max_len, max_c = g.max_c, excl_words = g.excl_words;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
   const uint32_t* excl = excl_words > 0 ? w.excluded : nullptr;
-  auto step_body = [&]() -> int {
-    hipMemsetAsync(w.st.flags, 0, 8, s);
-    if (g_opt_decode_v2) P5_TRY(decode_step2<T>(e, w, B, L, K, max_len, s));
-    else P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
+  const int* done = w.st.flags + 4;
+  if (g_opt_decode_v2) P5_TRY(decode_step2<T>(e, w, B, L, K, max_len, s));
+  else P5_TRY(decode_step<T>(e, w, B, L, K, max_len, s));
+  if (head_nv(e) > 0) {
+    const int nv = head_nv(e), nt = (c.vocab_size + nv - 1) / nv;
+    P5_LAUNCH((p5_dec_score2_kernel<T>), dim3(R), dim3(256), 0, s, w.row_top_score, w.row_top_c, w.n_cand, w.cand, (const float*)w.part_m,
+              (const float*)w.part_s, nt, (const T*)w.hn, Wc<T>(e, e->off_E), d, 1.0f / sqrtf((float)d), (const int*)w.st.run_node,
+              (const float*)w.st.run_score, g.child_off, g.child_tok, g.child_node, excl, excl_words, K, max_c, 2 * K, done);
+  } else {
     P5_LAUNCH(p5_dec_score_kernel, dim3(R), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_cand, (const float*)w.logits, Vp,
-              c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, child_off, child_tok, child_node, excl, excl_words, K, max_c, 2 * K);
-    P5_TRY(P5_KCHECK());
-    P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
-              (const int*)w.n_cand, child_off, child_tok, child_node, max_c, K, max_len, c.eos_id, R);
-    return P5_KCHECK();
-  };
+              c.vocab_size, (const int*)w.st.run_node, (const float*)w.st.run_score, g.child_off, g.child_tok, g.child_node, excl, excl_words, K, max_c,
+              2 * K, done);
+  }
+  P5_TRY(P5_KCHECK());
+  P5_LAUNCH(p5_beam_step_kernel, dim3(B), dim3(256), 0, s, w.st, (const float*)w.row_top_score, (const int*)w.row_top_c,
+            (const int*)w.n_cand, g.child_off, g.child_tok, g.child_node, max_c, K, max_len, c.eos_id, R);
+  return P5_KCHECK();
+}
+
+// One beam-search step: the whole decoder over R = B*K rows, the tied head, HF's candidate selection and bookkeeping.  Nothing
+// is read back: HF's global stop test (utils.py:3055-3075) is taken on the device by the beam step, which raises flags[4]; a
+// step enqueued after that returns at once in every kernel.  From the second step of a call on, the step is replayed from a
+// hipGraph captured once per (shape, workspace, trie, option) key.
+template <class T>
+static int decode_step_impl(P5Engine* e, hipStream_t s) {
+  GenCtx& g = e->gen;
+  P5_REQUIRE(g.active, "p5_decode_step without p5_decode_begin");
+  if (g.steps >= g.max_len - 1) return 0;          // no hypothesis can grow beyond max_len tokens
 #ifndef P5_EMU
-  // one decode step = ~85 tiny dependent kernels: capture it once into a hipGraph and replay it per step
   static const bool use_graph = !(getenv("P5_NO_GRAPH") && atoi(getenv("P5_NO_GRAPH")));
   GraphKey key;
   memset(&key, 0, sizeof(key));
-  key.B = B; key.L = L; key.K = K; key.max_len = max_len; key.max_c = max_c; key.excl_words = excl_words; key.ws = ws; key.trie = child_off; key.trie_tok = child_tok; key.trie_node = child_node; key.roots = roots;
-  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.fused = g_opt_decode_fused + 2 * g_opt_decode_v2 + 4 * g_opt_dec_fuseq + 8 * g_opt_dec_nb + 4096 * g_opt_dec_kw;
+  key.B = g.B; key.L = g.L; key.K = g.K; key.max_len = g.max_len; key.max_c = g.max_c; key.excl_words = g.excl_words; key.ws = g.ws;
+  key.trie = g.child_off; key.trie_tok = g.child_tok; key.trie_node = g.child_node; key.roots = g.roots;
+  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold;
+  key.fused = g_opt_decode_fused + 2 * g_opt_decode_v2 + 4 * g_opt_dec_fuseq + 8 * g_opt_dec_nb + 4096 * g_opt_dec_kw + (g_opt_dec_cross << 20) +
+              (g_opt_dec_head << 23) + (g_opt_dec_head_nv << 24);
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
-  auto capture = [&]() {
+  if (use_graph && !have_graph && g.steps >= 1 && !e->gen_graph_failed) {
     // (never during the very first step: the first launch of a kernel loads its code object, which is not allowed
     // while a stream is capturing)
     if (e->gen_graph_exec) { hipGraphExecDestroy(e->gen_graph_exec); e->gen_graph_exec = nullptr; }
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return; }
-    const int rc = step_body();
-    const hipError_t ec = hipStreamEndCapture(s, &graph);
-    if (rc == 0 && ec == hipSuccess && graph && hipGraphInstantiate(&e->gen_graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-      e->gen_graph_key = key;
-      have_graph = true;
-    } else {
-      e->gen_graph_exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+      const int rc = decode_step_body<T>(e, s);
+      const hipError_t ec = hipStreamEndCapture(s, &graph);
+      if (rc == 0 && ec == hipSuccess && graph && hipGraphInstantiate(&e->gen_graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        e->gen_graph_key = key;
+        have_graph = true;
+      } else {
+        e->gen_graph_exec = nullptr;
+      }
+      if (graph) hipGraphDestroy(graph);
     }
-    if (graph) hipGraphDestroy(graph);
     (void)hipGetLastError();
-  };
-#endif
-  int steps_run = 0;
-  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
-#ifndef P5_EMU
-    if (use_graph && !have_graph && steps_run >= 1 && !e->gen_graph_failed) {
-      capture();
-      if (!have_graph) e->gen_graph_failed = true;
-    }
-    if (have_graph) {
-      if (hipGraphLaunch(e->gen_graph_exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
-    } else
-#endif
-    {
-      P5_TRY(step_body());
-    }
-    steps_run++;
-    int flags[2] = {1, 1};
-    hipMemcpyAsync(flags, w.st.flags, 8, hipMemcpyDeviceToHost, s);
-    hipStreamSynchronize(s);
-    if (!(flags[0] > 0 && flags[1] > 0)) break;   // HF utils.py:3055-3075
+    if (!have_graph) e->gen_graph_failed = true;
   }
-  // the finished set written by the last step lives in the "next" buffer of that step's parity
-  if (steps_run & 1) std::swap(w.st.fin_seq, w.st.fin_seq_next);
-  hipMemcpyAsync(out_seq, w.st.fin_seq, (size_t)R * max_len * 4, hipMemcpyDeviceToDevice, s);
-  hipMemcpyAsync(out_score, w.st.fin_score, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
-  hipMemcpyAsync(out_len, w.st.fin_len, (size_t)R * 4, hipMemcpyDeviceToDevice, s);
+  if (have_graph) {
+    if (hipGraphLaunch(e->gen_graph_exec, s) != hipSuccess) return fail("hipGraphLaunch failed");
+    g.steps++;
+    return 0;
+  }
+#endif
+  P5_TRY(decode_step_body<T>(e, s));
+  g.steps++;
+  return 0;
+}
+
+static int decode_finish_impl(P5Engine* e, int* out_seq, float* out_score, int* out_len, hipStream_t s) {
+  GenCtx& g = e->gen;
+  P5_REQUIRE(g.active, "p5_decode_finish without p5_decode_begin");
+  const int R = g.B * g.K;
+  P5_LAUNCH(p5_beam_finalize_kernel, dim3((R * g.max_len + 255) / 256), dim3(256), 0, s, out_seq, out_score, out_len, g.w.st, R, g.max_len);
+  P5_TRY(P5_KCHECK());
+  g.active = false;
   return 0;
 }
 
@@ -1224,6 +1347,42 @@ static int refresh_fold(P5Engine* e, hipStream_t s) {
   return fold(e->fold_E, e->off_E, e->off_dec_fln, c.vocab_size);
 }
 
+// out[c, r] = in[r, c] for every [rows, cols] block of the descriptor table (64 x 64 tiles through LDS, 16-byte row accesses)
+struct P5TrDesc { int64_t off; int rows, cols, tile0; };
+__global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restrict__ out, const bf16* __restrict__ in, const P5TrDesc* __restrict__ tab,
+                                                                 int ndesc) {
+  __shared__ unsigned short tile[64][66];
+  const int t = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;             // last descriptor with tile0 <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const P5TrDesc dsc = tab[lo];
+  const int tc = (dsc.cols + 63) / 64;
+  const int lt = t - dsc.tile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
+  const unsigned short* src = (const unsigned short*)in + dsc.off;
+  unsigned short* dst = (unsigned short*)out + dsc.off;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {        // 64 rows x 8 pieces of 8 elements
+    const int r = i >> 3, p = (i & 7) * 8;
+    if (r0 + r < dsc.rows && c0 + p < dsc.cols) {           // (cols is a multiple of 8)
+      const u32x4 v = ld16(src + (size_t)(r0 + r) * dsc.cols + c0 + p);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { tile[r][p + 2 * q] = (unsigned short)(v[q] & 0xFFFF); tile[r][p + 2 * q + 1] = (unsigned short)(v[q] >> 16); }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {        // 64 output rows (= input columns) x 8 pieces
+    const int c = i >> 3, p = (i & 7) * 8;
+    if (c0 + c < dsc.cols && r0 + p < dsc.rows) {           // (rows is a multiple of 8)
+      u32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (unsigned)tile[p + 2 * q][c] | ((unsigned)tile[p + 2 * q + 1][c] << 16);
+      st16(dst + (size_t)(c0 + c) * dsc.rows + r0 + p, v);
+    }
+  }
+}
+
 extern "C" {
 
 const char* p5_last_error(void) { return g_err.c_str(); }
@@ -1239,6 +1398,11 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_nb")) g_opt_dec_nb = value;
   else if (!strcmp(name, "dec_kw")) g_opt_dec_kw = value;
   else if (!strcmp(name, "dec_fuseq")) g_opt_dec_fuseq = value;
+  else if (!strcmp(name, "dgrad_t")) g_opt_dgrad_t = value;
+  else if (!strcmp(name, "gemm_bigk")) g_opt_gemm_bigk = value;
+  else if (!strcmp(name, "dec_cross")) g_opt_dec_cross = value;
+  else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
+  else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
   else return fail("p5_set_option: unknown option");
   return 0;
 }
@@ -1288,6 +1452,46 @@ int p5_engine_bind_decode_fold(P5Engine* e, void* buf) { e->fold = buf; return 0
 int p5_refresh_decode_fold(P5Engine* e, void* stream) {
   P5_REQUIRE(e->P && e->fold, "engine / fold buffer not bound");
   return e->c.dtype == 1 ? refresh_fold<bf16>(e, (hipStream_t)stream) : refresh_fold<float>(e, (hipStream_t)stream);
+}
+
+int64_t p5_transposed_bytes(const P5Engine* e) {
+  return (int64_t)e->n_params * 2 + 256 + (int64_t)e->tr_list.size() * (int64_t)sizeof(P5TrDesc);
+}
+int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream) {
+  e->St = buf;
+  if (!buf) return 0;
+  P5_REQUIRE(e->c.dtype == 1, "the transposed weight copy serves the bf16 mode only");
+  // the descriptor table lives behind the copy itself (the library allocates nothing)
+  std::vector<P5TrDesc> tab;
+  for (auto& t : e->tr_list) tab.push_back({t.off, t.rows, t.cols, t.tile0});
+  char* at = (char*)buf + (((size_t)e->n_params * 2 + 255) & ~(size_t)255);
+#ifndef P5_EMU
+  P5_REQUIRE(hipMemcpyAsync(at, tab.data(), tab.size() * sizeof(P5TrDesc), hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess, "descriptor upload");
+  hipStreamSynchronize((hipStream_t)stream);      // (tab is a host temporary; one-time set-up call)
+  if (!e->tr_ev) hipEventCreateWithFlags(&e->tr_ev, hipEventDisableTiming);
+#else
+  memcpy(at, tab.data(), tab.size() * sizeof(P5TrDesc));
+#endif
+  return 0;
+}
+// Rebuild the transposed copy from the bf16 shadow (call after every parameter update, e.g. right after p5_adamw_step).  With a
+// side stream bound it runs there, behind everything enqueued on `stream` so far; the next backward waits for it -- the
+// forward in between does not, so the ~0.2 GB of copies overlap it.
+int p5_refresh_transposed(P5Engine* e, void* stream) {
+  P5_REQUIRE(e->St && e->S, "transposed copy / shadow not bound");
+  hipStream_t main = (hipStream_t)stream;
+  hipStream_t s = main;
+#ifndef P5_EMU
+  if (e->side) { fork_to_side(e, main); s = e->side; }
+#endif
+  const P5TrDesc* tab = (const P5TrDesc*)((char*)e->St + (((size_t)e->n_params * 2 + 255) & ~(size_t)255));
+  P5_LAUNCH(p5_transpose_blocks_kernel, dim3(e->tr_tiles), dim3(256), 0, s, (bf16*)e->St, (const bf16*)e->S, tab, (int)e->tr_list.size());
+  P5_TRY(P5_KCHECK());
+#ifndef P5_EMU
+  if (e->tr_ev) hipEventRecord(e->tr_ev, s);
+#endif
+  e->tr_pending = true;
+  return 0;
 }
 
 int p5_refresh_shadow(P5Engine* e, void* stream) {
@@ -1385,9 +1589,9 @@ int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int 
   P5Engine tmp = *e;
   return layout_gen(&tmp, nullptr, B, L, K, max_len, max_children, excluded_words, nullptr);
 }
-int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
-                int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
-                const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
+int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
+                    int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
+                    const uint32_t* excluded_nodes, int excluded_words, int max_children, void* ws, int64_t ws_bytes, void* stream) {
   P5_REQUIRE(e->P, "engine not bound");
   P5_REQUIRE(K >= 1 && K <= 64, "1 <= num_beams <= 64");
   P5_REQUIRE(max_len >= 2 && max_len <= 64, "2 <= max_length <= 64");
@@ -1399,10 +1603,27 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
   P5_REQUIRE(ws_bytes >= need, "workspace too small");
   e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
   return e->c.dtype == 1
-             ? generate_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children, out_seq, out_score, out_len, (char*)ws,
-                                   (hipStream_t)stream)
-             : generate_impl<float>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children, out_seq, out_score, out_len,
-                                    (char*)ws, (hipStream_t)stream);
+             ? decode_begin_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children,
+                                       (char*)ws, (hipStream_t)stream)
+             : decode_begin_impl<float>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children,
+                                        (char*)ws, (hipStream_t)stream);
+}
+int p5_decode_step(P5Engine* e, void* stream) {
+  return e->c.dtype == 1 ? decode_step_impl<bf16>(e, (hipStream_t)stream) : decode_step_impl<float>(e, (hipStream_t)stream);
+}
+const int* p5_decode_done_flag(const P5Engine* e) { return e->gen.active ? e->gen.w.st.flags + 4 : nullptr; }
+int p5_decode_finish(P5Engine* e, int* out_seq, float* out_score, int* out_len, void* stream) {
+  return decode_finish_impl(e, out_seq, out_score, out_len, (hipStream_t)stream);
+}
+int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
+                int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
+                const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
+  P5_TRY(p5_decode_begin(e, input_ids, whole_word_ids, attention_mask, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes,
+                         excluded_words, max_children, ws, ws_bytes, stream));
+  // every step is enqueued without reading anything back (the search stops on the device); the caller bounds max_len by the
+  // depth of the trie, so at most a step or two are no-ops
+  for (int cur_len = 1; cur_len < max_len; ++cur_len) P5_TRY(p5_decode_step(e, stream));
+  return p5_decode_finish(e, out_seq, out_score, out_len, stream);
 }
 int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L,
               void* enc_out, void* ws, int64_t ws_bytes, void* stream) {
@@ -1478,6 +1699,23 @@ int p5_op_skinny_gemm(int dtype, int amode, const void* A, int lda, const float*
                       int epi, float alpha, float eps, void* stream) {
   return dtype == 1 ? skinny<bf16>((hipStream_t)stream, amode, A, lda, ln, (const bf16*)W, ldw, C, ldc, M, N, K, epi, alpha, eps, nullptr)
                     : skinny<float>((hipStream_t)stream, amode, A, lda, ln, (const float*)W, ldw, C, ldc, M, N, K, epi, alpha, eps, nullptr);
+}
+// single-token cross-attention of R = B * Kb beam rows (q given, not fused): variant 3 = MFMA kernel, 2 = scalar kernel
+int p5_op_dec_cross_attn(int dtype, int variant, void* out, const void* q, const void* kv, const int64_t* mask, int B, int H, int Kb, int L,
+                         void* stream) {
+  P5CrossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out = out; a.q = q; a.kv = kv; a.mask = mask; a.R = B * Kb; a.H = H; a.Kb = Kb; a.L = L; a.d = 0; a.eps = 0.f; a.done = nullptr;
+  const dim3 grid(B * ((Kb + 15) / 16), H), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 1) {
+    if (variant == 3) P5_LAUNCH((p5_dec_cross_attn3_kernel<bf16, false, 52>), grid, block, 0, s, a);
+    else P5_LAUNCH((p5_dec_cross_attn2_kernel<bf16, false, 48>), grid, block, 0, s, a);
+  } else {
+    if (variant == 3) P5_LAUNCH((p5_dec_cross_attn3_kernel<float, false, 96>), grid, block, 0, s, a);
+    else P5_LAUNCH((p5_dec_cross_attn2_kernel<float, false, 80>), grid, block, 0, s, a);
+  }
+  return P5_KCHECK();
 }
 int p5_op_tr_probe(void* out, const void* in, void* stream) {
   P5_LAUNCH(p5_tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned short*)out, (const unsigned short*)in);

@@ -119,6 +119,7 @@ class _P5LossFn(torch.autograd.Function):
 class P5T5Native(nn.Module):
     LUT_HALF = 512
     use_side_stream = True
+    use_transposed_weights = True     # bf16: keep W^T of the layer weights for the data gradients (p5_engine_bind_transposed)
     fuse_decode_norms = True      # generate(): fold the decoder RMSNorms into the GEMMs around them
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
@@ -141,10 +142,13 @@ class P5T5Native(nn.Module):
         self.ddp_world = 1          # set by the runner: gradient all-reduce across ranks during backward
         self.ddp_group = None
         self._ddp_sync = True       # False on all but the last micro-batch of a gradient-accumulation group
+        self.ddp_bucket_dtype = "fp32"   # "bf16": gradient buckets travel as bf16 (half the bytes on the xGMI links)
         self._pending = []
         self._side = None
         self._fold = None
         self._fold_dirty = True
+        self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
+        self._tr_dirty = True
         self._build(seed)
 
     # ------------------------------------------------------------------ engine / arena plumbing
@@ -222,6 +226,11 @@ class P5T5Native(nn.Module):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self._be.device)
             self._lib.p5_engine_set_side_stream(self._engine, ctypes.c_void_p(self._side.cuda_stream))
+        if self.compute_dtype == 1 and self.use_transposed_weights:
+            nbytes = int(self._lib.p5_transposed_bytes(self._engine))
+            self._shadow_t = torch.zeros(nbytes, dtype=torch.uint8, device=self._be.device)
+            self._be.check(self._lib.p5_engine_bind_transposed(self._engine, _ptr(self._shadow_t), self._be.stream_ptr()), "p5_engine_bind_transposed")
+            self._tr_dirty = True
 
     @torch.no_grad()
     def _init_weights(self, seed):
@@ -272,6 +281,13 @@ class P5T5Native(nn.Module):
         """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
         self._shadow_dirty = not shadow_fresh
         self._fold_dirty = True
+        self._tr_dirty = True
+
+    def _sync_transposed(self):
+        """W^T of the layer weights for the next backward (enqueued on the side stream: it overlaps the forward)."""
+        if self._shadow_t is not None and self._tr_dirty:
+            self._be.check(self._lib.p5_refresh_transposed(self._engine, self._be.stream_ptr()), "p5_refresh_transposed")
+            self._tr_dirty = False
 
     # ------------------------------------------------------------------ nn.Module protocol
     def _apply(self, fn, recurse=True):
@@ -322,6 +338,7 @@ class P5T5Native(nn.Module):
             raise RuntimeError(f"load_state_dict: missing={missing} unexpected={unexpected}")
         self._shadow_dirty = True
         self._fold_dirty = True
+        self._tr_dirty = True
         return missing, unexpected
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -423,6 +440,7 @@ class P5T5Native(nn.Module):
         B, L = input_ids.shape
         T = labels.shape[1]
         self._sync_shadow()
+        self._sync_transposed()     # (no-op unless the parameters changed; a backward may follow this forward)
         ws = self._workspace(self._lib.p5_train_workspace_bytes(self._engine, B, L, T))
         nll = torch.empty(B * T, dtype=torch.float32, device=dev)
         training = 1 if (self.training and self.config.dropout_rate > 0) else 0
@@ -444,6 +462,7 @@ class P5T5Native(nn.Module):
             nst = lib.p5_backward_num_stages(eng)
             b, e = ctypes.c_int64(), ctypes.c_int64()
             self._pending = []
+            half = str(self.ddp_bucket_dtype).replace("torch.", "") in ("bf16", "bfloat16")
             for st in range(nst):
                 self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
                 lib.p5_backward_stage_range(eng, st, ctypes.byref(b), ctypes.byref(e))
@@ -452,9 +471,15 @@ class P5T5Native(nn.Module):
                     # AND carries the stage's weight-gradient GEMMs
                     ctx = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
                     with ctx:
-                        self._pending.append(dist.all_reduce(self._grads[b.value:e.value], op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True))
-            for w in self._pending:
+                        seg = self._grads[b.value:e.value]
+                        buf = seg.to(torch.bfloat16) if half else seg       # bf16 bucket: cast, reduce, cast back (below)
+                        self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True), buf, seg))
+            for w, buf, seg in self._pending:
                 w.wait()
+                if half:
+                    if buf.is_cuda:
+                        buf.record_stream(torch.cuda.current_stream())      # allocated on the side stream, read here
+                    seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
             self._pending = []
             if self._side is not None:
                 # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
@@ -481,6 +506,7 @@ class P5T5Native(nn.Module):
         output_attention = self._i64(output_attention, dev)
         T = labels.shape[1]
         self._sync_shadow()
+        self._sync_transposed()
         ws = self._workspace(self._lib.p5_train_workspace_bytes(self._engine, B, L, T))
         out = torch.empty(B * T + 1, dtype=torch.float32, device=dev)
         training = 1 if (self.training and self.config.dropout_rate > 0) else 0
@@ -565,6 +591,10 @@ class P5T5Native(nn.Module):
                 raise ValueError(f"excluded bitmap must be [B={B}, >= {(trie.n_nodes + 31) // 32}] uint32, got {excl_np.shape}")
             excl_words = int(excl_np.shape[1])
             excl_t = torch.from_numpy(excl_np.view(np.int32)).to(dev)
+        # no hypothesis is longer than the deepest trie path, and the search stops on the device (no per-step read-back):
+        # enqueue exactly as many decode steps as can do work.  (With max_length == depth the forced finish at max_length
+        # coincides with the leaves' </s>, so results are those of the unbounded call.)
+        max_length = max(2, min(int(max_length), int(trie.max_depth)))
         ws = self._workspace(self._lib.p5_generate_workspace_bytes(self._engine, B, L, K, max_length, maxc, excl_words), "_gen_ws")
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)

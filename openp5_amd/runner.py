@@ -50,6 +50,8 @@ def parse_runner_args(parser):
     parser.add_argument("--id_metrics", type=int, default=1, help="compare generated token ids with the gold ids on the device "
                         "instead of decoding to strings (same Hit/NDCG; 0 = the reference's string path).")
     parser.add_argument("--compute_dtype", type=str, default="bf16", help="bf16 (fast) or fp32 (parity) engine arithmetic")
+    parser.add_argument("--ddp_bucket_dtype", type=str, default="fp32", help="fp32 | bf16: dtype of the gradient buckets the ranks exchange "
+                        "(bf16 halves the bytes on the xGMI links; the sums are identical on every rank either way).")
     parser.add_argument("--resume", type=int, default=0, help="continue from <model_path>.resume when it exists (weights + optimizer "
                         "moments + schedule position + epoch/step + dropout and data-order state; the reference saves weights only).")
     parser.add_argument("--save_steps", type=int, default=0, help="with --resume: also write the resume file every N optimizer steps "
@@ -163,6 +165,7 @@ class DistributedRunner:
         self.device, self.args, self.rank = device, args, rank
         self.world = _world()
         self.model.ddp_world = self.world          # gradient all-reduce inside the staged backward
+        self.model.ddp_bucket_dtype = getattr(args, "ddp_bucket_dtype", "fp32")
         ds0 = self.train_loader.dataset.datasets[0] if train_loader is not None else None
         self.regenerate_candidate = ds0 is not None and "candidate_items" in ds0.info
         self.reconstruct_data = args.sample_prompt

@@ -97,6 +97,22 @@ class CompiledTrie:
         self.n_nodes = len(self.child_off) - 1
         self.max_children = int(np.max(np.diff(self.child_off))) if self.n_nodes > 0 else 0
         self._dev = {}
+        self._max_depth = None
+
+    @property
+    def max_depth(self) -> int:
+        """Number of tokens of the longest root-to-leaf path (including the decoder start token): no hypothesis of a search
+        constrained by this trie is longer, which bounds the number of decode steps worth enqueuing."""
+        if self._max_depth is None:
+            depth = np.zeros(self.n_nodes, dtype=np.int32)
+            # children always carry larger node ids than their parent (breadth-first numbering), so one forward sweep suffices
+            counts = np.diff(self.child_off)
+            parents = np.repeat(np.arange(self.n_nodes, dtype=np.int64), counts)
+            order = np.argsort(self.child_node[:len(parents)], kind="stable")
+            for e in order:
+                depth[self.child_node[e]] = depth[parents[e]] + 1
+            self._max_depth = int(depth.max()) if self.n_nodes > 0 else 0
+        return self._max_depth
 
     @staticmethod
     def from_dict(trie_dict: Dict[int, dict]) -> "CompiledTrie":

@@ -243,6 +243,7 @@ template <class T> static inline T __shfl_down(T v, int d) {
 
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 #define __expf expf

@@ -159,3 +159,25 @@ def test_skinny_gemm(emu, dtype, shape):
     column-tile widths 64 / 32 / 16 as d_model grows."""
     amode, M, N, K, epi = shape
     cases.skinny_gemm_case(emu, dtype, amode, M, N, K, epi)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("shape", [(3, 2, 10, 128), (2, 2, 5, 37), (2, 1, 20, 300), (1, 2, 16, 512)])
+def test_dec_cross_attn(emu, dtype, variant, shape):
+    """single-token cross-attention of the beams of an item (HF modeling_t5.py:404-432 with zero position bias): the matrix-core
+    kernel and the scalar kernel against float64, incl. ragged L, > 16 beams (two row tiles) and L = 512 (four key chunks)."""
+    cases.dec_cross_attn_case(emu, dtype, variant, *shape)
+
+
+def test_stepwise_decode_api(emu):
+    """include/p5hip.h: p5_decode_begin / p5_decode_step / p5_decode_done_flag / p5_decode_finish reproduce p5_generate."""
+    n = cases.stepwise_decode_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40)
+    assert n >= 3
+
+
+@pytest.mark.parametrize("n_wide,K", [(300, 6), (1100, 10)])
+def test_generate_wide_fanout(emu, n_wide, K):
+    """trie levels with 300 / 1100 siblings (ML-1M-like number pieces, collaborative <CIk> tokens): the streaming head's
+    per-row radix select, including the ties of the dead beams, reproduces HF's top-2K order."""
+    cases.generate_wide_fanout_case(emu, O.T5Cfg.named("tiny", vocab_size=1200), 2, 16, K, n_wide)

@@ -65,3 +65,41 @@ def test_two_ranks_one_gpu_gloo(hip, tmp_path):
     m._grads.copy_(0.5 * (gs[0] + gs[1]))
     opt.step()
     assert torch.allclose(m._flat, r0["flat"].cuda(), atol=1e-5, rtol=1e-4)
+
+
+def _nccl_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" IS RCCL on ROCm
+    from openp5_amd._lib import hip_backend
+    from openp5_amd.model import P5ModelConfig, P5T5Native
+    from openp5_amd.optim import FusedAdamW
+    from openp5_amd.runner import training_step
+    be = hip_backend(dev)
+    cfg = P5ModelConfig(vocab_size=600, d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, dropout_rate=0.1)
+    model = P5T5Native(cfg, dtype="bf16", device=dev, backend=be, seed=3)
+    model.ddp_world = world
+    model.set_dropout_seed(2023 + rank, 0)
+    opt = FusedAdamW(model, lr=1e-2, max_grad_norm=1.0)
+    model.train()
+    g = torch.Generator().manual_seed(100 + rank)
+    for _ in range(3):                                          # three real steps: staged backward + bucket all-reduce on the side stream
+        ids = torch.randint(3, 600, (8, 24), generator=g).to(dev)
+        labels = torch.randint(3, 600, (8, 6), generator=g).to(dev)
+        training_step(model, opt, (ids, torch.zeros_like(ids), torch.ones_like(ids), labels, torch.ones_like(labels)))
+    torch.cuda.synchronize()
+    torch.save({"flat": model._flat.cpu()}, os.path.join(tmp, f"n{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs one GPU per rank (this box has fewer than 2)")
+def test_two_ranks_rccl(tmp_path):
+    """backend="nccl" (RCCL over xGMI), one process per GPU: after three dropout-on bf16 training steps with rank-specific data the
+    ranks hold bit-identical parameters (gradients all-reduced per backward stage, deterministic clip factor)."""
+    world, port = 2, 27500 + random.randint(0, 1500)
+    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n0, n1 = torch.load(tmp_path / "n0.pt"), torch.load(tmp_path / "n1.pt")
+    assert torch.equal(n0["flat"], n1["flat"]), "ranks diverged over RCCL"

@@ -127,6 +127,7 @@ def _ddp_worker(rank, world, port, tmp, out):
     tok = build_offline_tokenizer(VOCAB)
     model = tiny_model(be, len(tok), seed=3)
     model.ddp_world = world
+    model.ddp_bucket_dtype = out or "fp32"
     opt = FusedAdamW(model, lr=1e-2, max_grad_norm=1.0)
     g = torch.Generator().manual_seed(100 + rank)            # each rank gets its own shard of the global batch
     ids = torch.randint(3, len(tok), (4, 12), generator=g)
@@ -394,3 +395,23 @@ def test_torch_ddp_wrapper_is_inert(emu):
         assert "lm_head.weight" in sd
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_bf16_buckets(emu, tmp_path):
+    """--ddp_bucket_dtype bf16: the ranks exchange bf16 gradient buckets (half the bytes per step); both ranks still end with
+    bit-identical parameters, and the reduced gradient is the fp32 one to bf16 accuracy."""
+    world, port = 2, 25000 + random.randint(0, 2000)
+    mp.spawn(_ddp_worker, args=(world, port, str(tmp_path), "bf16"), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["grads"], r1["grads"])
+    assert torch.equal(r0["grads"], r0["grads"].to(torch.bfloat16).float())          # what came back is a bf16 value
+    tok = build_offline_tokenizer(VOCAB)
+    gs = []
+    for r in (r0, r1):
+        m = tiny_model(emu, len(tok), seed=3)
+        m.eval()
+        nll = m(input_ids=r["ids"], whole_word_ids=torch.zeros_like(r["ids"]), attention_mask=torch.ones_like(r["ids"]), labels=r["labels"])["loss"]
+        masked_mean_loss(nll, torch.ones_like(r["labels"])).backward()
+        gs.append(m._grads.clone())
+    want = gs[0].to(torch.bfloat16).float() + gs[1].to(torch.bfloat16).float()
+    assert torch.allclose(r0["grads"], want, atol=1e-6, rtol=2 ** -7)
