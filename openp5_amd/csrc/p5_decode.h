@@ -265,7 +265,36 @@ struct P5BeamSh {
   int sel_run[P5_MAX_K], fin_src[P5_MAX_K], fin_fl[P5_MAX_K], fin_ln[P5_MAX_K];
   float fin_sc[P5_MAX_K], run_sc[P5_MAX_K];
   int s_nothit;
+  // the item's OLD state, fetched at kernel entry together with the candidate lists (one round trip instead of a chain of
+  // dependent ones further down: the kernel is one workgroup per item and spent 77 % of its cycles waiting on such loads)
+  int old_unsat, old_node[P5_MAX_K], old_coff[P5_MAX_K];
+  float old_fin_score[P5_MAX_K];
+  int old_fin_flag[P5_MAX_K], old_fin_len[P5_MAX_K];
+  int old_run_seq[P5_MAX_K * 64], old_fin_seq[P5_MAX_K * 64], old_anc[P5_MAX_K * 64];     // [Kb][max_len], [Kb][max_len], [pos+1][Kb]
 };
+
+// issue every load of the item's old state (see P5BeamSh); the caller's next __syncthreads() publishes it
+__device__ static __forceinline__ void p5_beam_prefetch(const P5BeamState& st, P5BeamSh& sh, int b, int tid, int Kb, int max_len, int R, int cur_len,
+                                                        const int* __restrict__ child_off) {
+  if (tid == 0) sh.old_unsat = st.unsat[b];
+  if (tid < Kb) {
+    const int nd = st.run_node[b * Kb + tid];
+    sh.old_node[tid] = nd;
+    sh.old_coff[tid] = nd >= 0 ? child_off[nd] : 0;
+    sh.old_fin_score[tid] = st.fin_score[b * Kb + tid];
+    sh.old_fin_flag[tid] = st.fin_flag[b * Kb + tid];
+    sh.old_fin_len[tid] = st.fin_len[b * Kb + tid];
+  }
+  for (int t = tid; t < Kb * max_len; t += 256) {
+    sh.old_run_seq[t] = st.run_seq[(size_t)b * Kb * max_len + t];
+    sh.old_fin_seq[t] = st.fin_seq[(size_t)b * Kb * max_len + t];
+  }
+  const int pos = cur_len - 1;
+  for (int t = tid; t < Kb * pos; t += 256) {                // ancestry rows 0 .. pos-1 of the item's beams
+    const int p = t / Kb, j = t - p * Kb;
+    sh.old_anc[t] = st.anc[(size_t)p * R + b * Kb + j];
+  }
+}
 
 __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& sh, int b, int tid, int Kb, int K2, int max_len, int eos_id, int R,
                                                     int cur_len) {
@@ -290,8 +319,8 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
     if (rank < Kb) { sel_run[rank] = tid; run_sc[rank] = v; }
   }
   // ---- f: finished beams = stable top-K over [old finished ; new candidates] ----
-  const bool uns = st.unsat[b] != 0;
-  if (tid < Kb) msc[tid] = st.fin_score[b * Kb + tid];
+  const bool uns = sh.old_unsat != 0;
+  if (tid < Kb) msc[tid] = sh.old_fin_score[tid];
   else if (tid < Kb + K2) {
     const int i = tid - Kb;
     float v = top_lp[i] / (float)cur_len;
@@ -306,7 +335,7 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
     for (int j = 0; j < Kb + K2; ++j) rank += (msc[j] > v || (msc[j] == v && j < tid)) ? 1 : 0;
     if (rank < Kb) {
       fin_sc[rank] = v;
-      if (tid < Kb) { fin_src[rank] = tid; fin_fl[rank] = st.fin_flag[b * Kb + tid]; fin_ln[rank] = st.fin_len[b * Kb + tid]; }
+      if (tid < Kb) { fin_src[rank] = tid; fin_fl[rank] = sh.old_fin_flag[tid]; fin_ln[rank] = sh.old_fin_len[tid]; }
       else { const int i = tid - Kb; fin_src[rank] = -(i + 1); fin_fl[rank] = (hit[i] && i < Kb) ? 1 : 0; fin_ln[rank] = cur_len; }
     }
   }
@@ -328,10 +357,10 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
   for (int t = tid; t < Kb * max_len; t += 256) {
     const int j = t / max_len, p = t % max_len;
     int v;
-    if (fin_src[j] >= 0) v = st.fin_seq[((size_t)b * Kb + fin_src[j]) * max_len + p];
+    if (fin_src[j] >= 0) v = sh.old_fin_seq[fin_src[j] * max_len + p];
     else {
       const int i = -fin_src[j] - 1;
-      v = (p == cur_len) ? top_tok[i] : st.run_seq[((size_t)b * Kb + top_beam[i]) * max_len + p];
+      v = (p == cur_len) ? top_tok[i] : sh.old_run_seq[top_beam[i] * max_len + p];
     }
     st.fin_seq_next[((size_t)b * Kb + j) * max_len + p] = v;
   }
@@ -345,13 +374,13 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
     const int j = t / max_len, p = t % max_len;
     const int i = sel_run[j];
     st.run_seq_next[((size_t)b * Kb + j) * max_len + p] =
-        (p == cur_len) ? top_tok[i] : st.run_seq[((size_t)b * Kb + top_beam[i]) * max_len + p];
+        (p == cur_len) ? top_tok[i] : sh.old_run_seq[top_beam[i] * max_len + p];
   }
   const int pos = cur_len - 1;   // K/V of this step were stored at `pos` by row (b*Kb + old beam)
   for (int t = tid; t < Kb * (pos + 1); t += 256) {
     const int j = t / (pos + 1), p = t % (pos + 1);
-    const int parent_row = b * Kb + top_beam[sel_run[j]];
-    st.anc_next[(size_t)p * R + b * Kb + j] = (p == pos) ? parent_row : st.anc[(size_t)p * R + parent_row];
+    const int parent = top_beam[sel_run[j]];
+    st.anc_next[(size_t)p * R + b * Kb + j] = (p == pos) ? b * Kb + parent : sh.old_anc[p * Kb + parent];
   }
   if (tid < Kb) {
     const int i = sel_run[tid];
@@ -406,10 +435,13 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   int& s_nothit = sh.s_nothit;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int K2 = 2 * Kb;
-  // candidate pool: Kb rows x (<= K2) entries, flat index j*K2 + i
+  // candidate pool: Kb rows x (<= K2) entries, flat index j*K2 + i.  The lists are read unconditionally (the buffers are fully
+  // allocated; entries beyond a row's count are ignored) so that counts, scores and children travel in one round trip
+  p5_beam_prefetch(st, sh, b, tid, Kb, max_len, R, cur_len, child_off);
   for (int t = tid; t < Kb * K2; t += 256) {
     const int j = t / K2, i = t % K2;
-    cs[t] = i < row_n_top[b * Kb + j] ? row_top_score[(size_t)(b * Kb + j) * K2 + i] : P5_NEG_INF;
+    const float v = row_top_score[(size_t)(b * Kb + j) * K2 + i];
+    cs[t] = i < row_n_top[b * Kb + j] ? v : P5_NEG_INF;
   }
   if (tid == 0) s_nothit = 0;
   __syncthreads();
@@ -433,10 +465,9 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
       }
       if (rank < K2) {
         const int j = t / K2, c = key - j * max_c;
-        const int nd = st.run_node[b * Kb + j];
         top_lp[rank] = v; top_beam[rank] = j;
-        top_tok[rank] = child_tok[child_off[nd] + c];
-        top_node[rank] = child_node[child_off[nd] + c];
+        top_tok[rank] = child_tok[sh.old_coff[j] + c];
+        top_node[rank] = child_node[sh.old_coff[j] + c];
       }
     }
     __syncthreads();
@@ -455,10 +486,9 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
     if (tid == 0) {
       if (bi != 0x7fffffff) {
         const int j = bi / max_c, c = bi % max_c;
-        const int nd = st.run_node[b * Kb + j];
         top_lp[it] = bv; top_beam[it] = j;
-        top_tok[it] = child_tok[child_off[nd] + c];
-        top_node[it] = child_node[child_off[nd] + c];
+        top_tok[it] = child_tok[sh.old_coff[j] + c];
+        top_node[it] = child_node[sh.old_coff[j] + c];
         for (int i = 0; i < K2; ++i)        // mark taken (rows are short: <= K2 entries)
           if (cs[j * K2 + i] != P5_NEG_INF && row_top_c[(size_t)(b * Kb + j) * K2 + i] == c) { cs[j * K2 + i] = P5_NEG_INF; break; }
       } else {   // fewer than 2K allowed continuations: HF would pick arbitrary -inf entries

@@ -35,6 +35,10 @@ struct P5SkinnyArgs {
   const int* done;      // optional device flag: != 0 -> the whole launch is a no-op (search finished in an earlier step)
 };
 
+template <class T> __device__ static __forceinline__ float sk_exp(float x);
+template <> __device__ __forceinline__ float sk_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float sk_exp<bf16>(float x) { return __expf(x); }
+
 template <class T> struct SkT {
   static constexpr int EPS = 128 / (int)sizeof(T);   // K elements per 128-byte step
 };
@@ -45,32 +49,44 @@ __device__ static __forceinline__ void sk_norm_rows(char* aimg, const float* __r
                                                     float eps, int tid) {
   constexpr int EPS = SkT<T>::EPS;
   const int lane = tid & 63, wave = tid >> 6;
+  // all four rows of this wave are requested before the first reduction (four dependent round trips otherwise)
+  float xv[4][2][8];
+  float wv[2][8];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    const int row = wave * 4 + rr, gr = m0 + row;
-    float xv[2][8];
-    float ss = 0.f;
+    const int gr = m0 + wave * 4 + rr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = lane + i * 64;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xv[i][e] = 0.f;
-      if (c * 8 < d && gr < M) {
-        ldf<8>(x + (size_t)gr * d + c * 8, xv[i]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
-      }
+      for (int e = 0; e < 8; ++e) xv[rr][i][e] = 0.f;
+      if (c * 8 < d && gr < M) ldf<8>(x + (size_t)gr * d + c * 8, xv[rr][i]);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[i][e] = 0.f;
+    if (c * 8 < d) ldf<8>(ln + c * 8, wv[i]);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = wave * 4 + rr;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += xv[rr][i][e] * xv[rr][i][e];
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)d + eps);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = lane + i * 64;
       if (c * 8 < d) {
-        float wv[8], o[8];
-        ldf<8>(ln + c * 8, wv);
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = wv[e] * to_f<T>(from_f<T>(xv[i][e] * rstd));   // reference rounding order (p5_rmsnorm_fwd_kernel)
+        for (int e = 0; e < 8; ++e) o[e] = wv[i][e] * to_f<T>(from_f<T>(xv[rr][i][e] * rstd));   // reference rounding order (p5_rmsnorm_fwd_kernel)
         const int k0 = c * 8, step = k0 / EPS;
         if constexpr (sizeof(T) == 2) {
           const int slot = (k0 % EPS) >> 3;
@@ -118,13 +134,20 @@ __device__ static __forceinline__ f32x4 sk_mma(const char* aimg, const char* bim
   const int per = (nsteps + KP - 1) / KP;
   const int s0 = kp * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s = s0; s < s1; ++s) {
+  // four steps (eight 64-byte chunks) at a time: all sixteen fragment reads are issued before the first MFMA -- with one or two
+  // waves per SIMD nothing else hides the LDS latency of a read-then-multiply sequence
+  for (int sb = s0; sb < s1; sb += 4) {
+    u32x4 fa[8], fb[8];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const u32x4 fa = frag_load_kc128<T>(aimg + s * 2048, 0, c, lane);
-      const u32x4 fb = frag_load_kc128<T>(bimg + (size_t)s * NB * 128, nt * 16, c, lane);
-      mma16<T>(acc, fa, fb);
+    for (int i = 0; i < 8; ++i) {
+      int s = sb + (i >> 1);
+      s = s < s1 ? s : s1 - 1;                                   // (steps past the range re-read the last one; masked below)
+      fa[i] = frag_load_kc128<T>(aimg + s * 2048, 0, i & 1, lane);
+      fb[i] = frag_load_kc128<T>(bimg + (size_t)s * NB * 128, nt * 16, i & 1, lane);
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (sb + (i >> 1) < s1) mma16<T>(acc, fa[i], fb[i]);
   }
   if constexpr (KP > 1) {
     f32x4* r4 = (f32x4*)red;
@@ -319,7 +342,8 @@ struct P5CrossArgs {
   const float* x;          // FUSEQ: fp32 residual stream [R, d]
   const float* ln;         // FUSEQ: cross-attention norm weight [d]
   const void* Wq;          // FUSEQ: T [inner, d]
-  const void* kv;          // T [B*L, 2*inner]  (K then V)
+  const void* kv;          // T [B*L, ldkv]: K (inner columns) then V of this layer
+  int ldkv;                // row stride of kv in elements (2*inner, or n_layers*2*inner when all layers share one projection GEMM)
   const int64_t* mask;     // [B, L]
   int R, H, Kb, L, d;
   float eps;
@@ -346,11 +370,11 @@ __global__ __launch_bounds__(256) void p5_dec_cross_attn2_kernel(P5CrossArgs a) 
   char* kimg = (char*)(sM + 64);
   char* vimg = kimg + KVB;
   char* aimg = vimg + KVB;
-  const T* kvp = (const T*)a.kv + (size_t)b * a.L * 2 * inner + h * 64;
+  const T* kvp = (const T*)a.kv + (size_t)b * a.L * a.ldkv + h * 64;
   auto stage_kv = [&](int j0) {
     // rows j0.. of K and V: key row stride = 2*inner elements; NSD steps of 128 B each
-    sk_dma_rows<T>(kimg, kvp, 2 * inner, j0, a.L, 0, KC, NSD, tid);
-    sk_dma_rows<T>(vimg, kvp + inner, 2 * inner, j0, a.L, 0, KC, NSD, tid);
+    sk_dma_rows<T>(kimg, kvp, a.ldkv, j0, a.L, 0, KC, NSD, tid);
+    sk_dma_rows<T>(vimg, kvp + inner, a.ldkv, j0, a.L, 0, KC, NSD, tid);
   };
   stage_kv(0);
   if constexpr (FUSEQ) {
@@ -491,10 +515,10 @@ __global__ __launch_bounds__(256) void p5_dec_cross_attn3_kernel(P5CrossArgs a) 
   char* kimg = (char*)(sM + 64);
   char* vimg = kimg + KVB;
   char* aimg = vimg + KVB;
-  const T* kvp = (const T*)a.kv + (size_t)b * a.L * 2 * inner + h * 64;
+  const T* kvp = (const T*)a.kv + (size_t)b * a.L * a.ldkv + h * 64;
   auto stage_kv = [&](int j0) {
-    sk_dma_rows<T>(kimg, kvp, 2 * inner, j0, a.L, 0, KC, NSD, tid);
-    sk_dma_rows<T>(vimg, kvp + inner, 2 * inner, j0, a.L, 0, KC, NSD, tid);
+    sk_dma_rows<T>(kimg, kvp, a.ldkv, j0, a.L, 0, KC, NSD, tid);
+    sk_dma_rows<T>(vimg, kvp + inner, a.ldkv, j0, a.L, 0, KC, NSD, tid);
   };
   stage_kv(0);
   // ---- q rows -> qimg (as the activation dtype stores them) ----
@@ -630,49 +654,42 @@ __global__ __launch_bounds__(256) void p5_head_lse_kernel(float* __restrict__ pa
   constexpr int EPS = SkT<T>::EPS, EPF = TT<T>::EPF, KCH = TT<T>::KCH, NT = NV / 16;
   __shared__ __attribute__((aligned(16))) char lds[LDSKB * 1024];
   if (done && *done) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef P5_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the unit loop below branches on scalars
+#endif
   const int v0 = blockIdx.x * NV;
   const int nsteps = d / EPS;                                        // 128-byte steps per row
   sk_dma_rows<T>(lds, E, d, v0, V, 0, NV, nsteps, tid);              // rows past V are clamped (masked below)
   __syncthreads();
   const int nmt = (R + 15) / 16;
-  const int nkc = d / KCH;                                           // 64-byte chunks per row; 2 per step
-  const int ngrp = (nkc + 7) / 8;                                    // A fragments are fetched 8 chunks at a time ...
-  auto load_a = [&](u32x4 (&f)[8], int mt_, int g_) {
+  const int nkc = d / KCH;                                           // 64-byte chunks per row; two per 128-byte step
+  // B fragment addresses: row (lane & 15) of an n-tile, 16-byte slot ((chunk << 2 | lane >> 4) ^ (row & 7)); the swizzle only
+  // involves lane bits, so the two chunks of a step sit at two per-lane constants and everything else is an immediate.
+  const int off0 = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+  const int off1 = (lane & 15) * 128 + (((4 | (lane >> 4)) ^ (lane & 7)) << 4);
+  // A fragments come straight from global memory (hn is L2-resident), one UNIT = 8 chunks (4 steps) of one m-tile at a time,
+  // through a ring of four register buffers: a unit's loads are issued three units (~190 MFMAs) before its first use -- a
+  // load's latency (1-2 us under load) is ~10 x the MFMA time of a step.  The loads are raw (gload16_raw) and waited for by
+  // count: with compiler-tracked loads hipcc waits at every loop iteration for ALL loads in flight, including the ones just
+  // issued for later units (ISA: s_waitcnt vmcnt(7) right behind eight new loads), i.e. no lookahead at all.
+  // d_model % (8 * KCH) == 0 for every T5 size, so units are never partial.
+  constexpr int UC = 8;
+  const int upm = nkc / UC;                                          // units per m-tile
+  const int my_mt = wave < nmt ? (nmt - wave + 3) / 4 : 0;           // m-tiles of this wave: wave, wave + 4, ...
+  const int nunits = my_mt * upm;
+  auto load_unit = [&](u32x4 (&f)[UC], int u) {
+    const int mt_ = wave + 4 * (u / upm), hf = u % upm;
     int ar = mt_ * 16 + (lane & 15);
     ar = ar < R ? ar : R - 1;
-    const T* ap = hn + (size_t)ar * d + (lane >> 4) * EPF;
+    const T* ap = hn + (size_t)ar * d + (lane >> 4) * EPF + (size_t)hf * UC * KCH;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = (g_ * 8 + i < nkc) ? ld16(ap + (size_t)(g_ * 8 + i) * KCH) : zero16();
+    for (int i = 0; i < UC; ++i) gload16_raw(f[i], ap + (size_t)i * KCH);
   };
-  u32x4 fa[8], fnx[8];
-  if (wave < nmt) load_a(fa, wave, 0);
-  for (int mt = wave; mt < nmt; mt += 4) {
-    f32x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < ngrp; ++g) {
-      // ... and the next group (of this m-tile or of the wave's next one) is requested before this group's MFMAs are issued
-      const bool last = g + 1 == ngrp;
-      const int nmt_ = last ? mt + 4 : mt, ng = last ? 0 : g + 1;
-      const bool more = nmt_ < nmt;
-      if (more) load_a(fnx, nmt_, ng);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kc = g * 8 + i;
-        if (kc < nkc) {
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const u32x4 fb = frag_load_kc128<T>(lds + (size_t)(kc >> 1) * NV * 128, n * 16, kc & 1, lane);
-            mma16<T>(acc[n], fa[i], fb);
-          }
-        }
-      }
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = fnx[i];
-      }
-    }
+  f32x4 acc[NT];
+  auto epilogue = [&](int mt) {
     // row-wise (max, sum exp) over this tile's NV columns: element (row (lane>>4)*4 + r, col n*16 + (lane&15))
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -686,7 +703,9 @@ __global__ __launch_bounds__(256) void p5_head_lse_kernel(float* __restrict__ pa
       m = row16_max(m);
       float s = 0.f;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) s += (acc[n][r] == P5_NEG_INF) ? 0.f : expf(acc[n][r] - m);
+      // (fast mode: exp2-based __expf, 2 ulp -- the precise expf is ~30 instructions and, at 32 calls per lane per m-tile, was most
+      //  of this kernel: 53 % of its wave cycles were instruction issue with the matrix pipe 8 % busy)
+      for (int n = 0; n < NT; ++n) s += (acc[n][r] == P5_NEG_INF) ? 0.f : sk_exp<T>(acc[n][r] - m);
       s = row16_sum(s);
       const int row = mt * 16 + (lane >> 4) * 4 + r;
       if ((lane & 15) == 0 && row < R) {
@@ -694,5 +713,54 @@ __global__ __launch_bounds__(256) void p5_head_lse_kernel(float* __restrict__ pa
         part_s[(size_t)row * gridDim.x + blockIdx.x] = s;
       }
     }
+  };
+  auto compute = [&](const u32x4 (&f)[UC], int u) {
+    const int mt = wave + 4 * (u / upm), hf = u % upm;
+    // this unit's eight loads are followed by those of up to three later units (and possibly by an epilogue's stores, which
+    // only makes the wait stricter than necessary)
+    const int ahead = nunits - 1 - u;
+    if (ahead >= 3) P5_WAIT_VM(24);
+    else if (ahead == 2) P5_WAIT_VM(16);
+    else if (ahead == 1) P5_WAIT_VM(8);
+    else P5_WAIT_VM(0);
+    P5_SCHED_FENCE();
+    if (hf == 0) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // B fragments of chunk i+1 are read from LDS while the MFMAs of chunk i issue (one wave per SIMD: nobody else hides the
+    // ~100-cycle LDS latency; the compiler's own order was read, wait, MFMA, read, wait, MFMA)
+    const char* bs0 = lds + (size_t)(hf * (UC / 2)) * NV * 128;
+    u32x4 bq[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bq[0][n] = ld16(bs0 + n * 2048 + off0);
+#pragma unroll
+    for (int i = 0; i < UC; ++i) {
+      if (i + 1 < UC) {
+        const char* bn = bs0 + (size_t)((i + 1) >> 1) * NV * 128 + (((i + 1) & 1) ? off1 : off0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[(i + 1) & 1][n] = ld16(bn + n * 2048);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) mma16<T>(acc[n], f[i], bq[i & 1][n]);
+    }
+    if (hf == upm - 1) epilogue(mt);
+  };
+  u32x4 f0[UC], f1[UC], f2[UC], f3[UC];
+  if (nunits > 0) load_unit(f0, 0);
+  if (nunits > 1) load_unit(f1, 1);
+  if (nunits > 2) load_unit(f2, 2);
+  for (int u = 0; u < nunits; u += 4) {
+    if (u + 3 < nunits) load_unit(f3, u + 3);
+    compute(f0, u);
+    if (u + 1 >= nunits) break;
+    if (u + 4 < nunits) load_unit(f0, u + 4);
+    compute(f1, u + 1);
+    if (u + 2 >= nunits) break;
+    if (u + 5 < nunits) load_unit(f1, u + 5);
+    compute(f2, u + 2);
+    if (u + 3 >= nunits) break;
+    if (u + 6 < nunits) load_unit(f2, u + 6);
+    compute(f3, u + 3);
   }
 }

@@ -45,12 +45,32 @@ __host__ __device__ static __forceinline__ bf16 f2bf(float f) {
   r.v = (unsigned short)(u >> 16);
   return r;
 }
+// gfx950 converts two fp32 to packed bf16 (round-to-nearest-even, NaN-preserving) in ONE instruction; the integer sequence above
+// is ~10 VALU operations per element plus a NaN test that hipcc turns into a branch inside control flow -- every bf16 epilogue
+// (GEMM tiles, norms, attention outputs) converts tens of values per lane.  The host emulation keeps the integer sequence; the
+// two agree bit for bit on every finite value.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P5_EMU)
+__device__ static __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+#define P5_HW_BF16 1
+#endif
 template <class T> __host__ __device__ static __forceinline__ float to_f(T x);
 template <> __host__ __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __host__ __device__ __forceinline__ float to_f<bf16>(bf16 x) { return bf2f(x); }
 template <class T> __host__ __device__ static __forceinline__ T from_f(float x);
 template <> __host__ __device__ __forceinline__ float from_f<float>(float x) { return x; }
-template <> __host__ __device__ __forceinline__ bf16 from_f<bf16>(float x) { return f2bf(x); }
+template <> __host__ __device__ __forceinline__ bf16 from_f<bf16>(float x) {
+#ifdef P5_HW_BF16
+  bf16 r;
+  r.v = (unsigned short)(cvt_pk_bf16(x, x) & 0xFFFFu);
+  return r;
+#else
+  return f2bf(x);
+#endif
+}
 
 template <class T> struct TT;
 template <> struct TT<float> { static constexpr int EPF = 4; static constexpr int KCH = 16; static constexpr int DT = 0; };
@@ -166,6 +186,18 @@ __device__ static __forceinline__ void glds16_raw(const void* g, char* lds_wave_
 }
 #endif
 
+// 16-byte global load the compiler does NOT track (inline asm): its completion is the caller's business -- P5_WAIT_VM(n) with n =
+// number of vector-memory operations issued after it, then P5_SCHED_FENCE() before the first use.  This is the only way to
+// keep loads in flight across a loop back edge: hipcc's own waitcnt insertion waits for everything older than the current
+// block's loads there (cdna_hip_programming.md 5.7 form iii).  The destination must not be touched between issue and wait.
+#ifdef P5_EMU
+static inline void gload16_raw(u32x4& dst, const void* p) { dst = *(const u32x4*)p; }
+#else
+__device__ static __forceinline__ void gload16_raw(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+#endif
+
 // compiler scheduling fence: nothing is moved across it (used to keep an end-of-step barrier BELOW the MFMAs it follows
 // in program order -- hipcc otherwise hoists "s_waitcnt vmcnt(0); s_barrier" above them and serialises copy and math)
 #ifdef P5_EMU
@@ -247,6 +279,12 @@ template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {
 template <> __device__ __forceinline__ u32x4 pack16<bf16>(const float* in) {
   u32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf(in[2 * i]).v | ((unsigned)f2bf(in[2 * i + 1]).v << 16);
+  for (int i = 0; i < 4; ++i) {
+#ifdef P5_HW_BF16
+    v[i] = cvt_pk_bf16(in[2 * i], in[2 * i + 1]);
+#else
+    v[i] = (unsigned)f2bf(in[2 * i]).v | ((unsigned)f2bf(in[2 * i + 1]).v << 16);
+#endif
+  }
   return v;
 }

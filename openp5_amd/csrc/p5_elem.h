@@ -479,6 +479,6 @@ __global__ __launch_bounds__(256) void p5_adamw_kernel(P5AdamArgs a) {
     p = p - step_size * (m / (sqrtf(v) + a.eps));
     p = p - a.lr * a.wd * p;
     a.p[i] = p;
-    if (a.shadow) ((bf16*)a.shadow)[i] = f2bf(p);
+    if (a.shadow) ((bf16*)a.shadow)[i] = from_f<bf16>(p);
   }
 }

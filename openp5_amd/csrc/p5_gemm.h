@@ -302,7 +302,7 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int lc = wn * (BN / WNW) + j * 16 + (lane & 15);
-            *(bf16*)(lds + lr * CST + lc * 2) = f2bf(acc[i][j][r] * sc);
+            *(bf16*)(lds + lr * CST + lc * 2) = from_f<bf16>(acc[i][j][r] * sc);
           }
         }
       __syncthreads();

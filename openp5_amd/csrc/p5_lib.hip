@@ -53,7 +53,6 @@ static int g_opt_decode_v2 = getenv("P5_DECODE_V2") ? atoi(getenv("P5_DECODE_V2"
 static int g_opt_dec_nb = getenv("P5_DEC_NB") ? atoi(getenv("P5_DEC_NB")) : 0;           // skinny GEMM: forced column-tile width (0 = auto)
 static int g_opt_dec_kw = getenv("P5_DEC_KW") ? atoi(getenv("P5_DEC_KW")) : 0;           // skinny GEMM: forced K range per workgroup (0 = auto)
 static int g_opt_dec_fuseq = getenv("P5_DEC_FUSEQ") ? atoi(getenv("P5_DEC_FUSEQ")) : 1;   // cross-attention computes its own q projection
-static int g_opt_gemm_bigk = getenv("P5_GEMM_BIGK") ? atoi(getenv("P5_GEMM_BIGK")) : 0;   // 128x128 tiles at one full round when K >= this (0 = off)
 static int g_opt_dgrad_t = getenv("P5_DGRAD_T") ? atoi(getenv("P5_DGRAD_T")) : 1;       // data gradients on the transposed weight copy when one is bound
 static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS")) : 3;   // 3 = MFMA cross-attention, 2 = scalar score / PV loops
 static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
@@ -133,8 +132,6 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
-  // one full round of 128x128 tiles with a long reduction (8192 x 512 x {1536, 2048}: FFN down-projection, wi / qkv data gradients)
-  if (!force_tile && g_opt_gemm_bigk > 0 && !g.a_ks && !g.b_ks && t128 >= 256 && g.K >= g_opt_gemm_bigk && g.epi != P5_EPI_ATOMIC) big = true;
   // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
   // split-K so that tiles x splits ~ 160: in isolation ~256 (every CU) is fastest, inside the step fewer, longer workgroups leave
   // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
@@ -247,7 +244,8 @@ struct Bump {
 struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S, *fold; int sz, fused; };
 
 struct GenWs {
-  void* kv_cross[64];   // per decoder layer: T [B*L, 2*inner]
+  void* kv_cross[64];   // per decoder layer: T [B*L, ldkv] -- column slices of ONE [B*L, n_dec*2*inner] block in the latency-shaped path
+  int ldkv;             // (all layers' K/V projections are a single GEMM, as in training), separate [B*L, 2*inner] blocks otherwise
   void* cache[64];      // per decoder layer: T [max_len, R, 2*inner]
   void *xa, *xb, *n, *qkv, *q, *o, *h, *hn;
   float* x32;             // [R, d] fp32 residual stream of the decode step (v2: updated in place with atomics)
@@ -962,9 +960,13 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   Bump b{base, (size_t)enc_bytes};
   GenWs tmp;
   GenWs& w = g ? *g : tmp;
-  for (int i = 0; i < c.n_dec_layers; ++i) {
-    w.kv_cross[i] = b.take((size_t)B * L * 2 * in * sz);
-    w.cache[i] = b.take((size_t)max_len * R * 2 * in * sz);
+  {
+    char* kv_all = g_opt_decode_v2 ? (char*)b.take((size_t)B * L * c.n_dec_layers * 2 * in * sz) : nullptr;
+    w.ldkv = g_opt_decode_v2 ? c.n_dec_layers * 2 * in : 2 * in;
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      w.kv_cross[i] = g_opt_decode_v2 ? (base ? (void*)(kv_all + (size_t)i * 2 * in * sz) : nullptr) : b.take((size_t)B * L * 2 * in * sz);
+      w.cache[i] = b.take((size_t)max_len * R * 2 * in * sz);
+    }
   }
   w.xa = b.take(R * d * sz); w.xb = b.take(R * d * sz); w.n = b.take(R * d * sz);
   w.qkv = b.take(R * 3 * in * sz); w.q = b.take(R * in * sz); w.o = b.take(R * in * sz);
@@ -1158,7 +1160,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
     // ---- cross-attention ----
     P5CrossArgs a;
     a.out = w.o; a.q = w.q; a.x = x; a.ln = e->P + lo.ca.ln; a.Wq = Wc<T>(e, lo.ca.q); a.kv = w.kv_cross[i]; a.mask = w.mask_copy;
-    a.R = R; a.H = H; a.Kb = K; a.L = L; a.d = d; a.eps = c.eps; a.done = done;
+    a.R = R; a.H = H; a.Kb = K; a.L = L; a.d = d; a.eps = c.eps; a.done = done; a.ldkv = w.ldkv;
     const dim3 cgrid(B * ((K + 15) / 16), H);
     if (fuseq) {
       if constexpr (sizeof(T) == 2) {
@@ -1219,8 +1221,12 @@ static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, cons
   if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
   P5_TRY(encoder_fwd<T>(e, s));
-  for (int i = 0; i < c.n_dec_layers; ++i)
-    P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, e->dec[i].ca.k), w.kv_cross[i], 2 * in, B * L, 2 * in, d));
+  if (g_opt_decode_v2) {     // K/V projections of every decoder layer in ONE GEMM over the contiguous weight block (build_layout)
+    P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, e->dec[0].ca.k), w.kv_cross[0], w.ldkv, B * L, c.n_dec_layers * 2 * in, d));
+  } else {
+    for (int i = 0; i < c.n_dec_layers; ++i)
+      P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, e->dec[i].ca.k), w.kv_cross[i], 2 * in, B * L, 2 * in, d));
+  }
   P5_LAUNCH(p5_beam_init_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, child_off, child_tok, child_node, roots, B, K, max_len,
             c.pad_id);
   P5_TRY(P5_KCHECK());
@@ -1399,7 +1405,6 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_kw")) g_opt_dec_kw = value;
   else if (!strcmp(name, "dec_fuseq")) g_opt_dec_fuseq = value;
   else if (!strcmp(name, "dgrad_t")) g_opt_dgrad_t = value;
-  else if (!strcmp(name, "gemm_bigk")) g_opt_gemm_bigk = value;
   else if (!strcmp(name, "dec_cross")) g_opt_dec_cross = value;
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
@@ -1706,6 +1711,7 @@ int p5_op_dec_cross_attn(int dtype, int variant, void* out, const void* q, const
   P5CrossArgs a;
   memset(&a, 0, sizeof(a));
   a.out = out; a.q = q; a.kv = kv; a.mask = mask; a.R = B * Kb; a.H = H; a.Kb = Kb; a.L = L; a.d = 0; a.eps = 0.f; a.done = nullptr;
+  a.ldkv = 2 * H * 64;
   const dim3 grid(B * ((Kb + 15) / 16), H), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == 1) {

@@ -13,5 +13,5 @@ def run(name, **opts):
     dt, loss = bench.time_training(model, opt, batch, 20, 5, 1, dev)
     print(f"{name:40s} {dt / 20 * 1e3:7.3f} ms/step  loss {loss:.4f}", flush=True)
 for rep in range(2):
-    run("dgrad on transposed weights", dgrad_t=1)
+    run("defaults", dgrad_t=1)
     run("dgrad with K-strided weights", dgrad_t=0)
