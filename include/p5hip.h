@@ -71,6 +71,10 @@ int p5_refresh_transposed(P5Engine* e, void* stream);
 /* The caller has just zero-filled the gradient arena on the stream the next backward will use (optimizer.zero_grad()):
  * that backward then skips its own clearing pass (243 MB for T5-small).  One-shot. */
 int p5_engine_grads_zeroed(P5Engine* e);
+/* optimizer.zero_grad() (DistributedRunner.py:93) done by the engine: the fill is issued on the side stream when one is bound,
+ * ordered after everything `stream` holds so far (the optimizer step that read the gradients), so that it overlaps the next
+ * forward; the next backward waits for it.  Nothing else may read the gradient arena before that backward. */
+int p5_engine_clear_grads(P5Engine* e, void* stream);
 /* optional second stream: weight-gradient GEMMs run on it, one sub-layer behind the dgrad chain (NULL = single stream) */
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream);
 

@@ -133,9 +133,6 @@ __device__ static __forceinline__ u32x4 tile_frag_ks(const char* lds, int e0, in
   return r;
 }
 
-template <class T> __device__ static __forceinline__ float p5_exp(float x);
-template <> __device__ __forceinline__ float p5_exp<float>(float x) { return expf(x); }
-template <> __device__ __forceinline__ float p5_exp<bf16>(float x) { return __expf(x); }
 
 // stage per-head relative bias (index = k - q + Lq - 1) and the additive key mask into LDS
 __device__ static __forceinline__ void stage_bias_mask(const P5AttnArgs& a, int b, int h, float* sbias, float* skneg,
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char tile[64 * C::TS];
   __shared__ __attribute__((aligned(16))) char pbuf[4 * 16 * C::TS];
   __shared__ float sbias[1024];
-  __shared__ float skneg[NKT * 16];
+  __shared__ __attribute__((aligned(16))) float skneg[NKT * 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
@@ -173,6 +170,11 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
     for (int c = 0; c < C::NCK; ++c)
       qf[c] = qrow < a.Lq ? ld16(Q + ((size_t)b * a.Lq + qrow) * a.ldq + h * 64 + c * C::KCH + g * C::EPF) : zero16();
   }
+  // Scores are formed TRANSPOSED (keys along the accumulator rows): s[t][r] = score of key t*16 + g*4 + r for the lane's ONE
+  // query q0 + li.  The softmax statistics are then per lane (reduced over r, t in registers and over the four g groups with
+  // two shuffles), the mask is one 16-byte LDS read per 16 keys, and the four probabilities a lane owns are consecutive keys of
+  // one row of P: one 8-byte LDS store instead of four 2-byte ones.  Everything below is select-based -- no per-lane branches
+  // (the first version's `if (valid) { LDS read; ... }` per element serialised ~2 LDS round trips per score).
   f32x4 s[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -186,58 +188,58 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int c = 0; c < C::NCK; ++c) mma16<T>(s[ch * 4 + t], qf[c], tile_frag_kc<T>(tile, t * 16, c, lane));
+        for (int c = 0; c < C::NCK; ++c) mma16<T>(s[ch * 4 + t], tile_frag_kc<T>(tile, t * 16, c, lane), qf[c]);
     }
   }
   __syncthreads();  // sbias/skneg visible even when Lk == 0 chunks were skipped
 
   // ---- exact softmax over the register-resident score rows ----
-  float m[4], l[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) m[r] = P5_NEG_INF;
+  const int qi = q0 + li;
+  const bool qok = qi < a.Lq;
+  const int qic = qok ? qi : a.Lq - 1;          // (keeps the bias index of a padding row inside the table)
+  const bool causal = a.causal != 0;
+  float m = P5_NEG_INF;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
-    const int kj = t * 16 + li;
+    const int kb = t * 16 + g * 4;
+    const f32x4 kn = *(const f32x4*)(skneg + kb);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.rel_table) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[r] = sbias[kb + r - qic + a.Lq - 1];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int qi = q0 + g * 4 + r;
-      float v = P5_NEG_INF;
-      if (kj < a.Lk && qi < a.Lq && !(a.causal && kj > qi)) {
-        v = s[t][r] + skneg[kj];
-        if (a.rel_table) v += sbias[kj - qi + a.Lq - 1];
-      }
+      const int kj = kb + r;
+      const bool ok = (kj < a.Lk) & qok & !(causal & (kj > qi));
+      const float v = ok ? (s[t][r] + kn[r]) + bias[r] : P5_NEG_INF;
       s[t][r] = v;
-      m[r] = fmaxf(m[r], v);
+      m = fmaxf(m, v);
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    m[r] = row16_max(m[r]);
-    if (m[r] == P5_NEG_INF) m[r] = 0.f;
-    l[r] = 0.f;
-  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (m == P5_NEG_INF) m = 0.f;
+  float l = 0.f;
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = p5_exp<T>(s[t][r] - m[r]);
+      const float p = p5_exp<T>(s[t][r] - m);
       s[t][r] = p;
-      l[r] += p;
+      l += p;
     }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    l[r] = row16_sum(l[r]);
-    const int qi = q0 + g * 4 + r;
-    if (li == 0 && qi < a.Lq && a.lse) a.lse[((size_t)b * a.H + h) * a.Lq + qi] = m[r] + logf(l[r]);
-  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (g == 0 && qok && a.lse) a.lse[((size_t)b * a.H + h) * a.Lq + qi] = m + logf(l);
   if (a.drop.state != nullptr && a.drop.thr != 0) {
     const uint32_t seed = p5_seed(a.drop);
+    const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + g * 4 + r, kj = t * 16 + li;
-        const uint32_t idx = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk + kj);
+        const uint32_t idx = rowbase + (uint32_t)(t * 16 + g * 4 + r);
         s[t][r] = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? s[t][r] * a.drop.scale : 0.f;
       }
   }
@@ -253,10 +255,10 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
       __syncthreads();
       stage_tile64<T>(tile, V + ((size_t)b * a.Lk + ch * 64) * a.ldv + h * 64, a.ldv, a.Lk - ch * 64, tid);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *(T*)(pw + (g * 4 + r) * C::TS + (t * 16 + li) * C::SZ) = from_f<T>(s[ch * 4 + t][r]);
+      for (int t = 0; t < 4; ++t) {
+        const float v4[4] = {s[ch * 4 + t][0], s[ch * 4 + t][1], s[ch * 4 + t][2], s[ch * 4 + t][3]};
+        st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, v4);
+      }
       __syncthreads();
 #pragma unroll
       for (int kc = 0; kc < C::NCK; ++kc) {
@@ -266,9 +268,11 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
       }
     }
   }
+  // the output tile is in the usual layout (lane owns queries g*4 + r): fetch those rows' 1/l from the lanes that hold them
+  const float inv_q = l > 0.f ? 1.f / l : 0.f;
   float inv[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) inv[r] = l[r] > 0.f ? 1.f / l[r] : 0.f;
+  for (int r = 0; r < 4; ++r) inv[r] = __shfl(inv_q, g * 4 + r);
   wave_store_16x64<T>((T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64, a.ldo, q0, a.Lq, o, inv, pw, lane);
 }
 
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char pbuf[4 * 16 * C::TS];
   __shared__ float sbias[1024];
   __shared__ float sdb[1024];
-  __shared__ float skneg[512];
+  __shared__ __attribute__((aligned(16))) float skneg[512];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
@@ -322,15 +326,16 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
     Drow += __shfl_xor(Drow, 32);
     if (g == 0 && qrow < a.Lq) a.Dvec[((size_t)b * a.H + h) * a.Lq + qrow] = Drow;
   }
-  float lse_r[4], D_r[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + g * 4 + r;
-    lse_r[r] = qi < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
-    D_r[r] = __shfl(Drow, g * 4 + r);
-  }
+  // scores transposed as in the forward kernel: the lane owns ONE query (q0 + li) and keys t*16 + g*4 + r
+  const int qi = q0 + li;
+  const bool qok = qi < a.Lq;
+  const int qic = qok ? qi : a.Lq - 1;
+  const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
+  const float D_q = Drow;          // (all four g lanes of a query hold the reduced sum)
+  const bool causal = a.causal != 0;
   const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
   const uint32_t seed = p5_seed(a.drop);
+  const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
 
   f32x4 dq[4];
 #pragma unroll
@@ -347,27 +352,30 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
       f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < C::NCK; ++c) {
-        mma16<T>(sacc, qf[c], tile_frag_kc<T>(tileK, t * 16, c, lane));
-        mma16<T>(dpacc, dof[c], tile_frag_kc<T>(tileV, t * 16, c, lane));
+        mma16<T>(sacc, tile_frag_kc<T>(tileK, t * 16, c, lane), qf[c]);
+        mma16<T>(dpacc, tile_frag_kc<T>(tileV, t * 16, c, lane), dof[c]);
       }
-      const int kj = ch * 64 + t * 16 + li;
+      const int kb = ch * 64 + t * 16 + g * 4;
+      const f32x4 kn = *(const f32x4*)(skneg + kb);
+      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.rel_table) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = sbias[kb + r - qic + a.Lq - 1];
+      }
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (do_drop) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+      }
+      float dsv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + g * 4 + r;
-        float ds = 0.f;
-        if (kj < a.Lk && qi < a.Lq && !(a.causal && kj > qi) && skneg[kj] == 0.f) {
-          float sv = sacc[r];
-          if (a.rel_table) sv += sbias[kj - qi + a.Lq - 1];
-          const float p = p5_exp<T>(sv - lse_r[r]);
-          float dp = dpacc[r];
-          if (do_drop) {
-            const uint32_t idx = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk + kj);
-            dp = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? dp * a.drop.scale : 0.f;
-          }
-          ds = p * (dp - D_r[r]);
-        }
-        *(T*)(pw + (g * 4 + r) * C::TS + (t * 16 + li) * C::SZ) = from_f<T>(ds);
+        const int kj = kb + r;
+        const bool ok = (kj < a.Lk) & qok & !(causal & (kj > qi)) & (kn[r] == 0.f);     // (bitwise: no short-circuit branches)
+        const float p = p5_exp<T>((sacc[r] + bias[r]) - lse_q);
+        dsv[r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
       }
+      st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv);
     }
     __syncthreads();
     if (a.d_rel_table) {
@@ -425,8 +433,8 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char pbufP[4 * 16 * C::TS];
   __shared__ __attribute__((aligned(16))) char pbufS[4 * 16 * C::TS];
   __shared__ float sbias[1024];
-  __shared__ float slse[64];
-  __shared__ float sD[64];
+  __shared__ __attribute__((aligned(16))) float slse[64];
+  __shared__ __attribute__((aligned(16))) float sD[64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
@@ -447,14 +455,15 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
       vf[c] = krow < a.Lk ? ld16(V + ((size_t)b * a.Lk + krow) * a.ldv + col) : zero16();
     }
   }
-  bool kvalid[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kj = k0 + g * 4 + r;
-    kvalid[r] = kj < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + kj] != 0);
-  }
+  // scores transposed (queries along the accumulator rows): the lane owns ONE key (k0 + li) and queries t*16 + g*4 + r of the
+  // staged tile, so its four P / dS values are consecutive queries of one key row: 8-byte LDS stores, per-query statistics in
+  // one 16-byte read each, no per-lane branches
+  const int kj = k0 + li;
+  const bool kok = kj < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + kj] != 0);
+  const bool causal = a.causal != 0;
   const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
   const uint32_t seed = p5_seed(a.drop);
+  const uint32_t headbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq) * a.Lk) + (uint32_t)kj;
 
   f32x4 dk[4], dv[4];
 #pragma unroll
@@ -478,29 +487,36 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
       f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < C::NCK; ++c) {
-        mma16<T>(sacc, kf[c], tile_frag_kc<T>(tileQ, t * 16, c, lane));
-        mma16<T>(dpacc, vf[c], tile_frag_kc<T>(tileDO, t * 16, c, lane));
+        mma16<T>(sacc, tile_frag_kc<T>(tileQ, t * 16, c, lane), kf[c]);
+        mma16<T>(dpacc, tile_frag_kc<T>(tileDO, t * 16, c, lane), vf[c]);
       }
-      const int qi = qc * 64 + t * 16 + li;
+      const int qb = t * 16 + g * 4;
+      const f32x4 ls = *(const f32x4*)(slse + qb), dd = *(const f32x4*)(sD + qb);
+      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.rel_table) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qc * 64 + qb + r;
+          bias[r] = sbias[kj - (qi < a.Lq ? qi : a.Lq - 1) + a.Lq - 1];
+        }
+      }
+      const uint32_t tbase = headbase + (uint32_t)(qc * 64 + qb) * (uint32_t)a.Lk;
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (do_drop) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, tbase + (uint32_t)r * (uint32_t)a.Lk, a.drop.thr) ? a.drop.scale : 0.f;
+      }
+      float pv[4], dsv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kj = k0 + g * 4 + r;
-        float pd = 0.f, ds = 0.f;
-        if (kvalid[r] && qi < a.Lq && !(a.causal && kj > qi)) {
-          float sv = sacc[r];
-          if (a.rel_table) sv += sbias[kj - qi + a.Lq - 1];
-          const float p = p5_exp<T>(sv - slse[t * 16 + li]);
-          float mk = 1.f;
-          if (do_drop) {
-            const uint32_t idx = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk + kj);
-            mk = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? a.drop.scale : 0.f;
-          }
-          pd = p * mk;
-          ds = p * (dpacc[r] * mk - sD[t * 16 + li]);
-        }
-        *(T*)(pP + (g * 4 + r) * C::TS + (t * 16 + li) * C::SZ) = from_f<T>(pd);
-        *(T*)(pS + (g * 4 + r) * C::TS + (t * 16 + li) * C::SZ) = from_f<T>(ds);
+        const int qi = qc * 64 + qb + r;
+        const bool ok = kok & (qi < a.Lq) & !(causal & (kj > qi));
+        const float p = p5_exp<T>((sacc[r] + bias[r]) - ls[r]);
+        pv[r] = ok ? p * mk[r] : 0.f;
+        dsv[r] = ok ? p * (dpacc[r] * mk[r] - dd[r]) : 0.f;
       }
+      st4<T>(pP + li * C::TS + (t * 16 + g * 4) * C::SZ, pv);
+      st4<T>(pS + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv);
     }
     __syncthreads();
 #pragma unroll
@@ -517,4 +533,205 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, pP, lane);
   wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, pS, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward, fused (bf16, Lq and Lk <= 128: the encoder's self-attention at the benchmark shape).  The two-kernel backward
+// above reads Q, K, V, dO twice and recomputes P twice; measured on MI355X both kernels (and the forward) take ~0.4 us per
+// MB they move whatever their arithmetic looks like (rewriting the per-element code branch-free changed nothing), i.e. the
+// strided 128-byte head-slice rows of the fused projection output bound them, not MFMA or VALU.  Here ONE 8-wave workgroup
+// per (batch, head) loads Q, K, V, dO once, keeps P and dS for the whole [Lq, Lk] block in LDS, and produces dQ, dK and dV:
+//   phase A  wave w = queries 16w..16w+15: S^T and dP^T by MFMA, P and dS element-wise (transposed layout as above),
+//            written to the [query][key] LDS matrices; d(rel-bias) diagonal sums; dQ = dS K;
+//   phase B  wave w = keys 16w..16w+15: dV = P^T dO, dK = dS^T Q, the A fragments read TRANSPOSED out of the same matrices
+//            (ds_read_b64_tr_b16), Q / dO as K-strided operands.
+// LDS: four [128][64] tiles + two [128][128] matrices = 143 KiB -> one workgroup per CU.
+// ------------------------------------------------------------------------------------------------------------
+__device__ static __forceinline__ u32x4 frag_ks_stride(const char* lds, int stride, int e0, int kc, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const char* base = lds + (kc * 32 + g * 8 + (i >> 2)) * stride + (e0 + (i & 3) * 4) * 2;
+  const u32x2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * stride);
+  u32x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
+  static_assert(sizeof(T) == 2, "fused attention backward: bf16 only");
+  using C = AttnC<T>;
+  constexpr int TP = 128 * 2 + 16;      // row stride of the [128][128] bf16 matrices
+  __shared__ __attribute__((aligned(16))) char tK[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tV[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tQ[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tDO[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char mP[128 * TP];
+  __shared__ __attribute__((aligned(16))) char mS[128 * TP];
+  __shared__ float sbias[256];
+  __shared__ float sdiag[8 * 144];        // per-wave diagonal sums of dS
+  __shared__ __attribute__((aligned(16))) float skneg[128];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+  const T* dO = (const T*)a.dO + (size_t)b * a.Lq * a.lddo + h * 64;
+  const T* O = (const T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64;
+  const int nrel = a.Lq + a.Lk - 1;
+
+  // ---- every global load of the workgroup is issued before the first use ----
+  u32x4 rq[2], rk[2], rv[2], rdo[2], of[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + i * 512, row = p >> 3, pc = p & 7;
+    rq[i] = row < a.Lq ? ld16(Q + (size_t)row * a.ldq + pc * 8) : zero16();
+    rdo[i] = row < a.Lq ? ld16(dO + (size_t)row * a.lddo + pc * 8) : zero16();
+    rk[i] = row < a.Lk ? ld16(K + (size_t)row * a.ldk + pc * 8) : zero16();
+    rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();
+  }
+  const int q0 = wave * 16, qi = q0 + li;
+  const bool qok = qi < a.Lq;
+  const int qic = qok ? qi : a.Lq - 1;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) of[c] = qok ? ld16(O + (size_t)qi * a.ldo + c * 32 + g * 8) : zero16();
+  const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
+  stage_bias_mask(a, b, h, sbias, skneg, 128, tid);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + i * 512, row = p >> 3, pc = p & 7;
+    st16(tQ + row * C::TS + pc * 16, rq[i]);
+    st16(tDO + row * C::TS + pc * 16, rdo[i]);
+    st16(tK + row * C::TS + pc * 16, rk[i]);
+    st16(tV + row * C::TS + pc * 16, rv[i]);
+  }
+  __syncthreads();
+
+  // ---- phase A ----
+  const bool causal = a.causal != 0;
+  const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const uint32_t seed = p5_seed(a.drop);
+  const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+  u32x4 qf[2], dof[2];
+  float D_q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    qf[c] = tile_frag_kc<T>(tQ, q0, c, lane);
+    dof[c] = tile_frag_kc<T>(tDO, q0, c, lane);
+    float x[8], y[8];
+    unpack16<T>(dof[c], x);
+    unpack16<T>(of[c], y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) D_q += x[e] * y[e];
+  }
+  D_q += __shfl_xor(D_q, 16);
+  D_q += __shfl_xor(D_q, 32);
+  char* myP = mP + qi * TP;
+  char* myS = mS + qi * TP;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      mma16<T>(sacc, tile_frag_kc<T>(tK, t * 16, c, lane), qf[c]);
+      mma16<T>(dpacc, tile_frag_kc<T>(tV, t * 16, c, lane), dof[c]);
+    }
+    const int kb = t * 16 + g * 4;
+    const f32x4 kn = *(const f32x4*)(skneg + kb);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.rel_table) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[r] = sbias[(kb + r - qic + a.Lq - 1) & 255];
+    }
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (do_drop) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+    }
+    float pv[4], dsv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kj = kb + r;
+      const bool ok = (kj < a.Lk) & qok & !(causal & (kj > qi)) & (kn[r] == 0.f);
+      const float p = p5_exp<T>((sacc[r] + bias[r]) - lse_q);
+      pv[r] = ok ? p * mk[r] : 0.f;
+      dsv[r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
+    }
+    st4<T>(myP + kb * 2, pv);
+    st4<T>(myS + kb * 2, dsv);
+  }
+  P5_WAVE_SYNC();
+  if (a.d_rel_table) {
+    // d(rel-bias): sums of dS along the 143 diagonals (constant key - query) of this wave's [16 q][128 keys] rows, one diagonal
+    // per lane, 16 independent 2-byte reads each, kept PER WAVE: LDS float atomics retire at ~2.5 cycles per lane (one
+    // ds_add_f32 per score element cost 20 us per workgroup), so nothing is accumulated atomically per element or per diagonal
+    for (int dd = lane; dd < 128 + 15; dd += 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int qr = 0; qr < 16; ++qr) {
+        const int kcol = dd - 15 + qr;
+        const bool in = (kcol >= 0) & (kcol < 128);
+        const float v = to_f<T>(*(const T*)(mS + (q0 + qr) * TP + (in ? kcol : 0) * 2));
+        sum += in ? v : 0.f;
+      }
+      sdiag[wave * 144 + dd] = sum;
+    }
+  }
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const u32x4 dsa = ld16(myS + kc * 64 + g * 16);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) mma16<T>(dq[dt], dsa, tile_frag_ks<T>(tK, dt * 16, kc, lane));
+  }
+  __syncthreads();      // P and dS complete; K and V tiles dead from here on
+
+  if (a.d_rel_table && wave == 7) {
+    // relative positions -> buckets -> one global atomic per (bucket, head) into one of `rel_copies` partial tables, by ONE
+    // wave and BEFORE phase B: a workgroup does not retire until its atomics have returned (~4 us when they were the last thing
+    // it did), so they are put in flight here, under the MFMAs and stores of phase B
+    float* sbk = sbias;   // (dead since phase A)
+    sbk[lane] = 0.f;
+    P5_WAVE_SYNC();
+    for (int i = lane; i < nrel; i += 64) {
+      // relative position i - (Lq - 1) is diagonal dd = i + 15 + 16 w - (Lq - 1) of wave w's rows
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const int dd = i + 15 + 16 * w - (a.Lq - 1);
+        const bool in = (dd >= 0) & (dd < 128 + 15);
+        const float x = sdiag[w * 144 + (in ? dd : 0)];
+        v += in ? x : 0.f;
+      }
+      if (v != 0.f) atomicAdd(&sbk[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] & 63], v);
+    }
+    P5_WAVE_SYNC();
+    if (sbk[lane] != 0.f) {
+      const int copy = a.rel_copies > 1 ? (b % a.rel_copies) : 0;
+      atomicAdd(&a.d_rel_table[(size_t)copy * a.rel_stride + lane * a.H + h], sbk[lane]);
+    }
+  }
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  char* scratch = tK + wave * 16 * C::TS;     // (8 waves x 16 rows = exactly the K tile)
+  wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, scratch, lane);
+
+  // ---- phase B ----
+  const int k0 = wave * 16;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const u32x4 pa = frag_ks_stride(mP, TP, k0, kc, lane);
+    const u32x4 sa = frag_ks_stride(mS, TP, k0, kc, lane);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      mma16<T>(dv[dt], pa, tile_frag_ks<T>(tDO, dt * 16, kc, lane));
+      mma16<T>(dk[dt], sa, tile_frag_ks<T>(tQ, dt * 16, kc, lane));
+    }
+  }
+  wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, scratch, lane);
+  wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, scratch, lane);
 }

@@ -35,10 +35,6 @@ struct P5SkinnyArgs {
   const int* done;      // optional device flag: != 0 -> the whole launch is a no-op (search finished in an earlier step)
 };
 
-template <class T> __device__ static __forceinline__ float sk_exp(float x);
-template <> __device__ __forceinline__ float sk_exp<float>(float x) { return expf(x); }
-template <> __device__ __forceinline__ float sk_exp<bf16>(float x) { return __expf(x); }
-
 template <class T> struct SkT {
   static constexpr int EPS = 128 / (int)sizeof(T);   // K elements per 128-byte step
 };
@@ -705,7 +701,7 @@ __global__ __launch_bounds__(256) void p5_head_lse_kernel(float* __restrict__ pa
 #pragma unroll
       // (fast mode: exp2-based __expf, 2 ulp -- the precise expf is ~30 instructions and, at 32 calls per lane per m-tile, was most
       //  of this kernel: 53 % of its wave cycles were instruction issue with the matrix pipe 8 % busy)
-      for (int n = 0; n < NT; ++n) s += (acc[n][r] == P5_NEG_INF) ? 0.f : sk_exp<T>(acc[n][r] - m);
+      for (int n = 0; n < NT; ++n) s += (acc[n][r] == P5_NEG_INF) ? 0.f : p5_exp<T>(acc[n][r] - m);
       s = row16_sum(s);
       const int row = mt * 16 + (lane >> 4) * 4 + r;
       if ((lane & 15) == 0 && row < R) {

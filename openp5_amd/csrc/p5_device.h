@@ -228,6 +228,12 @@ __device__ static __forceinline__ void gload16_raw(u32x4& dst, const void* p) {
 #define P5_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
+// ---- exponential of the mode: exact expf in the fp32 parity mode, the exp2-based 2-ulp __expf in the bf16 mode (the precise
+// one is ~30 instructions; softmax / log-sum-exp kernels call it tens of times per lane) ----
+template <class T> __device__ static __forceinline__ float p5_exp(float x);
+template <> __device__ __forceinline__ float p5_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float p5_exp<bf16>(float x) { return __expf(x); }
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -268,6 +274,22 @@ template <> __device__ __forceinline__ void unpack16<bf16>(const u32x4& v, float
     lo.u = v[i] << 16; hi.u = v[i] & 0xFFFF0000u;
     out[2 * i] = lo.f; out[2 * i + 1] = hi.f;
   }
+}
+// four consecutive T elements (8 bytes of bf16 / 16 bytes of fp32) from fp32, one store
+template <class T> __device__ static __forceinline__ void st4(void* p, const float* in);
+template <> __device__ __forceinline__ void st4<float>(void* p, const float* in) {
+  *(f32x4*)p = (f32x4){in[0], in[1], in[2], in[3]};
+}
+template <> __device__ __forceinline__ void st4<bf16>(void* p, const float* in) {
+  u32x2 v;
+#ifdef P5_HW_BF16
+  v[0] = cvt_pk_bf16(in[0], in[1]);
+  v[1] = cvt_pk_bf16(in[2], in[3]);
+#else
+  v[0] = (unsigned)f2bf(in[0]).v | ((unsigned)f2bf(in[1]).v << 16);
+  v[1] = (unsigned)f2bf(in[2]).v | ((unsigned)f2bf(in[3]).v << 16);
+#endif
+  *(u32x2*)p = v;
 }
 template <class T> __device__ static __forceinline__ u32x4 pack16(const float* in);
 template <> __device__ __forceinline__ u32x4 pack16<float>(const float* in) {

@@ -335,6 +335,8 @@ __device__ static __forceinline__ float block_reduce(float v, bool is_max, float
   return r;
 }
 
+// (T selects the exponential: exact expf in the fp32 parity mode, the 2-ulp exp2-based one in the bf16 mode -- 16 M calls per step)
+template <class T>
 __global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll, float* __restrict__ lse_out,
                                                        const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                        int V, int ldl) {
@@ -347,22 +349,22 @@ __global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll,
   for (int j = tid; j < V4; j += 256) {
     const f32x4 v = *(const f32x4*)(lr + 4 * j);
     const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    if (mx > m) { s *= expf(m - mx); m = mx; }
-    s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+    if (mx > m) { s *= p5_exp<T>(m - mx); m = mx; }
+    s += p5_exp<T>(v[0] - m) + p5_exp<T>(v[1] - m) + p5_exp<T>(v[2] - m) + p5_exp<T>(v[3] - m);
   }
   for (int j = (V4 << 2) + tid; j < V; j += 256) {
     const float v = lr[j];
-    if (v > m) { s *= expf(m - v); m = v; }
-    s += expf(v - m);
+    if (v > m) { s *= p5_exp<T>(m - v); m = v; }
+    s += p5_exp<T>(v - m);
   }
   {
     const float wm_ = wave_max(m);
-    s = wave_sum(m == P5_NEG_INF ? 0.f : s * expf(m - wm_));
+    s = wave_sum(m == P5_NEG_INF ? 0.f : s * p5_exp<T>(m - wm_));
     if ((tid & 63) == 0) { sm[tid >> 6] = wm_; ss[tid >> 6] = s; }
     __syncthreads();
     m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     s = 0.f;
-    for (int w = 0; w < 4; ++w) s += ss[w] * expf(sm[w] - m);
+    for (int w = 0; w < 4; ++w) s += ss[w] * p5_exp<T>(sm[w] - m);
   }
   if (threadIdx.x == 0) {
     const float lse = m + logf(s);
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void p5_ce_bwd_kernel(T* __restrict__ dlogits,
     float v[8], o[8];
     ldf<EPF>(lr + j, v);
 #pragma unroll
-    for (int e = 0; e < EPF; ++e) o[e] = (j + e < V) ? (expf(v[e] - l) - (j + e == lab ? 1.f : 0.f)) * g : 0.f;
+    for (int e = 0; e < EPF; ++e) o[e] = (j + e < V) ? (p5_exp<T>(v[e] - l) - (j + e == lab ? 1.f : 0.f)) * g : 0.f;
     st16(dlogits + (size_t)row * ldd + j, pack16<T>(o));
   }
 }

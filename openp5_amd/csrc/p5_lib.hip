@@ -45,6 +45,8 @@ static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE"
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
 static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
+static int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
+static int g_opt_gemm_small_ring_tiles = getenv("P5_GEMM_SMALL_RING_TILES") ? atoi(getenv("P5_GEMM_SMALL_RING_TILES")) : 256;   // ... up to this many 64x64 tiles
 static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
 static int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING_WGS")) : 160;      // target tiles x splits (in-step sweep: 96..192 equal, 256 +1.5 %)
 static int g_opt_decode_fused = getenv("P5_DECODE_FUSED") ? atoi(getenv("P5_DECODE_FUSED")) : 1;   // RMSNorm folded into the decode-step GEMMs
@@ -145,7 +147,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     g.splitk = sk < 1 ? 1 : (sk > maxs ? maxs : sk);
   }
   const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-  if (sizeof(T) == 2 && !big && !force_tile && g_opt_gemm_small_ring && !g.ring && tiles <= 256 && g.K >= 256 && (g.K % 64) == 0 &&
+  if (sizeof(T) == 2 && !big && !force_tile && g_opt_gemm_small_ring && !g.ring && tiles <= g_opt_gemm_small_ring_tiles && g.K >= 256 && (g.K % 64) == 0 &&
       (g.a_ks == 0 || g.b_ks == 1) &&
       (g.epi != P5_EPI_ATOMIC || g.K <= 1024)) {
     g.ring = 1;                      // (long-K atomic problems keep the split-K path below)
@@ -190,6 +192,13 @@ template <class T>
 static int launch_attn_bwd(const P5AttnArgs& a, hipStream_t s) {
   P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
   dim3 block(256);
+  if constexpr (sizeof(T) == 2) {
+    // one workgroup per (batch, head) that reads Q, K, V, dO once (p5_attn.h); short decoder blocks stay on the two-kernel path
+    if (g_opt_attn_fused && a.Lq <= 128 && a.Lk <= 128 && a.Lq > 16 && a.Lk > 16) {
+      P5_LAUNCH((p5_attn_bwd_fused_kernel<T>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      return P5_KCHECK();
+    }
+  }
   P5_LAUNCH((p5_attn_bwd_dq_kernel<T>), dim3((a.Lq + 63) / 64, a.B * a.H), block, 0, s, a);
   P5_TRY(P5_KCHECK());
   P5_LAUNCH((p5_attn_bwd_dkv_kernel<T>), dim3((a.Lk + 63) / 64, a.B * a.H), block, 0, s, a);
@@ -308,7 +317,9 @@ struct P5Engine {
   std::vector<TrDesc> tr_list;
   int tr_tiles = 0;
   bool tr_pending = false;
+  bool zg_pending = false;        // p5_engine_clear_grads(): the clear runs on the side stream; the next backward waits for zg_ev
 #ifndef P5_EMU
+  hipEvent_t zg_ev = nullptr;
   hipEvent_t tr_ev = nullptr;
   hipGraphExec_t gen_graph_exec = nullptr;
   bool gen_graph_failed = false;
@@ -756,7 +767,7 @@ template <class T>
 static int forward_impl(P5Engine* e, float* nll_out, hipStream_t s) {
   P5_TRY(encoder_fwd<T>(e, s));
   P5_TRY(decoder_fwd<T>(e, s));
-  P5_LAUNCH(p5_ce_fwd_kernel, dim3(e->Md), dim3(256), 0, s, nll_out, e->lse_tok, (const float*)e->logits, e->labels, e->c.vocab_size, e->Vp);
+  P5_LAUNCH((p5_ce_fwd_kernel<T>), dim3(e->Md), dim3(256), 0, s, nll_out, e->lse_tok, (const float*)e->logits, e->labels, e->c.vocab_size, e->Vp);
   return P5_KCHECK();
 }
 
@@ -846,6 +857,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     if (e->tr_pending && e->tr_ev) { hipStreamWaitEvent(s, e->tr_ev, 0); hipStreamWaitEvent(e->side ? e->side : s, e->tr_ev, 0); }
 #endif
     e->tr_pending = false;
+#ifndef P5_EMU
+    if (e->zg_pending && e->zg_ev) { hipStreamWaitEvent(s, e->zg_ev, 0); if (e->side) hipStreamWaitEvent(e->side, e->zg_ev, 0); }
+#endif
+    e->zg_pending = false;
     if (!dnll) P5_REQUIRE(e->out_attn, "backward without dnll needs p5_forward_loss (output_attention mask)");
     P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
               e->labels, dnll, c.vocab_size, e->Vp, e->Vp, e->out_attn, e->T, 1.0f / (float)e->B);
@@ -1132,6 +1147,9 @@ static int skinny(hipStream_t s, int amode, const void* A, int lda, const float*
 // fits 128 KiB (bf16 d_model 512 -> 128, 768/1024 -> 64; fp32 512 -> 64, 768/1024 -> 32)
 static int head_nv(const P5Engine* e) {
   if (!g_opt_dec_head || !g_opt_decode_v2) return 0;
+  // the kernel walks K in units of eight 64-byte chunks (p5_decode2.h): d_model % 256 (bf16) / % 128 (fp32) -- every T5 size;
+  // other widths (toy models) take the materialised-logits head
+  if (e->c.d_model % (e->c.dtype == 1 ? 256 : 128) != 0) return 0;
   const size_t row = (size_t)e->c.d_model * (e->c.dtype == 1 ? 2 : 4);
   if (g_opt_dec_head_nv) return (size_t)g_opt_dec_head_nv * row <= 128 * 1024 ? g_opt_dec_head_nv : 0;
   for (int nv = 128; nv >= 16; nv >>= 1)
@@ -1399,6 +1417,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring")) g_opt_gemm_ring = value;
   else if (!strcmp(name, "decode_fused")) g_opt_decode_fused = value;
   else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
+  else if (!strcmp(name, "gemm_small_ring_tiles")) g_opt_gemm_small_ring_tiles = value;
+  else if (!strcmp(name, "attn_fused")) g_opt_attn_fused = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else if (!strcmp(name, "decode_v2")) g_opt_decode_v2 = value;
   else if (!strcmp(name, "dec_nb")) g_opt_dec_nb = value;
@@ -1546,6 +1566,27 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   return 0;
 }
 int p5_engine_grads_zeroed(P5Engine* e) { e->grads_zeroed = true; return 0; }
+
+// zero_grad() of the reference loop (DistributedRunner.py:93): the 4 B x n_params fill is HBM-bound and nothing before the next
+// backward needs its result, so it goes to the side stream (ordered after everything `stream` has been given so far, i.e. after
+// the optimizer read the gradients) and overlaps the next forward; backward stage 0 waits for it.
+int p5_engine_clear_grads(P5Engine* e, void* stream) {
+  P5_REQUIRE(e->G, "engine not bound");
+  hipStream_t main = (hipStream_t)stream, s = main;
+#ifndef P5_EMU
+  if (e->side) { fork_to_side(e, main); s = e->side; }
+#endif
+  if (hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s) != 0) return fail("clear_grads: hipMemsetAsync failed");
+#ifndef P5_EMU
+  if (e->side) {
+    if (!e->zg_ev) hipEventCreateWithFlags(&e->zg_ev, hipEventDisableTiming);
+    hipEventRecord(e->zg_ev, s);
+    e->zg_pending = true;
+  }
+#endif
+  e->grads_zeroed = true;
+  return 0;
+}
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
 #ifndef P5_EMU
   if (side_stream && !e->side) {
@@ -1697,7 +1738,7 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
   return dtype == 1 ? launch_attn_bwd<bf16>(a, (hipStream_t)stream) : launch_attn_bwd<float>(a, (hipStream_t)stream);
 }
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream) {
-  P5_LAUNCH(p5_ce_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, nll, lse, logits, labels, V, ldl);
+  P5_LAUNCH((p5_ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream, nll, lse, logits, labels, V, ldl);
   return P5_KCHECK();
 }
 int p5_op_skinny_gemm(int dtype, int amode, const void* A, int lda, const float* ln, const void* W, int ldw, void* C, int ldc, int M, int N, int K,

@@ -21,9 +21,12 @@ __host__ __device__ static inline uint32_t p5_mix32(uint32_t x) {  // "lowbias32
   return x;
 }
 __host__ __device__ static inline uint32_t p5_site_key(uint32_t site) { return site * 0x85EBCA6Bu + 0x27D4EB2Fu; }
+// keep(seed, site, idx): ONE mixing round per element -- the (seed, site) part is mixed separately and is loop-invariant
+// (wave-uniform, hoisted by the compiler), so an element costs an xor and lowbias32's two 32-bit multiplies.  32-bit integer
+// multiplies are quarter-rate on CDNA; the first version (idx * odd + seed -> mix -> xor site -> mix: five of them per element)
+// made the dropout epilogues of the GEMMs and the attention kernels VALU-bound.
 __host__ __device__ static inline bool p5_keep(uint32_t seed, uint32_t site_key, uint32_t idx, uint32_t thr) {
-  uint32_t h = p5_mix32(idx * 0x9E3779B1u + seed);
-  h = p5_mix32(h ^ site_key);
+  const uint32_t h = p5_mix32(idx ^ p5_mix32(seed + site_key));
   return (h >> 8) >= thr;
 }
 __host__ static inline uint32_t p5_drop_thr(float p) { return (uint32_t)(p * 16777216.0f); }

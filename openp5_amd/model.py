@@ -399,10 +399,10 @@ class P5T5Native(nn.Module):
         return self
 
     def zero_grad(self, set_to_none: bool = True):
-        # the views stay attached; the engine would clear the arena at the start of the next backward anyway -- tell it that
-        # this fill already did (one 243 MB pass per step instead of two)
-        self._grads.zero_()
-        self._lib.p5_engine_grads_zeroed(self._engine)
+        # the views stay attached.  The engine clears the arena itself -- on its side stream, after the optimizer step already
+        # queued on this stream, so that the 243 MB fill overlaps the next forward; the next backward waits for it (nothing
+        # reads gradients in between in the reference loop, DistributedRunner.py:84-93)
+        self._be.check(self._lib.p5_engine_clear_grads(self._engine, self._be.stream_ptr()), "clear_grads")
 
     def tie_weights(self):
         return None

@@ -169,8 +169,9 @@ def _mix32(x: Tensor) -> Tensor:
 def dropout_keep_mask(seed: int, site: int, numel: int, p: float) -> Tensor:
     """keep[i] for linear element index i; identical to `p5_keep(seed, site, i, thr)` on the device."""
     idx = torch.arange(numel, dtype=torch.int64)
-    h = _mix32((idx * 0x9E3779B1 + (seed & _M32)) & _M32)
-    h = _mix32(h ^ ((site * 0x85EBCA6B + 0x27D4EB2F) & _M32))
+    site_key = (site * 0x85EBCA6B + 0x27D4EB2F) & _M32
+    sm = int(_mix32(torch.tensor([((seed & _M32) + site_key) & _M32], dtype=torch.int64))[0])
+    h = _mix32((idx & _M32) ^ sm)
     thr = int(p * 16777216.0)
     return (h >> 8) >= thr
 

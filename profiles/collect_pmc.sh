@@ -46,5 +46,6 @@ for k, e in tab.items():
         e["traffic_bytes"] = e["read_bytes"] + e["write_bytes"]
         e["note"] = "per launch; FETCH_SIZE x2 (gfx950), separate --pmc passes, averaged over the launches of tools/gemm_one.py"
 json.dump(tab, open(f"{root}/profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump(tab, open(f"{root}/gpurun_out/pmc_traffic.json", "w"), indent=1, sort_keys=True)   # gpurun merges gpurun_out/ back
 print(json.dumps(tab, indent=1, sort_keys=True))
 PY

@@ -239,6 +239,50 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
     return errs
 
 
+def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
+    """bf16 attention backward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_bwd_fused_kernel) against the
+    two-kernel path on identical inputs (same forward output, lse and counter-based masks).  Both round P and dS to bf16 at the
+    same point, so they differ only by the order of fp32 accumulation."""
+    g = torch.Generator().manual_seed(seed)
+    inner = H * 64
+    tt = torch.bfloat16
+    qkv = dev(be, (0.5 * torch.randn(B * L, 3 * inner, generator=g)).to(tt))
+    Qd, Kd, Vd = qkv, qkv[:, inner:], qkv[:, 2 * inner:]
+    table_d = dev(be, 0.5 * torch.randn(32, H, generator=g))
+    lut_half = 512
+    lut_d = dev(be, relative_position_bucket_lut(lut_half, mode == "enc", 32, 128))
+    kmask = torch.ones(B, L, dtype=torch.long)
+    if mode == "enc":
+        for b in range(B):
+            kmask[b, int(torch.randint(max(1, L // 2), L + 1, (1,), generator=g)):] = 0
+    km_d = dev(be, kmask) if mode == "enc" else None
+    causal = 1 if mode == "dec" else 0
+    dOd = dev(be, torch.randn(B * L, inner, generator=g).to(tt))
+    rng = dev(be, torch.tensor([1234, 7], dtype=torch.int32))
+    Od = dev(be, torch.zeros(B * L, inner, dtype=tt))
+    lse = dev(be, torch.zeros(B * H * L))
+    be.check(be.lib.p5_op_attn_fwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner,
+                                   3 * inner, 3 * inner, inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_fwd")
+    res = []
+    for fused in (1, 0):
+        be.check(be.lib.p5_set_option(b"attn_fused", fused), "set_option")
+        dqkv = dev(be, torch.zeros(B * L, 3 * inner, dtype=tt))
+        dtab = dev(be, torch.zeros(32, H))
+        Dv = dev(be, torch.zeros(B * H * L))
+        be.check(be.lib.p5_op_attn_bwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(dOd), P(lse), P(Dv), P(dqkv), P(dqkv[:, inner:]), P(dqkv[:, 2 * inner:]),
+                                       P(table_d), P(dtab), P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner, 3 * inner, 3 * inner, inner,
+                                       3 * inner, 3 * inner, 3 * inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_bwd")
+        sync(be)
+        res.append((dqkv.cpu().float(), dtab.cpu().clone()))
+    be.check(be.lib.p5_set_option(b"attn_fused", 1), "set_option")
+    (ga, ta), (gb, tb) = res
+    assert gb.abs().max() > 0.05
+    e_g = (ga - gb).abs().max().item() / gb.abs().max().item()
+    e_t = (ta - tb).abs().max().item() / max(1e-6, tb.abs().max().item())
+    assert e_g <= 1e-2 and e_t <= 1e-3, f"fused vs two-kernel attention backward: grads {e_g}, rel-bias table {e_t}"
+    return e_g, e_t
+
+
 # ---------------------------------------------------------------------------------------------------------
 def build_model(be, ocfg, params, dtype, dropout=0.0, seed=1):
     cfg = P5ModelConfig(vocab_size=ocfg.vocab_size, d_model=ocfg.d_model, d_ff=ocfg.d_ff, num_layers=ocfg.num_layers,

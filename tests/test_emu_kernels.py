@@ -81,6 +81,17 @@ def test_attention_long(emu):
     cases.attn_case(emu, 0, 1, 1, 130, 130, "enc")
 
 
+@pytest.mark.parametrize("L", [120, 128])
+def test_attention_bf16_full_block(emu, L):
+    """the shapes the fused bf16 backward (one workgroup per (batch, head), L <= 128) is built for"""
+    cases.attn_case(emu, 1, 1, 2, L, L, "enc")
+
+
+@pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 50), ("dec", 24)])
+def test_attention_fused_backward_matches_split(emu, mode, L):
+    cases.attn_fused_bwd_case(emu, 2, 2, L, mode)
+
+
 def test_model_fp32(emu):
     cases.model_train_case(emu, O.T5Cfg.named("tiny"), 3, 20, 6, "fp32", 0.0)
 
@@ -168,6 +179,14 @@ def test_dec_cross_attn(emu, dtype, variant, shape):
     """single-token cross-attention of the beams of an item (HF modeling_t5.py:404-432 with zero position bias): the matrix-core
     kernel and the scalar kernel against float64, incl. ragged L, > 16 beams (two row tiles) and L = 512 (four key chunks)."""
     cases.dec_cross_attn_case(emu, dtype, variant, *shape)
+
+
+@pytest.mark.parametrize("dtype,d_model,heads", [("fp32", 64, 1), ("fp32", 64, 2), ("fp32", 192, 2), ("bf16", 64, 1)])
+def test_generate_odd_widths(emu, dtype, d_model, heads):
+    """d_model that the streaming head's K units do not divide (toy models of the runner tests): the engine must take the
+    materialised-logits head there instead of computing nothing (inf scores)."""
+    cfg = O.T5Cfg.named("tiny", d_model=d_model, d_ff=128, num_heads=heads, num_layers=1, num_decoder_layers=1)
+    cases.generate_case(emu, cfg, 3, 20, 5, 12, 40, dtype=dtype, score_tol=2e-5 if dtype == "fp32" else 0.3)
 
 
 def test_stepwise_decode_api(emu):

@@ -64,6 +64,19 @@ def test_attention(hip, dtype, mode, Lq, Lk):
     cases.attn_case(hip, dtype, 2, 3, Lq, Lk, mode)
 
 
+@pytest.mark.parametrize("d_model", [64, 192])
+def test_generate_odd_width(hip, d_model):
+    """d_model that is not a multiple of the streaming head's K unit (the runner tests' toy model): materialised-logits head"""
+    cfg = O.T5Cfg.named("tiny", d_model=d_model, d_ff=128, num_heads=1, num_layers=1, num_decoder_layers=1)
+    cases.generate_case(hip, cfg, 3, 20, 5, 12, 40, score_tol=1e-4)
+
+
+@pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 120), ("enc", 50), ("dec", 24)])
+def test_attention_fused_backward_matches_split(hip, mode, L):
+    """bf16, dropout on: the fused dQ/dK/dV kernel against the two-kernel backward on the same inputs and masks"""
+    cases.attn_fused_bwd_case(hip, 4, 8, L, mode)
+
+
 def test_model_fp32(hip):
     cases.model_train_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6, "fp32", 0.0)
 

@@ -11,3 +11,4 @@ timeout 600 python bench.py > gpurun_out/final_bench.log 2>&1; grep '^{' gpurun_
 bash profiles/profile.sh final_train python bench.py --steps 10 --warmup 3 --no-cpu --no-gen --legs none
 bash profiles/profile.sh final_gen python tools/gen_bench.py 20 5
 bash profiles/profile.sh final_train_serialized python tools/bench_noside.py --steps 10 --warmup 3 --no-cpu --no-gen --legs none
+python tools/attn_bench.py > gpurun_out/final_attn_bench.txt 2>&1; tail -4 gpurun_out/final_attn_bench.txt
