@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void p5_embed_fwd_kernel(T* __restrict__ out, 
   }
 }
 
-// dE[ids[row],:] += mask(dres[row,:]);  dWW[ww[row],:] += same   (SURVEY.md App. C "Embedding lookups")
+// dE[ids[row],:] += mask(dres[row,:]);  dWW[ww[row],:] += same   (SURVEY.md App. C "Embedding lookups"); either table may be
+// nullptr (the two scatters of the encoder run on two streams at the end of the backward, where nothing else is left to overlap)
 template <class T>
 __global__ __launch_bounds__(256) void p5_embed_bwd_kernel(float* __restrict__ dE, float* __restrict__ dWW,
                                                           const float* __restrict__ dres, const int64_t* __restrict__ ids,
@@ -46,14 +47,14 @@ __global__ __launch_bounds__(256) void p5_embed_bwd_kernel(float* __restrict__ d
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int64_t id = ids[row];
+  const int64_t id = dE ? ids[row] : 0;
   const int64_t w = dWW ? ww[row] : 0;
   const bool do_drop = drop.state != nullptr && drop.thr != 0;
   const uint32_t seed = p5_seed(drop);
   for (int c = lane; c < d; c += 64) {
     float v = dres[(size_t)row * d + c];
     if (do_drop) v = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c), drop.thr) ? v * drop.scale : 0.f;
-    atomicAdd(dE + (size_t)id * d + c, v);
+    if (dE) atomicAdd(dE + (size_t)id * d + c, v);
     if (dWW) atomicAdd(dWW + (size_t)w * d + c, v);
   }
 }

@@ -518,7 +518,9 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
   constexpr int NFR = TM + TN, NMM = TM * TN;
   static_assert(NST >= 2 && NST <= 8 && (NST - 2) * ((BM + BN) / 32) <= 60, "LDS stages / vmcnt range");
   constexpr int PFD = NST - 1;                        // stages in flight ahead of the one being multiplied
-  static_assert(NMM >= NFR, "interleave pattern: one fragment read per MFMA");
+  // fragment reads / stage copies issued behind each MFMA of a K-half (1 whenever the wave tile has at least as many MFMAs as
+  // fragments, i.e. from 64x64 up; 2 for the 32x64 tile of the sub-CU-count decoder problems)
+  constexpr int LPM = (NFR + NMM - 1) / NMM, DPM = (NDMA + NMM - 1) / NMM;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -647,8 +649,12 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
         P5_SCHED_FENCE();
-        if (t < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), t);
-        if (t < NDMA) copy_one(nb2, t);     // stage s+PFD -> ring slot of stage s-1 (read out before that step's barrier)
+#pragma unroll
+        for (int q = t * LPM; q < (t + 1) * LPM; ++q)
+          if (q < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), q);
+#pragma unroll
+        for (int q = t * DPM; q < (t + 1) * DPM; ++q)
+          if (q < NDMA) copy_one(nb2, q);   // stage s+PFD -> ring slot of stage s-1 (read out before that step's barrier)
         P5_SCHED_FENCE();
       }
       P5_WAIT_VM((PFD - 1) * NDMA);         // this wave's share of stage s+1 has landed
@@ -658,7 +664,9 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa1[t / TN], fb1[t % TN]);
         P5_SCHED_FENCE();
-        if (t < NFR) load_one(fa0, fb0, nb1, P5Bool<false>(), t);
+#pragma unroll
+        for (int q = t * LPM; q < (t + 1) * LPM; ++q)
+          if (q < NFR) load_one(fa0, fb0, nb1, P5Bool<false>(), q);
         P5_SCHED_FENCE();
       }
     };
@@ -692,9 +700,14 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
       for (int t = 0; t < NMM; ++t) {
         mma16<T>(acc[t / TN][t % TN], fa0[t / TN], fb0[t % TN]);
         P5_SCHED_FENCE();
-        if (t < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), t);
-        if constexpr (COPY)
-          if (t < NDMA) copy_one(buf ^ 1, t);
+#pragma unroll
+        for (int q = t * LPM; q < (t + 1) * LPM; ++q)
+          if (q < NFR) load_one(fa1, fb1, buf, P5Bool<true>(), q);
+        if constexpr (COPY) {
+#pragma unroll
+          for (int q = t * DPM; q < (t + 1) * DPM; ++q)
+            if (q < NDMA) copy_one(buf ^ 1, q);
+        }
         P5_SCHED_FENCE();
       }
 #pragma unroll

@@ -45,6 +45,7 @@ static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE"
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
 static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
+static int g_opt_gemm_ring32 = getenv("P5_GEMM_RING32") ? atoi(getenv("P5_GEMM_RING32")) : 128;   // 32x64 ring tiles for problems of at most this many 64x64 tiles (0 = off)
 static int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
 static int g_opt_gemm_small_ring_tiles = getenv("P5_GEMM_SMALL_RING_TILES") ? atoi(getenv("P5_GEMM_SMALL_RING_TILES")) : 256;   // ... up to this many 64x64 tiles
 static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
@@ -173,6 +174,17 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     if (force_tile == 256 || (!force_tile && kc_dma && t256 >= 256 && g.K >= 1024 && g.splitk <= 1)) {
       if (g.splitk <= 0) g.splitk = 1;
       return launch_gemm_tile<T, 256, 256>(g, s);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // the decoder's 512-row problems: 64 tiles of 64x64 use a quarter of the CUs, each pulling 128 KiB through its ring; 32x64
+    // tiles double the workgroups and halve the A rows each one waits for
+    if (!big && g.ring && !g.a_ks && !g.b_ks && g.splitk <= 1 && tiles <= g_opt_gemm_ring32) {
+      dim3 grid((g.N + 63) / 64, (g.M + 31) / 32, 1);
+      g.xcd_bm = g.xcd_bn = 0;
+      g.splitk = 1;
+      P5_LAUNCH((p5_gemm2_kernel<32, 64, 8, false, false>), grid, dim3(256), 0, s, g);
+      return P5_KCHECK();
     }
   }
   return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
@@ -953,11 +965,22 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     return 0;
   }
   if (stage == nd + ne + 3) {
-    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_enc_rel,
+    // the tail of the backward: nothing is left to overlap these with except each other -- the whole-word scatter and the
+    // relative-bias reduction go to the side stream (p5_backward_stage joins it after this stage), the token scatter stays here
+    hipStream_t s2 = s;
+#ifndef P5_EMU
+    if (e->side) { fork_to_side(e, s); s2 = e->side; }
+#endif
+    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s2, e->G + e->off_enc_rel,
               (const float*)e->rel_partial, c.rel_buckets * H, REL_COPIES);
     P5_TRY(P5_KCHECK());
-    P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, e->G + e->off_E, e->G + e->off_WW, (const float*)e->dres_cur,
-              e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
+    if (s2 != s) {
+      P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s2, (float*)nullptr, e->G + e->off_WW, (const float*)e->dres_cur,
+                e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
+      P5_TRY(P5_KCHECK());
+    }
+    P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, e->G + e->off_E, s2 != s ? (float*)nullptr : e->G + e->off_WW,
+              (const float*)e->dres_cur, e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
     return P5_KCHECK();
   }
   return fail("backward: bad stage");
@@ -1419,6 +1442,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
   else if (!strcmp(name, "gemm_small_ring_tiles")) g_opt_gemm_small_ring_tiles = value;
   else if (!strcmp(name, "attn_fused")) g_opt_attn_fused = value;
+  else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else if (!strcmp(name, "decode_v2")) g_opt_decode_v2 = value;
   else if (!strcmp(name, "dec_nb")) g_opt_dec_nb = value;

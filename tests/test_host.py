@@ -126,7 +126,10 @@ def test_metrics_equal_reference():
     assert a == b_
 
 
-def make_args(tmp, extra=()):
+SMALL_TOY = dict(n_users=12, n_items=24, n_inter=90)     # a third of the Toy set: the emulated-kernel runner tests that only need "some epochs"
+
+
+def make_args(tmp, extra=(), toy=None):
     parser = argparse.ArgumentParser()
     utils.parse_global_args(parser)
     MultiTaskDataset.parse_dataset_args(parser)
@@ -134,7 +137,7 @@ def make_args(tmp, extra=()):
     from openp5_amd.runner import parse_runner_args
     parse_runner_args(parser)
     prompt = write_prompt_file(os.path.join(tmp, "prompt.txt"))
-    write_dataset(os.path.join(tmp, "data"), "Toy")
+    write_dataset(os.path.join(tmp, "data"), "Toy", **(toy or {}))
     args = parser.parse_args(["--data_path", os.path.join(tmp, "data"), "--datasets", "Toy", "--tasks", "sequential,straightforward",
                               "--item_indexing", "sequential", "--prompt_file", prompt, "--sample_prompt", "1", "--sample_num", "3,3",
                               "--max_his", "20", "--distributed", "0", "--batch_size", "4", "--eval_batch_size", "5"] + list(extra))

@@ -18,7 +18,7 @@ from openp5_amd.optim import FusedAdamW
 from openp5_amd.runner import DistributedRunner, masked_mean_loss
 from openp5_amd.sampler import DistMultiDataTaskSampler, SingleMultiDataTaskSampler
 from openp5_amd.tokenizer import build_offline_tokenizer
-from tests.test_host import make_args
+from tests.test_host import SMALL_TOY, make_args
 
 VOCAB = 2400
 
@@ -31,7 +31,7 @@ def tiny_model(be, vocab, dropout=0.0, seed=3, dtype="fp32"):
 def test_runner_train_and_eval(emu, tmp_path):
     tok = build_offline_tokenizer(VOCAB)
     args = make_args(str(tmp_path), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics", "hit@5,ndcg@5",
-                                     "--eval_batch_size", "6", "--batch_size", "8", "--sample_num", "1,1", "--max_his", "3"])
+                                     "--eval_batch_size", "6", "--batch_size", "8", "--sample_num", "1,1", "--max_his", "3"], toy=SMALL_TOY)
     args.model_path = str(tmp_path / "m.pt")
     random.seed(0)
     train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
@@ -65,7 +65,7 @@ def test_runner_train_and_eval(emu, tmp_path):
 
 def _eval_runner(emu, tmp_path, tok, extra):
     args = make_args(str(tmp_path), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics",
-                                     "hit@1,hit@5,ndcg@5", "--batch_size", "8", "--sample_num", "1,1", "--max_his", "8"] + extra)
+                                     "hit@1,hit@5,ndcg@5", "--batch_size", "8", "--sample_num", "1,1", "--max_his", "8"] + extra, toy=SMALL_TOY)
     random.seed(0)
     train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
     loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
@@ -209,7 +209,7 @@ def test_resume_is_exact(emu, tmp_path):
 
     def build(epochs, extra=()):
         args = make_args(str(tmp_path), ["--epochs", str(epochs), "--test_before_train", "0", "--test_epoch", "0", "--batch_size", "8",
-                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra))
+                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra), toy=SMALL_TOY)
         args.model_path = str(tmp_path / "m.pt")
         random.seed(0)
         train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
@@ -244,7 +244,7 @@ def test_resume_mid_epoch_is_exact(emu, tmp_path):
 
     def build(extra=()):
         args = make_args(str(tmp_path), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--batch_size", "8",
-                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra))
+                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra), toy=SMALL_TOY)
         args.model_path = str(tmp_path / "m.pt")
         random.seed(0)
         train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
@@ -302,7 +302,7 @@ def _world2_runner_worker(rank, world, port, tmp, _):
     tok = build_offline_tokenizer(VOCAB)
     args = make_args(os.path.join(tmp, f"r{rank}"), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "1", "--metrics", "hit@5,ndcg@5",
                                                     "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3",
-                                                    "--distributed", "1"])
+                                                    "--distributed", "1"], toy=SMALL_TOY)
     args.rank = rank
     args.model_path = os.path.join(tmp, f"m{rank}.pt")
     random.seed(0)
@@ -334,13 +334,14 @@ def test_world2_runner_train_and_test(emu, tmp_path):
     assert torch.equal(w0["flat"], w1["flat"]), "ranks diverged during runner.train()"
     assert w0["res"] == w1["res"] and len(w0["res"]) == 2
     assert len(w0["losses"]) == 1 and w1["losses"] == []           # only rank 0 records the (all-reduced) epoch loss
-    for i0, i1, tl_n in zip(w0["idx"], w1["idx"], (30, 30)):
+    nu = SMALL_TOY["n_users"]
+    for i0, i1, tl_n in zip(w0["idx"], w1["idx"], (nu, nu)):
         assert len(i0) == len(i1) == (tl_n + 1) // 2 and set(i0) | set(i1) == set(range(tl_n))     # DistributedSampler shards
     # single-process evaluation of the same weights on the users rank 0 and rank 1 saw (DistributedSampler pads by repetition:
     # a few users are counted twice, SURVEY.md App. B #11 -- reproduce exactly that multiset)
     tok = build_offline_tokenizer(VOCAB)
     args = make_args(str(tmp_path / "single"), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "0", "--metrics", "hit@5,ndcg@5",
-                                                "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3"])
+                                                "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3"], toy=SMALL_TOY)
     random.seed(0)
     train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
     loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
