@@ -38,6 +38,10 @@ def load_hip_library():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "openp5_amd has no CPU fallback.")
+        # torch first: its wheel bundles its own libamdhip64; a process that loads this library (linked against the system HIP
+        # runtime) BEFORE torch ends up with two HIP runtimes, and every launch from here then fails with "no ROCm-capable
+        # device is detected" because device memory and streams belong to the other one
+        import torch  # noqa: F401
         lib = _abi.bind(ctypes.CDLL(LIB_PATH))
         if lib.p5_is_emulator():
             raise ImportError("libp5hip.so is an emulator build; refusing to use it as the product library")
