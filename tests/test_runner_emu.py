@@ -202,6 +202,47 @@ def test_gradient_accumulation_equals_big_batch(emu):
     assert float(ma._grads.abs().sum()) == 0.0                      # zero_grad after the group
 
 
+def _ddp_accum_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openp5_amd.runner import training_step
+    from tests.emu.emu_backend import emu_backend
+    be = emu_backend()
+    tok = build_offline_tokenizer(VOCAB)
+    model = tiny_model(be, len(tok), seed=5)
+    model.ddp_world = world
+    opt = FusedAdamW(model, lr=1e-2, max_grad_norm=1.0)
+    model.eval()
+    batches = _fixed_batches(tok, 4)
+    mine = batches[2 * rank:2 * rank + 2]                      # rank r owns micro-batches 2r, 2r+1 of the group
+    training_step(model, opt, mine[0], micro=0, accum=2)
+    local_only = model._grads.clone()                          # no exchange on the first micro-batch
+    training_step(model, opt, mine[1], micro=1, accum=2)
+    torch.save({"flat": model._flat.clone(), "local": local_only, "t": opt.t}, os.path.join(tmp, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_accumulation(emu, tmp_path):
+    """world_size 2 x --gradient_accumulation_steps 2: gradients are exchanged on the LAST micro-batch only, one optimizer step per
+    group, and the result equals ONE process stepping on the concatenation of the four micro-batches."""
+    from openp5_amd.runner import training_step
+    world, port = 2, 25000 + random.randint(0, 2000)
+    mp.spawn(_ddp_accum_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a0, a1 = torch.load(tmp_path / "a0.pt"), torch.load(tmp_path / "a1.pt")
+    assert a0["t"] == a1["t"] == 1
+    assert torch.equal(a0["flat"], a1["flat"]), "ranks diverged"
+    assert not torch.equal(a0["local"], a1["local"])           # the first micro-batch's gradients stayed local
+    tok = build_offline_tokenizer(VOCAB)
+    batches = _fixed_batches(tok, 4)
+    big = tuple(torch.cat([b[i] for b in batches]) for i in range(5))
+    m = tiny_model(emu, len(tok), seed=5)
+    o = FusedAdamW(m, lr=1e-2, max_grad_norm=1.0)
+    m.eval()
+    training_step(m, o, big)
+    assert torch.allclose(m._flat, a0["flat"], atol=2e-6, rtol=1e-5), float((m._flat - a0["flat"]).abs().max())
+
+
 def test_resume_is_exact(emu, tmp_path):
     """train 2 epochs straight == train 1 epoch, save the resume file, build everything anew, --resume, train the 2nd epoch:
     identical parameters and optimizer moments (weights + m/v/t + schedule position + dropout counter + data order)."""
