@@ -277,6 +277,142 @@ __global__ __launch_bounds__(256) void p5_attn_fwd_kernel(P5AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward, one workgroup per (batch, head) (bf16, Lq and Lk <= 128).  The kernel above is ~60 % operand fetch at the benchmark
+// shape (its loads alone take 10-14 us of its 19 us) and reads K and V once per 64-query block; the decoder's
+// 8-query calls are chains of round trips (bias table, K tile, V tile, each behind a barrier).  Here NW waves (8 for
+// 64 < Lq <= 128, 4 below) share ONE copy of the whole K and V of the head, every global load of the workgroup is issued before
+// the first use, and after the single barrier each wave runs on its own: scores for its 16 queries against all keys, the exact
+// softmax, P through a wave-private tile, O = P V.  Same arithmetic, same order per row as p5_attn_fwd_kernel<T, 8>.
+// ------------------------------------------------------------------------------------------------------------
+template <class T, int NW>
+__global__ __launch_bounds__(NW * 64) void p5_attn_fwd_wg_kernel(P5AttnArgs a) {
+  static_assert(sizeof(T) == 2, "whole-head attention forward: bf16 only");
+  using C = AttnC<T>;
+  constexpr int NT = NW * 64, NKT = 8, NP = 128 * C::PPR / NT;
+  __shared__ __attribute__((aligned(16))) char tK[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tV[128 * C::TS];
+  __shared__ __attribute__((aligned(16))) char pbuf[NW * 16 * C::TS];
+  __shared__ float sbias[256];
+  __shared__ __attribute__((aligned(16))) float skneg[NKT * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int q0 = wave * 16, qi = q0 + li;
+  const bool qok = qi < a.Lq;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+
+  // ---- every global load of the workgroup, then one barrier ----
+  u32x4 qf[C::NCK], rk[NP], rv[NP];
+#pragma unroll
+  for (int c = 0; c < C::NCK; ++c) qf[c] = qok ? ld16(Q + (size_t)qi * a.ldq + c * C::KCH + g * C::EPF) : zero16();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = tid + i * NT, row = p / C::PPR, pc = p % C::PPR;
+    rk[i] = row < a.Lk ? ld16(K + (size_t)row * a.ldk + pc * C::EPF) : zero16();
+    rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * C::EPF) : zero16();
+  }
+  stage_bias_mask(a, b, h, sbias, skneg, NKT * 16, tid);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = tid + i * NT, row = p / C::PPR, pc = p % C::PPR;
+    st16(tK + row * C::TS + pc * 16, rk[i]);
+    st16(tV + row * C::TS + pc * 16, rv[i]);
+  }
+  __syncthreads();
+  if (q0 >= a.Lq) return;            // (no barrier below: a wave without queries is done once the tiles are staged)
+
+  // ---- scores (transposed: keys along the accumulator rows, see p5_attn_fwd_kernel) ----
+  const int nkt = (a.Lk + 15) / 16;
+  f32x4 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < nkt) {
+#pragma unroll
+      for (int c = 0; c < C::NCK; ++c) mma16<T>(s[t], tile_frag_kc<T>(tK, t * 16, c, lane), qf[c]);
+    }
+  }
+  const int qic = qok ? qi : a.Lq - 1;
+  const bool causal = a.causal != 0;
+  float m = P5_NEG_INF;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int kb = t * 16 + g * 4;
+    const f32x4 kn = *(const f32x4*)(skneg + kb);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.rel_table) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[r] = sbias[(kb + r - qic + a.Lq - 1) & 255];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kj = kb + r;
+      const bool ok = (kj < a.Lk) & qok & !(causal & (kj > qi));
+      const float v = ok ? (s[t][r] + kn[r]) + bias[r] : P5_NEG_INF;
+      s[t][r] = v;
+      m = fmaxf(m, v);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (m == P5_NEG_INF) m = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = p5_exp<T>(s[t][r] - m);
+      s[t][r] = p;
+      l += p;
+    }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (g == 0 && qok && a.lse) a.lse[((size_t)b * a.H + h) * a.Lq + qi] = m + logf(l);
+  if (a.drop.state != nullptr && a.drop.thr != 0) {
+    const uint32_t seed = p5_seed(a.drop);
+    const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t idx = rowbase + (uint32_t)(t * 16 + g * 4 + r);
+        s[t][r] = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? s[t][r] * a.drop.scale : 0.f;
+      }
+  }
+
+  // ---- O = P V: P goes through the wave's own tile, 64 keys at a time; V is already resident ----
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  char* pw = pbuf + wave * 16 * C::TS;
+#pragma unroll
+  for (int ch = 0; ch < NKT / 4; ++ch) {
+    if (ch * 64 < a.Lk) {
+      P5_WAVE_SYNC();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v4[4] = {s[ch * 4 + t][0], s[ch * 4 + t][1], s[ch * 4 + t][2], s[ch * 4 + t][3]};
+        st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, v4);
+      }
+      P5_WAVE_SYNC();
+#pragma unroll
+      for (int kc = 0; kc < C::NCK; ++kc) {
+        const u32x4 pa = ld16(pw + li * C::TS + kc * 64 + g * 16);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) mma16<T>(o[dt], pa, tile_frag_ks<T>(tV + ch * 64 * C::TS, dt * 16, kc, lane));
+      }
+    }
+  }
+  const float inv_q = l > 0.f ? 1.f / l : 0.f;
+  float inv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) inv[r] = __shfl(inv_q, g * 4 + r);
+  wave_store_16x64<T>((T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64, a.ldo, q0, a.Lq, o, inv, pw, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, part 1: dQ (+ d rel-bias table, + D = rowsum(dO*O) for part 2).  One wave = 16 queries.
 // ------------------------------------------------------------------------------------------------------------
 template <class T>

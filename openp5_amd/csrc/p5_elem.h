@@ -51,11 +51,24 @@ __global__ __launch_bounds__(256) void p5_embed_bwd_kernel(float* __restrict__ d
   const int64_t w = dWW ? ww[row] : 0;
   const bool do_drop = drop.state != nullptr && drop.thr != 0;
   const uint32_t seed = p5_seed(drop);
-  for (int c = lane; c < d; c += 64) {
-    float v = dres[(size_t)row * d + c];
-    if (do_drop) v = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c), drop.thr) ? v * drop.scale : 0.f;
-    if (dE) atomicAdd(dE + (size_t)id * d + c, v);
-    if (dWW) atomicAdd(dWW + (size_t)w * d + c, v);
+  // the row's values are all requested before the first atomic (an atomic per dependent load ran at 40 % of the atomic rate of the
+  // part): 16 columns per lane per pass
+  for (int c0 = 0; c0 < d; c0 += 64 * 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = c0 + k * 64 + lane;
+      v[k] = c < d ? dres[(size_t)row * d + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = c0 + k * 64 + lane;
+      if (c >= d) continue;
+      float x = v[k];
+      if (do_drop) x = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c), drop.thr) ? x * drop.scale : 0.f;
+      if (dE) atomicAdd(dE + (size_t)id * d + c, x);
+      if (dWW) atomicAdd(dWW + (size_t)w * d + c, x);
+    }
   }
 }
 

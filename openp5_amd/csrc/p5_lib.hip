@@ -46,6 +46,7 @@ static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING"
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
 static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
 static int g_opt_gemm_ring32 = getenv("P5_GEMM_RING32") ? atoi(getenv("P5_GEMM_RING32")) : 128;   // 32x64 ring tiles for problems of at most this many 64x64 tiles (0 = off)
+static int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")) : 1;   // whole-(batch, head) attention forward (bf16, L <= 128)
 static int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
 static int g_opt_gemm_small_ring_tiles = getenv("P5_GEMM_SMALL_RING_TILES") ? atoi(getenv("P5_GEMM_SMALL_RING_TILES")) : 256;   // ... up to this many 64x64 tiles
 static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
@@ -193,6 +194,14 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
 template <class T>
 static int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) {
   P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  if constexpr (sizeof(T) == 2) {
+    // one workgroup per (batch, head): K and V fetched once, every load up front, one barrier (p5_attn.h)
+    if (g_opt_attn_fwd_wg && a.Lq <= 128 && a.Lk <= 128) {
+      if (a.Lq > 64) P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 8>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      return P5_KCHECK();
+    }
+  }
   dim3 grid((a.Lq + 63) / 64, a.B * a.H), block(256);
   if (a.Lk <= 64) P5_LAUNCH((p5_attn_fwd_kernel<T, 4>), grid, block, 0, s, a);
   else if (a.Lk <= 128) P5_LAUNCH((p5_attn_fwd_kernel<T, 8>), grid, block, 0, s, a);
@@ -1442,6 +1451,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_small_ring")) g_opt_gemm_small_ring = value;
   else if (!strcmp(name, "gemm_small_ring_tiles")) g_opt_gemm_small_ring_tiles = value;
   else if (!strcmp(name, "attn_fused")) g_opt_attn_fused = value;
+  else if (!strcmp(name, "attn_fwd_wg")) g_opt_attn_fwd_wg = value;
   else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else if (!strcmp(name, "decode_v2")) g_opt_decode_v2 = value;

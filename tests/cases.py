@@ -239,6 +239,45 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
     return errs
 
 
+def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6):
+    """bf16 attention forward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_fwd_wg_kernel) against the
+    64-query-block kernel on identical inputs and masks.  Same arithmetic in the same order per row: outputs and lse are equal."""
+    g = torch.Generator().manual_seed(seed)
+    inner = H * 64
+    tt = torch.bfloat16
+    self_attn = mode != "cross"
+    if self_attn:
+        qkv = dev(be, (0.5 * torch.randn(B * Lq, 3 * inner, generator=g)).to(tt))
+        Qd, Kd, Vd, ldq, ldk = qkv, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, 3 * inner
+    else:
+        Qd = dev(be, (0.5 * torch.randn(B * Lq, inner, generator=g)).to(tt))
+        kv = dev(be, (0.5 * torch.randn(B * Lk, 2 * inner, generator=g)).to(tt))
+        Kd, Vd, ldq, ldk = kv, kv[:, inner:], inner, 2 * inner
+    table_d = dev(be, 0.5 * torch.randn(32, H, generator=g)) if self_attn else None
+    lut_half = 512
+    lut_d = dev(be, relative_position_bucket_lut(lut_half, mode == "enc", 32, 128)) if self_attn else None
+    kmask = torch.ones(B, Lk, dtype=torch.long)
+    if mode != "dec":
+        for b in range(B):
+            kmask[b, int(torch.randint(max(1, Lk // 2), Lk + 1, (1,), generator=g)):] = 0
+    km_d = dev(be, kmask) if mode != "dec" else None
+    rng = dev(be, torch.tensor([4321, 3], dtype=torch.int32))
+    res = []
+    for wg in (1, 0):
+        be.check(be.lib.p5_set_option(b"attn_fwd_wg", wg), "set_option")
+        Od = dev(be, torch.zeros(B * Lq, inner, dtype=tt))
+        lse = dev(be, torch.zeros(B * H * Lq))
+        be.check(be.lib.p5_op_attn_fwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk,
+                                       ldk, inner, 1 if mode == "dec" else 0, P(rng), 9, drop_p, be.stream_ptr()), "attn_fwd")
+        sync(be)
+        res.append((Od.cpu().float(), lse.cpu().clone()))
+    be.check(be.lib.p5_set_option(b"attn_fwd_wg", 1), "set_option")
+    (oa, la), (ob, lb) = res
+    assert ob.abs().max() > 0.05
+    assert torch.equal(la, lb), float((la - lb).abs().max())
+    assert torch.equal(oa, ob), float((oa - ob).abs().max())
+
+
 def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
     """bf16 attention backward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_bwd_fused_kernel) against the
     two-kernel path on identical inputs (same forward output, lse and counter-based masks).  Both round P and dS to bf16 at the

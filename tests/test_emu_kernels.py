@@ -87,6 +87,13 @@ def test_attention_bf16_full_block(emu, L):
     cases.attn_case(emu, 1, 1, 2, L, L, "enc")
 
 
+@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 128, 128), ("enc", 70, 70), ("enc", 33, 33), ("dec", 8, 8), ("dec", 24, 24), ("cross", 8, 128),
+                                        ("cross", 17, 70)])
+def test_attention_forward_whole_head_matches_blocked(emu, mode, Lq, Lk):
+    """bf16, dropout on: one workgroup per (batch, head) == the 64-query-block kernel, bit for bit"""
+    cases.attn_fwd_wg_case(emu, 3, 2, Lq, Lk, mode)
+
+
 @pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 50), ("dec", 24)])
 def test_attention_fused_backward_matches_split(emu, mode, L):
     cases.attn_fused_bwd_case(emu, 2, 2, L, mode)

@@ -71,6 +71,13 @@ def test_generate_odd_width(hip, d_model):
     cases.generate_case(hip, cfg, 3, 20, 5, 12, 40, score_tol=1e-4)
 
 
+@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 128, 128), ("enc", 70, 70), ("enc", 33, 33), ("dec", 8, 8), ("dec", 24, 24), ("cross", 8, 128),
+                                        ("cross", 17, 70)])
+def test_attention_forward_whole_head_matches_blocked(hip, mode, Lq, Lk):
+    """bf16, dropout on: one workgroup per (batch, head) == the 64-query-block kernel, bit for bit"""
+    cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode)
+
+
 @pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 120), ("enc", 50), ("dec", 24)])
 def test_attention_fused_backward_matches_split(hip, mode, L):
     """bf16, dropout on: the fused dQ/dK/dV kernel against the two-kernel backward on the same inputs and masks"""
