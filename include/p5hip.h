@@ -151,6 +151,20 @@ int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_i
 int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* aux, int M, int N, int K, int lda, int ldb,
                int ldc, int ldaux, int a_ks, int b_ks, int epi, int c_f32, int splitk, float alpha,
                const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
+/* Persistent ring GEMM (openp5_amd/csrc/p5_gemm4.h), bf16 operands: up to 8 problems C[M,N] (+)= A B^T in ONE launch (the weight
+ * gradients of a layer; nn.Linear autograd, DistributedRunner.py:80).  ks = 0: A [M, lda], B [N, ldb] (reduction dim contiguous);
+ * ks = 1: A [K, lda], B [K, ldb] (reduction dim strided: dW = dy^T x).  epi as p5_op_gemm (0 store, 1 relu(+dropout), 2 residual +
+ * dropout, 3 mask by aux > 0, 4 fp32 atomic add, 6 fp32 C += without split-K).  tile_cfg 0 = 128x128, 1 = 256x128, 2 = 128x256.
+ * rowss / ssq_out: optional T5LayerNorm statistics carried through the epilogue (row sum of squares in, sum of squares of the stored
+ * row out), NULL = off.  `probs` is a HOST array. */
+typedef struct P5GemmProblem {
+  const void *A, *B; void* C; const void* aux;
+  int M, N, K, lda, ldb, ldc, ldaux, epi, c_f32, splitk;
+  float alpha;
+  const float* rowss; float rowss_eps; float* ssq_out;
+} P5GemmProblem;
+int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,
+                     void* stream);
 int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream);
 int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
                       const float* rstd, const float* dres_in, int rows, int d,

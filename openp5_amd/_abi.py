@@ -15,6 +15,11 @@ class P5Config(C.Structure):
     ]
 
 
+class P5GemmProblem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("aux", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
+                ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp)]
+
+
 # name -> (restype, argtypes)
 PROTOTYPES = {
     "p5_last_error": (C.c_char_p, []),
@@ -53,6 +58,7 @@ PROTOTYPES = {
     "p5_decode_finish": (i32, [vp, vp, vp, vp, vp]),
     "p5_encode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i64, vp]),
     "p5_op_gemm": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, u32, f32, vp]),
+    "p5_op_gemm_group": (i32, [i32, i32, i32, C.POINTER(P5GemmProblem), vp, u32, f32, vp]),
     "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),
     "p5_op_rmsnorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "p5_op_attn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u32, f32, vp]),

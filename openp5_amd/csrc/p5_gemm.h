@@ -50,6 +50,7 @@ struct P5GemmArgs {
   float* ssq_out;       // [M] or nullptr: += sum of squares of the stored C row (as rounded to the C dtype)
   float alpha;
   P5Drop drop;
+  int g4_tiles_n, g4_nk;   // p5_gemm4.h launcher-internal: tiles along N, K-steps (of 64) per work unit
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets

@@ -15,6 +15,7 @@
 #include "p5_device.h"
 #include "p5_rng.h"
 #include "p5_gemm.h"
+#include "p5_gemm4.h"
 #include "p5_attn.h"
 #include "p5_elem.h"
 #include "p5_decode.h"
@@ -189,6 +190,49 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     }
   }
   return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
+}
+
+// ---- persistent ring GEMM (p5_gemm4.h): one launch over a group of problems, bf16 operands, K % (64 * splitk) == 0 ----
+static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 5;          // ring depth of the 128x128 configuration
+static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
+enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2 };
+template <int BM, int BN, int WMW, int WNW, int NST, bool KS>
+static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
+  int units = 0;
+  for (int i = 0; i < grp.nprob; ++i) {
+    P5GemmArgs& g = grp.p[i];
+    if (g.splitk < 1) g.splitk = 1;
+    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm4: K must be a multiple of 64 x split-K");
+    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm4: operand alignment");
+    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm4: split-K needs the atomic epilogue");
+    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm4: accumulate epilogues need fp32 C");
+    if (KS) P5_REQUIRE(g.c_f32 || true, "gemm4");
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    g.g4_tiles_n = tn;
+    g.g4_nk = g.K / 64 / g.splitk;
+    grp.unit_begin[i] = units;
+    units += tm * tn * g.splitk;
+  }
+  grp.unit_begin[grp.nprob] = units;
+  grp.total_units = units;
+  int nwg = ((units + 7) / 8) * 8;
+  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
+  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
+  return P5_KCHECK();
+}
+static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
+  P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
+  if (ks) {
+    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 tiles");
+    if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
+    if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
+    return launch_gemm4_cfg<128, 128, 2, 2, 5, true>(grp, s);
+  }
+  if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, false>(grp, s);
+  if (cfg == P5_G4_128x256) return launch_gemm4_cfg<128, 256, 2, 4, 3, false>(grp, s);
+  if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, false>(grp, s);
+  if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, false>(grp, s);
+  return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
 }
 
 template <class T>
@@ -1462,6 +1506,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_cross")) g_opt_dec_cross = value;
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
+  else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
+  else if (!strcmp(name, "g4_wgs")) g_opt_g4_wgs = value;
   else return fail("p5_set_option: unknown option");
   return 0;
 }
@@ -1732,6 +1778,21 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
   g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
   g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr;
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
+}
+int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,
+                     void* stream) {
+  P5_REQUIRE(nprob >= 1 && nprob <= P5_MAX_GROUP && probs, "gemm_group: 1..8 problems");
+  P5GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.nprob = nprob;
+  for (int i = 0; i < nprob; ++i) {
+    const P5GemmProblem& q = probs[i];
+    P5GemmArgs& g = grp.p[i];
+    g.A = q.A; g.B = q.B; g.C = q.C; g.aux = q.aux; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldaux = q.ldaux;
+    g.a_ks = ks; g.b_ks = ks; g.epi = q.epi; g.c_f32 = q.c_f32; g.splitk = q.splitk; g.alpha = q.alpha; g.drop = op_drop(rng_state, site, drop_p);
+    g.rowss = q.rowss; g.rowss_invd = q.rowss ? 1.0f / (float)q.K : 0.f; g.rowss_eps = q.rowss_eps; g.ssq_out = q.ssq_out;
+  }
+  return launch_gemm4(tile_cfg, ks != 0, grp, (hipStream_t)stream);
 }
 int p5_op_rmsnorm_fwd(int dtype, void* y, float* rstd, const void* x, const float* w, int rows, int d, float eps, void* stream) {
   return dtype == 1 ? rmsnorm_fwd<bf16>((hipStream_t)stream, y, rstd, x, w, rows, d, eps, no_drop())

@@ -10,6 +10,7 @@ Differences, all deliberate:
   * the trie constraint runs on the device (the model recognises our and the reference's prefix_allowed_tokens_fn).
 """
 import logging
+import math
 import time
 
 import numpy as np
@@ -96,7 +97,7 @@ def training_step(model, optimizer, batch, alpha=2, micro=0, accum=1):
     input_ids, whole_ids, attn, output_ids, output_attention = batch[:5]
     fused = getattr(model, "loss_and_backward", None)
     last = micro == accum - 1
-    if accum > 1 and fused is not None:
+    if fused is not None and hasattr(model, "begin_micro_batch"):
         model.begin_micro_batch(first=micro == 0, sync=last)
     if fused is not None:
         loss = fused(input_ids, whole_ids, attn, output_ids, output_attention)
@@ -184,7 +185,8 @@ class DistributedRunner:
     # ------------------------------------------------------------------ setup
     def create_optimizer_and_scheduler(self):
         batch_per_epoch = len(self.train_loader)
-        total_steps = batch_per_epoch // self.args.gradient_accumulation_steps * self.args.epochs
+        # one optimizer step per group of `accum` batches, the trailing (shorter) group of an epoch included
+        total_steps = math.ceil(batch_per_epoch / max(1, self.args.gradient_accumulation_steps)) * self.args.epochs
         warmup_steps = int(total_steps * self.args.warmup_prop)
         if self.rank == 0:
             logging.info(f"Batch per epoch: {batch_per_epoch}; total steps: {total_steps}; warm up steps: {warmup_steps}")
@@ -217,28 +219,45 @@ class DistributedRunner:
         cumulative shuffle (MultiTaskDataset.py:189-195): restoring it and replaying the epoch's setup reproduces the batch
         stream exactly, so a mid-epoch resume only has to skip the batches already consumed."""
         import random
-        state = {"py_random": random.getstate(), "np_random": np.random.get_state(), "torch_rng": torch.get_rng_state()}
+        # (plain containers + tensors only, so that the resume file loads with torch.load(weights_only=True))
+        pv, pk, pg = random.getstate()
+        nn, nk, npos, nhas, ncached = np.random.get_state()
+        state = {"py_random": [int(pv), [int(x) for x in pk], pg], "np_random": [str(nn), torch.from_numpy(nk.astype(np.int64)), int(npos), int(nhas), float(ncached)],
+                 "torch_rng": torch.get_rng_state()}
         if self.train_loader is not None:
             state["task_data"] = [{t: list(v) for t, v in ds.task_data.items()} for ds in self.train_loader.dataset.datasets]
         return state
 
     def _restore_epoch_start(self, state):
         import random
-        random.setstate(state["py_random"])
-        np.random.set_state(state["np_random"])
+        pv, pk, pg = state["py_random"]
+        random.setstate((pv, tuple(pk), pg))
+        nn, nk, npos, nhas, ncached = state["np_random"]
+        np.random.set_state((nn, nk.numpy().astype(np.uint32), npos, nhas, ncached))
         torch.set_rng_state(state["torch_rng"])
         for ds, td in zip(self.train_loader.dataset.datasets, state.get("task_data", [])):
             ds.task_data = {t: list(v) for t, v in td.items()}
 
     def save_checkpoint(self, path, epoch, step_in_epoch, epoch_start, extra=None):
         """Weights (HF key layout, as utils.save_model) + optimizer moments / step / schedule position + epoch, step inside
-        the epoch, dropout counter and the epoch-start data state.  Written by rank 0 (all ranks hold identical state)."""
+        the epoch, dropout counter and the epoch-start data state.  Written by rank 0: parameters and optimizer state are
+        identical on every rank (all-reduced gradients, deterministic clip factor), the Python / NumPy / torch RNG states that
+        drive the data order are identical by construction (every rank seeds them alike and draws the same sequence; the
+        samplers shard AFTER shuffling, DistMultiDataTaskSampler.py:30-33).  The dropout counter is the one piece of state a
+        launcher may seed per rank (bench.py, tests/test_gpu_ddp.py do): it is gathered from all ranks and restored per rank."""
+        rng = [int(x) for x in getattr(self.model, "_rng_cpu", [0, 0])]
+        rng_ranks = [rng]
+        if self.world > 1:
+            t = torch.tensor(rng, dtype=torch.int64, device=self.device)
+            parts = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t)
+            rng_ranks = [[int(v) for v in p.tolist()] for p in parts]
         if self.rank != 0:
             return
         ck = {"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
               "optimizer": {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
               "epoch": int(epoch), "step_in_epoch": int(step_in_epoch), "epoch_start": epoch_start,
-              "dropout_rng": list(getattr(self.model, "_rng_cpu", [0, 0])), "world": self.world}
+              "dropout_rng": rng, "dropout_rng_ranks": rng_ranks, "world": self.world}
         ck.update(extra or {})
         tmp = str(path) + ".tmp"
         torch.save(ck, tmp)
@@ -246,11 +265,12 @@ class DistributedRunner:
         os.replace(tmp, path)
 
     def load_checkpoint(self, path):
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        ck = torch.load(path, map_location="cpu", weights_only=True)     # tensors and plain containers only: nothing is unpickled
         self.model.load_state_dict(ck["model"], strict=False)
         self.optimizer.load_state_dict(ck["optimizer"])
         if hasattr(self.model, "set_dropout_seed"):
-            self.model.set_dropout_seed(*ck["dropout_rng"])
+            ranks = ck.get("dropout_rng_ranks") or [ck["dropout_rng"]]
+            self.model.set_dropout_seed(*(ranks[self.rank] if self.rank < len(ranks) and ck.get("world") == self.world else ck["dropout_rng"]))
         return ck
 
     # ------------------------------------------------------------------ training
@@ -262,9 +282,11 @@ class DistributedRunner:
         resume = int(getattr(self.args, "resume", 0)) > 0
         save_steps = int(getattr(self.args, "save_steps", 0))
         start_epoch, skip_batches, pending_start = 0, 0, None
+        carry_sum, carry_cnt = 0.0, 0          # loss of the batches of a resumed epoch that ran before the checkpoint was written
         if resume and os.path.exists(self._resume_path()):
             ck = self.load_checkpoint(self._resume_path())
             start_epoch, skip_batches, pending_start = ck["epoch"], ck["step_in_epoch"], ck["epoch_start"]
+            carry_sum, carry_cnt = float(ck.get("loss_sum", 0.0)), int(ck.get("loss_cnt", 0))
             train_losses, valid_losses, best_epoch = ck.get("train_losses", []), ck.get("valid_losses", []), ck.get("best_epoch", -1)
             if self.rank == 0:
                 logging.info(f"Resume from {self._resume_path()}: epoch {start_epoch + 1}, batch {skip_batches}, optimizer step {self.optimizer.t}")
@@ -286,29 +308,36 @@ class DistributedRunner:
                 self.train_loader.sampler.set_epoch(epoch)
             self.model.train()
             losses, n_samples, n_batches = [], 0, 0
+            n_total = len(self.train_loader)
             t0 = time.perf_counter()
             for batch in Prefetcher(self.train_loader, pin=torch.cuda.is_available()):
                 n_batches += 1
                 if n_batches <= skip_batches:         # already consumed before the checkpoint was written
                     continue
                 input_ids, attn, whole_ids, output_ids, output_attention = self._to_dev(batch)[:5]
-                micro = (n_batches - 1) % accum
+                # groups of `accum` batches; the LAST group of the epoch may be shorter -- its last batch is still the one that
+                # exchanges gradients across ranks and steps (on the mean over the group's actual size), so every rank applies the
+                # same update (a partial group stepped on rank-local sums would let the replicas drift apart for good)
+                g0 = (n_batches - 1) // accum * accum
+                gsize = min(accum, n_total - g0)
+                micro = n_batches - 1 - g0
                 loss = training_step(self.model, self.optimizer, (input_ids, whole_ids, attn, output_ids, output_attention), self.args.alpha,
-                                     micro=micro, accum=accum)
+                                     micro=micro, accum=gsize)
                 losses.append(loss)
                 n_samples += input_ids.shape[0]
-                if resume and save_steps > 0 and micro == accum - 1 and self.optimizer.t % save_steps == 0:
+                if resume and save_steps > 0 and micro == gsize - 1 and self.optimizer.t % save_steps == 0:
                     self.save_checkpoint(self._resume_path(), epoch, n_batches, epoch_start,
-                                         {"train_losses": train_losses, "valid_losses": valid_losses, "best_epoch": best_epoch})
+                                         {"train_losses": train_losses, "valid_losses": valid_losses, "best_epoch": best_epoch,
+                                          "loss_sum": carry_sum + float(torch.stack(losses).sum()), "loss_cnt": carry_cnt + len(losses)})
             skip_batches = 0
-            if n_batches % accum:                    # a trailing partial group: step on what was accumulated
-                self.optimizer.step(grad_accum=n_batches % accum)
-                self.model.zero_grad()
+            assert n_batches == n_total, (n_batches, n_total)
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             self.samples_per_sec = self.world * n_samples / max(dt, 1e-9)
-            epoch_loss = torch.stack(losses).mean() if losses else torch.zeros((), device=self.device)
+            epoch_loss = ((torch.stack(losses).sum() + carry_sum) / (len(losses) + carry_cnt) if losses
+                          else torch.full((), carry_sum / max(1, carry_cnt), device=self.device))
+            carry_sum, carry_cnt = 0.0, 0
             if self.world > 1:
                 dist.all_reduce(epoch_loss, op=dist.ReduceOp.SUM)
                 epoch_loss /= self.world

@@ -104,14 +104,20 @@ class CompiledTrie:
         """Number of tokens of the longest root-to-leaf path (including the decoder start token): no hypothesis of a search
         constrained by this trie is longer, which bounds the number of decode steps worth enqueuing."""
         if self._max_depth is None:
-            depth = np.zeros(self.n_nodes, dtype=np.int32)
-            # children always carry larger node ids than their parent (breadth-first numbering), so one forward sweep suffices
-            counts = np.diff(self.child_off)
-            parents = np.repeat(np.arange(self.n_nodes, dtype=np.int64), counts)
-            order = np.argsort(self.child_node[:len(parents)], kind="stable")
-            for e in order:
-                depth[self.child_node[e]] = depth[parents[e]] + 1
-            self._max_depth = int(depth.max()) if self.n_nodes > 0 else 0
+            # level-by-level frontier expansion from the root (node 0): no assumption about how the nodes are numbered, and one
+            # vectorised gather per trie level instead of a Python loop over every edge
+            depth, frontier = 0, np.zeros(1, dtype=np.int64)
+            off = self.child_off.astype(np.int64)
+            while self.n_nodes > 0 and frontier.size:
+                lo, cnt = off[frontier], off[frontier + 1] - off[frontier]
+                total = int(cnt.sum())
+                if total == 0:
+                    break
+                starts = np.repeat(lo - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt)
+                frontier = self.child_node[starts + np.arange(total, dtype=np.int64)].astype(np.int64)
+                depth += 1
+                assert depth <= self.n_nodes, "CompiledTrie: the child table has a cycle"
+            self._max_depth = depth
         return self._max_depth
 
     @staticmethod

@@ -22,7 +22,7 @@ What it restates (plain torch ops on CPU, fp32 or fp64, no HuggingFace import):
 Pinning: the reference repository ships NO tests / golden vectors for this path,
 and its own model file does not import under the installed transformers.  The restatement is therefore
 pinned against stock HF-5.15 T5ForConditionalGeneration run in this container
-(tests/test_oracle_vs_hf.py, fixtures made by tests/golden/make_golden.py) -- i.e. against outputs of
+(tests/test_oracle.py::test_oracle_vs_hf_live, fixtures made by tests/golden/make_golden.py) -- i.e. against outputs of
 the third-party dependency that holds the arithmetic, not against reference-owned vectors.
 """
 from __future__ import annotations
@@ -177,7 +177,7 @@ def dropout_keep_mask(seed: int, site: int, numel: int, p: float) -> Tensor:
 
 
 class DropoutPlan:
-    """Site numbering shared with the engine (openp5_amd/csrc/p5_engine.hip `site_id`)."""
+    """Site numbering shared with the engine (openp5_amd/csrc/p5_rng.h `p5_site_id`)."""
 
     def __init__(self, seed: int, p: float):
         self.seed, self.p = seed, p

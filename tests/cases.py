@@ -76,6 +76,72 @@ def gemm_case(be, dtype, M, N, K, a_ks, b_ks, epi=0, c_f32=0, splitk=1, seed=0):
     return err
 
 
+def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0):
+    """persistent ring GEMM (p5_gemm4.h): a GROUP of bf16 problems in one launch.  probs: list of (M, N, K, epi, c_f32, splitk).
+    Every epilogue against plain torch; accumulate epilogues (4 atomic, 6 C +=) start from a random C."""
+    from openp5_amd._abi import P5GemmProblem
+    g = torch.Generator().manual_seed(seed)
+    tt = torch.bfloat16
+    arr = (P5GemmProblem * len(probs))()
+    keep, checks = [], []
+    rng = dev(be, torch.tensor([77, 3], dtype=torch.int32)) if drop_p > 0 else None
+    for i, (M, N, K, epi, c_f32, splitk) in enumerate(probs):
+        A = torch.randn(M, K, generator=g).to(tt)
+        Bm = torch.randn(N, K, generator=g).to(tt)
+        ref = A.float() @ Bm.float().t()
+        A_ = A.t().contiguous() if ks else A
+        B_ = Bm.t().contiguous() if ks else Bm
+        aux = None
+        C0 = torch.zeros(M, N, dtype=torch.float32 if c_f32 else tt)
+        alpha = 0.5 if epi in (0, 4, 6) else 1.0
+        ref = ref * alpha
+        if epi in (1, 2) and drop_p > 0:
+            keepm = O.dropout_keep_mask((77 + 3 * 0x632BE5AB) & 0xFFFFFFFF, 5, M * N, drop_p).view(M, N)
+        else:
+            keepm = None
+        if epi == 1:
+            ref = torch.relu(ref)
+            if keepm is not None:
+                ref = torch.where(keepm, ref / (1 - drop_p), torch.zeros_like(ref))
+        elif epi == 2:
+            aux = torch.randn(M, N, generator=g).to(tt)
+            if keepm is not None:
+                ref = torch.where(keepm, ref / (1 - drop_p), torch.zeros_like(ref))
+            ref = ref + aux.float()
+        elif epi == 3:
+            aux = torch.randn(M, N, generator=g).to(tt)
+            ref = torch.where(aux.float() > 0, ref, torch.zeros_like(ref))
+        elif epi in (4, 6):
+            C0 = torch.randn(M, N, generator=g)
+            ref = ref + C0
+        Ad, Bd, Cd = dev(be, A_), dev(be, B_), dev(be, C0)
+        auxd = dev(be, aux) if aux is not None else None
+        keep += [Ad, Bd, Cd, auxd]
+        q = arr[i]
+        q.A, q.B, q.C, q.aux = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), (auxd.data_ptr() if auxd is not None else None)
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux = M, N, K, A_.shape[1], B_.shape[1], N, N
+        q.epi, q.c_f32, q.splitk, q.alpha = epi, c_f32, splitk, alpha
+        q.rowss, q.rowss_eps, q.ssq_out = None, 0.0, None
+        checks.append((Cd, ref, c_f32, K, (M, N, K, epi)))
+    lib = be.lib
+    try:
+        be.check(lib.p5_set_option(b"g4_nst", nst), "opt")
+        be.check(lib.p5_set_option(b"g4_wgs", wgs), "opt")
+        be.check(lib.p5_op_gemm_group(tile_cfg, ks, len(probs), arr, P(rng), 5, drop_p, be.stream_ptr()), "gemm_group")
+        sync(be)
+    finally:
+        lib.p5_set_option(b"g4_nst", 5)
+        lib.p5_set_option(b"g4_wgs", 256)
+    worst = 0.0
+    for Cd, ref, c_f32, K, tag in checks:
+        got = Cd.cpu().float()
+        tol = 1e-3 * max(1.0, K ** 0.5) if c_f32 else 2e-2 * max(1.0, float(ref.abs().max()))
+        err = (got - ref).abs().max().item()
+        assert err <= tol, f"gemm_group cfg={tile_cfg} ks={ks} {tag}: err {err} > {tol}"
+        worst = max(worst, err / tol)
+    return worst
+
+
 def gemm_v2_case(be, stages, M, N, K, epi, tile=128, ks=0):
     lib = be.lib
     try:
@@ -743,24 +809,39 @@ def grad_agreement(m, Pq):
     return rows, whole
 
 
-def bf16_c2_gradient_case(be, B=64, L=128, T=8):
-    """The benchmarked mode at the benchmarked shape (BASELINE.json configs[1]: T5-small, B=64, L=128, T=8, bf16 engine) against
-    the fp32 oracle: per-token NLL, every gradient tensor (relative L2 error + cosine), the whole gradient."""
-    ocfg = O.T5Cfg.named("t5-small", dropout=0.0)
+def bf16_gradient_case(be, ocfg, B, L, T, dropout=0.0, seed=3):
+    """bf16 engine against the fp32 oracle at a given model size / shape: per-token NLL, every gradient tensor (relative L2 error +
+    cosine), the whole gradient.  With dropout > 0 both sides draw the SAME masks (counter-based RNG restated in the oracle)."""
+    ocfg = O.T5Cfg(**{**ocfg.__dict__, "dropout": dropout})
     params = O.init_params(ocfg, 7)
-    ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, 3)
+    ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, seed)
     Pq = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    nll_o = O.p5_forward_nll(Pq, ocfg, ids, ww, mask, labels)
+    dp = O.DropoutPlan((1234 + 1 * 0x632BE5AB) & 0xFFFFFFFF, dropout) if dropout > 0 else None
+    nll_o = O.p5_forward_nll(Pq, ocfg, ids, ww, mask, labels, dp)
     O.runner_loss(nll_o, out_attn).backward()
-    m = build_model(be, ocfg, params, "bf16")
-    m.eval()
+    m = build_model(be, ocfg, params, "bf16", dropout)
+    if dropout > 0:
+        m.train()
+        m.set_dropout_seed(1234, 0)
+    else:
+        m.eval()
     loss = m.loss_and_backward(ids, ww, mask, labels, out_attn)
     sync(be)
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    if dropout > 0:
+        m.set_dropout_seed(1234, 0)       # the same masks for the NLL read-back
     nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"].detach().cpu()
+    for n, p in m.named_parameters():
+        p.grad = grads[n]
     e = (nll - nll_o.detach()).abs()
     rows, whole = grad_agreement(m, Pq)
     return dict(nll_max=float(e.max()), nll_mean=float(e.mean()), loss_err=abs(float(loss) - float(O.runner_loss(nll_o, out_attn))),
                 worst_rel=max(rows), worst_cos=min((r[1], r[2]) for r in rows), whole_rel=whole[0], whole_cos=whole[1])
+
+
+def bf16_c2_gradient_case(be, B=64, L=128, T=8):
+    """The benchmarked mode at the benchmarked shape (BASELINE.json configs[1]: T5-small, B=64, L=128, T=8, bf16 engine)."""
+    return bf16_gradient_case(be, O.T5Cfg.named("t5-small", dropout=0.0), B, L, T)
 
 
 def relu_flip_audit(taps, eps):

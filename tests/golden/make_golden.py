@@ -1,6 +1,6 @@
 """Generates tests/golden/*.pt from STOCK HuggingFace T5 (installed transformers, eager attention, fp32, CPU)
 run in the build container -- the third-party code that holds this path's arithmetic.
-The fixtures pin (a) the restated oracle (tests/test_oracle_vs_hf.py) and (b) the HIP path (-m gpu tests) on the GPU
+The fixtures pin (a) the restated oracle (tests/test_oracle.py) and (b) the HIP path (-m gpu tests) on the GPU
 box, where /root/reference and HF-vs-oracle cross-checks are not assumed.
 NOTE: the installed transformers is 5.15, the reference pins 4.26.0 (src/src_t5/environment_t5.txt:2), whose source is not on
 this box; SURVEY.md 8(c) lists the known behavioural deltas (vectorised beam search, pad fill after </s>).

@@ -44,6 +44,31 @@ def test_gemm_pipelined_loop_wgrad(emu, stages, shape):
     cases.gemm_v2_case(emu, stages, *shape, 4, ks=1)
 
 
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16)])
+def test_gemm_persistent_ring(emu, nst, wgs):
+    """p5_gemm4.h, K-contiguous operands: several problems per launch, more units than workgroups (wgs = 8: every workgroup walks
+    several units, the ring runs across unit boundaries), ragged M / N (row clamp, partial 8-column vectors), K from one K-step
+    (shorter than the ring) to ten, every epilogue incl. dropout masks and split-K atomics."""
+    probs = [(130, 200, 64, 0, 0, 1), (100, 72, 192, 2, 0, 1), (128, 128, 320, 1, 0, 1), (40, 136, 128, 3, 0, 1), (264, 72, 640, 4, 1, 2),
+             (72, 100, 128, 0, 1, 1), (136, 64, 256, 6, 1, 1)]
+    cases.gemm_group_case(emu, 0, 0, probs, nst=nst, wgs=wgs, drop_p=0.1)
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_gemm_persistent_ring_8_waves(emu, cfg):
+    """the 256x128 / 128x256 eight-wave configurations (three-slot ring)."""
+    probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1)]
+    cases.gemm_group_case(emu, cfg, 0, probs, wgs=8)
+
+
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8)])
+def test_gemm_persistent_ring_wgrad(emu, nst, wgs):
+    """p5_gemm4.h, both operands K-strided (weight gradients): grouped, no split-K with C += (epi 6), split-K with atomics (epi 4),
+    plain store; ragged output shapes."""
+    probs = [(136, 200, 128, 6, 1, 1), (128, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (8, 8, 64, 4, 1, 1), (200, 72, 192, 0, 1, 1)]
+    cases.gemm_group_case(emu, 0, 1, probs, nst=nst, wgs=wgs)
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("shape", [(72, 56, 128, 1, 1, 4), (200, 136, 192, 1, 1, 4), (130, 72, 64, 0, 1, 0), (96, 264, 256, 0, 1, 3),
                                    (64, 8, 64, 1, 1, 4), (8, 200, 64, 1, 1, 4)])

@@ -14,8 +14,9 @@ FP32_TIE_TOL = 1e-4   # fp32 engine vs oracle: two items whose oracle scores dif
                       # generation tests (1e-4) may swap places (measured: 2 of 240 users, score gaps <= 1.2e-5)
 BF16_SCORE_TOL = 0.03   # bf16 engine: ceiling on the largest |score - oracle score| of an item both list (measured 0.003 .. 0.016,
                         # depending on the weights the few training epochs produce)
-TIE_SCALE = 4.0         # decision margin of the ORACLE below which the bf16 engine may decide differently = TIE_SCALE x the score
-                        # error MEASURED in this run (an error of d per score can flip decisions with margin <= 2d; 2x head room)
+TIE_TOL = 2.0 * BF16_SCORE_TOL   # FIXED decision margin of the ORACLE below which the bf16 engine may decide differently: score errors
+                                 # below BF16_SCORE_TOL per score can flip decisions whose margin is at most twice that.  (Round 2
+                                 # scaled this with the error measured in the same run, so a regression widened its own excuse.)
 
 
 def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
@@ -36,7 +37,6 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     r_or = cases.collect_rankings(runner, cases.oracle_gen_fn({k: sd[k] for k in O.param_shapes(ocfg)}, ocfg, margins), K)
     m_bf16, m_fp32, m_or = cases.rankings_metrics(r_bf16), cases.rankings_metrics(r_fp32), cases.rankings_metrics(r_or)
     c32 = cases.compare_rankings(r_fp32, r_or, tie_tol=FP32_TIE_TOL)
-    TIE_TOL = TIE_SCALE * cases.compare_rankings(r_bf16, r_or, tie_tol=0.0)["max_score_diff"]
     c16 = cases.compare_rankings(r_bf16, r_or, tie_tol=TIE_TOL)
     print("[dataset] oracle metrics", m_or)
     print("[dataset] bf16 metrics  ", m_bf16)
@@ -50,11 +50,17 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     assert c32["same_gold_rank"] == c32["users"] and m_fp32 == m_or
     # bf16 engine.  Its scores are within BF16_SCORE_TOL of the oracle's; a beam search is a sequence of discrete decisions, so
     # it must reproduce the oracle exactly wherever the oracle took every decision by a margin larger than TIE_TOL
-    # (= TIE_SCALE x the measured score error) and may differ only where the oracle itself was that close to deciding otherwise:
+    # (fixed: 2 x the score-error ceiling) and may differ only where the oracle itself was that close to deciding otherwise:
     #   * list-robust users   -> identical ranked lists;
     #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
     #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
     assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
+    # what the bf16 mode measures on this 240-user set (round 2: 200-202 identical lists, 238-239 identical gold ranks, Hit@5/10
+    # identical), with some head room, as hard floors:
+    assert c16["identical_lists"] >= 0.80 * c16["users"], c16
+    assert c16["same_gold_rank"] >= 0.98 * c16["users"], c16
+    for mb, mo in zip(m_bf16, m_or):
+        assert mb["hit@5"] == mo["hit@5"] and mb["hit@10"] == mo["hit@10"], (mb, mo)
     rob = cases.robust_users(r_or, margins, TIE_TOL)
     flat_b, flat_o = [u for us in r_bf16 for u in us], [u for us in r_or for u in us]
     n_list = n_metric = n_fragile_moved = 0
@@ -75,7 +81,7 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
           f"{n - n_metric} fragile of which {n_fragile_moved} moved")
     sm = sorted(m[0] for m in margins)
     print(f"[dataset] TIE_TOL {TIE_TOL:.4f}; oracle set-margin quantiles 10/50/90%: {sm[n // 10]:.4f} {sm[n // 2]:.4f} {sm[9 * n // 10]:.4f}")
-    assert n_metric >= 0.05 * n, "the robust population is too small for the assertion to mean anything"
+    assert n_metric >= 0.5 * n, "the robust population is too small for the assertion to mean anything"
     for mb, mo in zip(m_bf16, m_or):      # dataset-level metrics: equal up to the fragile users that moved
         for k in mo:
             assert abs(mb[k] - mo[k]) <= n_fragile_moved / (n / len(m_or)) + 1e-12, (k, mb[k], mo[k])

@@ -104,7 +104,13 @@ def test_model_gated(hip):
 
 
 def test_model_bf16(hip):
-    cases.model_train_case(hip, O.T5Cfg.named("tiny"), 2, 16, 5, "bf16", 0.0, nll_tol=0.08, grad_tol=0.5)
+    """bf16 engine at tiny dims against the fp32 oracle, in the relative-L2 / cosine form of the benchmark-shape gate (round 2
+    compared max-abs errors against a 0.5 tolerance here)."""
+    r = cases.bf16_gradient_case(hip, O.T5Cfg.named("tiny"), 2, 16, 5)
+    print("[bf16 tiny]", r)
+    assert r["nll_max"] <= 0.08 and r["loss_err"] <= 0.03, r
+    assert r["worst_rel"][0] <= 0.15 and r["worst_cos"][0] >= 0.99, r
+    assert r["whole_rel"] <= 0.05 and r["whole_cos"] >= 0.999, r
 
 
 def test_model_t5_small_fp32(hip):
@@ -166,14 +172,19 @@ def test_generate_bf16_ranked_set(hip):
                      num_beams=10, num_return_sequences=10, output_scores=True, return_dict_in_generate=True)
     with torch.no_grad():
         s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), 10, 12)
-    seq = out["sequences"].cpu()
-    same = 0
+    seq, sc = out["sequences"].cpu(), out["sequences_scores"].cpu()
+    same, worst = 0, 0.0
     for b in range(8):
-        a = {tuple(t for t in r.tolist() if t > 1) for r in seq[b * 10:(b + 1) * 10]}
-        r_ = {tuple(t for t in r.tolist() if t > 1) for r in s_ref[b * 10:(b + 1) * 10]}
-        same += len(a & r_)
+        a = {tuple(t for t in r.tolist() if t > 1): float(sc[b * 10 + j]) for j, r in enumerate(seq[b * 10:(b + 1) * 10])}
+        r_ = {tuple(t for t in r.tolist() if t > 1): float(sc_ref[b * 10 + j]) for j, r in enumerate(s_ref[b * 10:(b + 1) * 10])}
+        common = set(a) & set(r_)
+        same += len(common)
+        worst = max([worst] + [abs(a[k] - r_[k]) for k in common])
+    print(f"[bf16 generate] {same}/80 top-10 items shared with the fp32 oracle, largest score error on a shared item {worst:.4f}")
+    # the score of every item both searches return agrees within the bf16 score tolerance of the dataset-level gate
+    # (tests/test_gpu_dataset.py::BF16_SCORE_TOL); items may only enter / leave the top-10 at its (near-tied) boundary
+    assert worst <= 0.03, worst
     assert same >= 72, f"only {same}/80 top-10 items agree between bf16 and the fp32 oracle"
-    assert (out["sequences_scores"].cpu() - sc_ref).abs().max() < 0.3
 
 
 @pytest.mark.parametrize("B,L,T", [(1, 1, 1), (2, 5, 1), (1, 3, 9), (1, 512, 16), (3, 300, 33)])
@@ -247,18 +258,67 @@ def test_generate_base_beam20_collaborative_vocab(hip):
     cases.compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, 2e-4)
 
 
-def test_bf16_large_L512_runs(hip):
-    """configs[4] shape in fast mode: T5-large dims at L = 512 (finite loss and gradients; parity is covered in fp32)."""
-    import torch
-    cfg = O.T5Cfg.named("t5-large", num_layers=2, num_decoder_layers=2, dropout=0.1)
-    m = cases.build_model(hip, cfg, O.init_params(cfg, 5), "bf16", dropout=0.1)
-    m.train()
-    ids, ww, mask, labels, out_attn = cases.synth_batch(cfg, 4, 512, 10, 3)
-    nll = m(input_ids=ids, whole_word_ids=ww, attention_mask=mask, labels=labels)["loss"]
-    loss = O.runner_loss(nll, out_attn.to(nll.device))
-    loss.backward()
-    torch.cuda.synchronize()
-    assert torch.isfinite(nll).all() and torch.isfinite(m._grads).all() and float(m._grads.abs().max()) > 0
+def test_bf16_gradients_t5_base_full_depth(hip):
+    """The mode behind bench.py's C3 leg (BASELINE.json configs[2]: T5-base, L=128, bf16 engine) at FULL depth 12+12 against the fp32
+    oracle: per-token NLL, relative L2 error and cosine of every gradient tensor and of the whole gradient.  Bounds ~2x the values
+    measured on MI355X (printed)."""
+    r = cases.bf16_gradient_case(hip, O.T5Cfg.named("t5-base"), 8, 128, 8)
+    print("[bf16 t5-base 12+12]", r)
+    assert r["nll_max"] <= 0.15 and r["nll_mean"] <= 0.04 and r["loss_err"] <= 0.04, r
+    assert r["worst_rel"][0] <= 0.25 and r["worst_cos"][0] >= 0.97, r
+    assert r["whole_rel"] <= 0.06 and r["whole_cos"] >= 0.998, r
+
+
+def test_bf16_gradients_t5_large_L512(hip):
+    """The mode behind bench.py's C5 leg (BASELINE.json configs[4]: T5-large dims, L=512, bf16 engine), two layers per stack,
+    against the fp32 oracle (round 2 only checked that loss and gradients were finite)."""
+    cfg = O.T5Cfg.named("t5-large", num_layers=2, num_decoder_layers=2)
+    r = cases.bf16_gradient_case(hip, cfg, 4, 512, 10)
+    print("[bf16 t5-large 2+2 L=512]", r)
+    assert r["nll_max"] <= 0.15 and r["nll_mean"] <= 0.04 and r["loss_err"] <= 0.04, r
+    assert r["worst_rel"][0] <= 0.25 and r["worst_cos"][0] >= 0.97, r
+    assert r["whole_rel"] <= 0.06 and r["whole_cos"] >= 0.998, r
+
+
+def test_bf16_gradients_dropout_on(hip):
+    """bf16 engine WITH dropout (the benchmarked configuration trains with p = 0.1) against the fp32 oracle drawing the same
+    masks (counter-based RNG, oracle/t5_oracle.py::dropout_keep_mask), T5-small dims."""
+    r = cases.bf16_gradient_case(hip, O.T5Cfg.named("t5-small"), 16, 128, 8, dropout=0.1)
+    print("[bf16 t5-small dropout 0.1]", r)
+    assert r["nll_max"] <= 0.1 and r["nll_mean"] <= 0.03 and r["loss_err"] <= 0.03, r
+    assert r["worst_rel"][0] <= 0.15 and r["worst_cos"][0] >= 0.99, r
+    assert r["whole_rel"] <= 0.04 and r["whole_cos"] >= 0.999, r
+
+
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16)])
+def test_gemm_persistent_ring(hip, nst, wgs):
+    """p5_gemm4.h on the hardware (direct-to-LDS ring with counted vmcnt across work units, permuted-row fragments, swapped MFMA
+    operands, register epilogue): same grouped cases as the host-emulation suite, every epilogue incl. dropout and split-K."""
+    probs = [(130, 200, 64, 0, 0, 1), (100, 72, 192, 2, 0, 1), (128, 128, 320, 1, 0, 1), (40, 136, 128, 3, 0, 1), (264, 72, 640, 4, 1, 2),
+             (72, 100, 128, 0, 1, 1), (136, 64, 256, 6, 1, 1)]
+    for rep in range(3):          # (a mis-counted wait shows up as a sporadic mismatch)
+        cases.gemm_group_case(hip, 0, 0, probs, nst=nst, wgs=wgs, drop_p=0.1, seed=rep)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_gemm_persistent_ring_step_shapes(hip, cfg):
+    """the shapes of the benchmark step (8192 token rows; N, K in {512, 1536, 2048}), several units per workgroup."""
+    for rep in range(2):
+        cases.gemm_group_case(hip, cfg, 0, [(8192, 2048, 512, 1, 0, 1)], drop_p=0.1, seed=rep)
+        cases.gemm_group_case(hip, cfg, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], drop_p=0.1, seed=rep)
+
+
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8)])
+def test_gemm_persistent_ring_wgrad(hip, nst, wgs):
+    probs = [(136, 200, 128, 6, 1, 1), (128, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (8, 8, 64, 4, 1, 1), (200, 72, 192, 0, 1, 1)]
+    for rep in range(3):
+        cases.gemm_group_case(hip, 0, 1, probs, nst=nst, wgs=wgs, seed=rep)
+
+
+def test_gemm_persistent_ring_wgrad_layer_group(hip):
+    """the four weight gradients of one T5-small encoder layer over 8192 tokens as ONE launch, no split-K, C += acc."""
+    probs = [(512, 2048, 8192, 6, 1, 1), (2048, 512, 8192, 6, 1, 1), (512, 512, 8192, 6, 1, 1), (1536, 512, 8192, 6, 1, 1)]
+    cases.gemm_group_case(hip, 0, 1, probs)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

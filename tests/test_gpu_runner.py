@@ -89,3 +89,50 @@ def test_filtered_evaluation_on_device(hip, tmp_path):
     for g, r in zip(got, ref):
         for k in r:
             assert abs(g[k] - r[k]) < 1e-12, (got, ref)
+
+
+def test_resume_on_device(hip, tmp_path):
+    """f3 on the device (the reference saves weights only, utils/utils.py:119-129): 2 epochs straight == 1 epoch + resume file + everything
+    rebuilt + `--resume 1` + the 2nd epoch, bf16 engine with dropout on the MI355X -- optimizer m/v/t, schedule position, dropout
+    counter, data order and the bf16 shadow all have to survive the round trip.  fp32 atomics (embedding scatter, relative-bias and
+    tied-head gradients) make two runs of the SAME step differ in the last bits on a GPU, so the comparison is tolerance-based here;
+    the bit-exact version of this test runs on the host emulation (tests/test_runner_emu.py::test_resume_is_exact)."""
+    from tests.test_host import SMALL_TOY
+    from tests.test_runner_emu import VOCAB, tiny_model
+    tok = build_offline_tokenizer(VOCAB)
+
+    def build(epochs, extra=()):
+        args = make_args(str(tmp_path), ["--epochs", str(epochs), "--test_before_train", "0", "--test_epoch", "0", "--batch_size", "8",
+                                         "--sample_num", "1,1", "--max_his", "3", "--lr", "3e-3"] + list(extra), toy=SMALL_TOY)
+        args.model_path = str(tmp_path / "m.pt")
+        random.seed(0)
+        train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
+        loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
+                            collate_fn=Collator(tok))
+        model = tiny_model(hip, len(tok), dropout=0.1, seed=9, dtype="bf16")
+        model.set_dropout_seed(77, 0)
+        return DistributedRunner(model, tok, loader, None, hip.device, args, 0)
+
+    straight = build(2)
+    straight.optimizer.total_steps = 2 * len(straight.train_loader)         # same schedule in all runs
+    l2 = straight.train()
+    again = build(2)                                                        # run-to-run noise floor of the same two epochs
+    again.optimizer.total_steps = straight.optimizer.total_steps
+    again.train()
+    noise = float((again.model._flat - straight.model._flat).abs().max())
+    first = build(1, ["--resume", "1"])
+    first.optimizer.total_steps = straight.optimizer.total_steps
+    first.optimizer.warmup_steps = straight.optimizer.warmup_steps
+    first.train()
+    assert os.path.exists(str(tmp_path / "m.pt") + ".resume")
+    second = build(2, ["--resume", "1"])
+    second.optimizer.total_steps = straight.optimizer.total_steps
+    second.optimizer.warmup_steps = straight.optimizer.warmup_steps
+    l12 = second.train()
+    assert second.optimizer.t == straight.optimizer.t and second.optimizer.sched_steps == straight.optimizer.sched_steps
+    diff = float((second.model._flat - straight.model._flat).abs().max())
+    scale = float(straight.model._flat.abs().max())
+    print(f"[resume] max |param diff| resumed vs straight {diff:.3e} (run-to-run noise of the straight run {noise:.3e}, largest parameter {scale:.3f})")
+    assert diff <= max(10 * noise, 1e-5 * scale), (diff, noise)
+    assert torch.allclose(second.optimizer.m, straight.optimizer.m, atol=max(10 * noise, 1e-6), rtol=1e-3)
+    assert len(l12) == len(l2) and abs(l12[-1] - l2[-1]) <= 1e-3 * abs(l2[-1]) + 1e-4

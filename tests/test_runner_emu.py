@@ -335,15 +335,23 @@ def test_filtered_batch_falls_back_beyond_device_beams(emu, tmp_path, monkeypatc
     assert a == b and all(0.0 <= v <= 1.0 for res in a for v in res.values())
 
 
-def _world2_runner_worker(rank, world, port, tmp, _):
+def _world2_runner_worker(rank, world, port, tmp, which):
+    """which = None: host-emulated kernels on CPU tensors; "hip": the product library, both ranks sharing cuda:0 (tests/test_gpu_ddp.py)"""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tests.emu.emu_backend import emu_backend
-    be = emu_backend()
+    extra_flags = []
+    if isinstance(which, (list, tuple)):
+        which, extra_flags = which[0], list(which[1])
+    if which == "hip":
+        from openp5_amd._lib import hip_backend
+        be = hip_backend(torch.device("cuda:0"))
+    else:
+        from tests.emu.emu_backend import emu_backend
+        be = emu_backend()
     tok = build_offline_tokenizer(VOCAB)
     args = make_args(os.path.join(tmp, f"r{rank}"), ["--epochs", "1", "--test_before_train", "0", "--test_epoch", "1", "--metrics", "hit@5,ndcg@5",
                                                     "--eval_batch_size", "4", "--batch_size", "4", "--sample_num", "1,1", "--max_his", "3",
-                                                    "--distributed", "1"], toy=SMALL_TOY)
+                                                    "--distributed", "1"] + extra_flags, toy=SMALL_TOY)
     args.rank = rank
     args.model_path = os.path.join(tmp, f"m{rank}.pt")
     random.seed(0)
@@ -351,26 +359,24 @@ def _world2_runner_worker(rank, world, port, tmp, _):
     sampler = DistMultiDataTaskSampler(train, args.batch_size, world, rank, args.seed, shuffle=True)
     loader = DataLoader(train, sampler=sampler, batch_size=args.batch_size, collate_fn=Collator(tok))
     model = tiny_model(be, len(tok), seed=3)
-    runner = DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, rank)
+    runner = DistributedRunner(model, tok, loader, None, be.device, args, rank)
     assert runner.world == 2 and all(l.sampler is not None and l.sampler.num_replicas == 2 for l in runner.testloaders)
     losses = runner.train()                                  # DistMultiDataTaskSampler shards + gradient all-reduce + epoch-loss all-reduce
     res = runner.test()                                      # DistributedSampler over the test users + metric all-reduce
     n_local = [len(list(iter(l.sampler))) for l in runner.testloaders]
-    torch.save({"flat": model._flat.clone(), "res": res, "losses": losses, "n_local": n_local,
+    torch.save({"flat": model._flat.detach().cpu().clone(), "res": res, "losses": losses, "n_local": n_local, "n_batches": len(loader),
+                "opt_t": runner.optimizer.t, "total_steps": runner.optimizer.total_steps,
                 "idx": [list(iter(l.sampler)) for l in runner.testloaders]}, os.path.join(tmp, f"w{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_runner_train_and_test(emu, tmp_path):
-    """a12/a16/e2: `runner.train()` + `runner.test()` with world_size 2 over gloo -- DistMultiDataTaskSampler sharding
-    (DistMultiDataTaskSampler.py:30-33), gradient all-reduce, DistributedSampler evaluation (DistributedRunner.py:186) and the
-    metric all-reduce (:389-395).  Both ranks end with bit-identical parameters and identical (all-reduced) metrics, and the
-    metrics equal a single-process evaluation of the same weights over the union of the two ranks' user shards."""
+def run_world2_runner_check(be, tmp_path, which):
+    """spawn two ranks of `_world2_runner_worker`, then verify their results against a single process on backend `be`"""
     world, port = 2, 31000 + random.randint(0, 2000)
     for r in range(world):
         os.makedirs(tmp_path / f"r{r}", exist_ok=True)
-    mp.spawn(_world2_runner_worker, args=(world, port, str(tmp_path), None), nprocs=world, join=True)
+    mp.spawn(_world2_runner_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True)
     w0, w1 = torch.load(tmp_path / "w0.pt", weights_only=False), torch.load(tmp_path / "w1.pt", weights_only=False)
     assert torch.equal(w0["flat"], w1["flat"]), "ranks diverged during runner.train()"
     assert w0["res"] == w1["res"] and len(w0["res"]) == 2
@@ -387,11 +393,11 @@ def test_world2_runner_train_and_test(emu, tmp_path):
     train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
     loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
                         collate_fn=Collator(tok))
-    model = tiny_model(emu, len(tok), seed=3)
+    model = tiny_model(be, len(tok), seed=3)
     with torch.no_grad():
-        model._flat.copy_(w0["flat"])
+        model._flat.copy_(w0["flat"].to(model._flat.device))
     model.mark_params_updated()
-    single = DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, 0)
+    single = DistributedRunner(model, tok, loader, None, be.device, args, 0)
     from torch.utils.data import Subset
     for li, tl in enumerate(single.testloaders):
         sums, n = 0, 0
@@ -401,12 +407,35 @@ def test_world2_runner_train_and_test(emu, tmp_path):
             trie, ct, _ = single._dataset_trie(ds)
             from openp5_amd import evaluate
             for batch in sub:
-                rel = single._generate_ids(batch, single.generate_num, 50, trie=ct)
+                rel = single._generate_ids(single._to_dev(batch), single.generate_num, 50, trie=ct)
                 sums = sums + evaluate.get_metrics_results_ids(rel, single.metrics)
                 n += len(rel)
-        want = (torch.as_tensor(sums, dtype=torch.float64) / n).tolist()
+        want = (torch.as_tensor(sums, dtype=torch.float64).cpu() / n).tolist()
         got = [w0["res"][li][m] for m in single.metrics]
         assert got == pytest.approx(want, abs=1e-12), (li, got, want)
+
+
+def test_world2_runner_train_and_test(emu, tmp_path):
+    """a12/a16/e2: `runner.train()` + `runner.test()` with world_size 2 over gloo -- DistMultiDataTaskSampler sharding
+    (DistMultiDataTaskSampler.py:30-33), gradient all-reduce, DistributedSampler evaluation (DistributedRunner.py:186) and the
+    metric all-reduce (:389-395).  Both ranks end with bit-identical parameters and identical (all-reduced) metrics, and the
+    metrics equal a single-process evaluation of the same weights over the union of the two ranks' user shards."""
+    run_world2_runner_check(emu, tmp_path, None)
+
+
+def test_world2_accumulation_trailing_group_stays_in_sync(emu, tmp_path):
+    """--gradient_accumulation_steps 4 with 10 batches per epoch and world_size 2: the epoch's trailing group has two batches; its
+    last batch must still exchange gradients before stepping, so both ranks keep bit-identical parameters (round 2 stepped that
+    group on rank-local sums and the replicas drifted apart), and the linear schedule is sized for ceil(batches / accum) steps."""
+    world, port = 2, 33000 + random.randint(0, 2000)
+    for r in range(world):
+        os.makedirs(tmp_path / f"r{r}", exist_ok=True)
+    mp.spawn(_world2_runner_worker, args=(world, port, str(tmp_path), (None, ["--gradient_accumulation_steps", "4", "--batch_size", "6"])),
+             nprocs=world, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt", weights_only=False), torch.load(tmp_path / "w1.pt", weights_only=False)
+    assert w0["n_batches"] % 4 != 0, "the case needs a trailing partial group"
+    assert w0["opt_t"] == w1["opt_t"] == (w0["n_batches"] + 3) // 4 == w0["total_steps"]
+    assert torch.equal(w0["flat"], w1["flat"]), "ranks diverged on the trailing partial accumulation group"
 
 
 def test_torch_ddp_wrapper_is_inert(emu):
