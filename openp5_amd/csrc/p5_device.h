@@ -186,6 +186,19 @@ __device__ static __forceinline__ void glds16_raw(const void* g, char* lds_wave_
 }
 #endif
 
+// the same copy addressed as SCALAR base + 32-bit per-lane byte offset (the `saddr` form of the instruction): a kernel that issues 16
+// copies per K-step keeps ONE offset register per operand instead of sixteen 64-bit pointers
+#ifdef P5_EMU
+static inline void glds16_raw_s(uint64_t sbase, uint32_t voff, char* lds_wave_base) {
+  memcpy(lds_wave_base + 16 * (int)emu::lane(), (const char*)(uintptr_t)sbase + voff, 16);
+}
+#else
+__device__ static __forceinline__ void glds16_raw_s(uint64_t sbase, uint32_t voff, char* lds_wave_base) {    // sbase: wave-uniform
+  const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)lds_wave_base));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m) : "memory");
+}
+#endif
+
 // 16-byte global load the compiler does NOT track (inline asm): its completion is the caller's business -- P5_WAIT_VM(n) with n =
 // number of vector-memory operations issued after it, then P5_SCHED_FENCE() before the first use.  This is the only way to
 // keep loads in flight across a loop back edge: hipcc's own waitcnt insertion waits for everything older than the current

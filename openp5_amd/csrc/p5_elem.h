@@ -276,6 +276,33 @@ __global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__
   }
 }
 
+// the same for every T5LayerNorm of a backward stage in ONE launch: slot z = blockIdx.z reduces its partial rows into its weight's
+// gradient (32 launches per T5-small step -> 14)
+struct P5ReduceMulti {
+  int n, d;
+  int nrows[4];
+  long long dst_off[4], part_off[4];    // element offsets into the gradient arena / the partial-sum scratch
+};
+__global__ __launch_bounds__(256) void p5_reduce_rows_multi_kernel(P5ReduceMulti a, float* __restrict__ G, const float* __restrict__ scratch) {
+  const int z = blockIdx.z;
+  const int nrows = a.nrows[z], d = a.d;
+  float* __restrict__ dst = G + a.dst_off[z];
+  const float* __restrict__ partial = scratch + a.part_off[z];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ float sred[4][64];
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per < nrows) ? b0 + per : nrows;
+  float s = 0.f;
+  if (j < d)
+    for (int b = b0 + part; b < b1; b += 4) s += partial[(size_t)b * d + j];
+  sred[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && j < d) {
+    const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
+    if (v != 0.f) atomicAdd(dst + j, v);
+  }
+}
+
 // dst[i] += sum_c partial[c][i]   (partial copies of the relative-bias gradient)
 __global__ __launch_bounds__(256) void p5_reduce_copies_kernel(float* __restrict__ dst, const float* __restrict__ partial, int n, int copies) {
   const int i = blockIdx.x * 256 + threadIdx.x;

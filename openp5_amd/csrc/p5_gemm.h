@@ -732,6 +732,12 @@ __global__ __launch_bounds__(256) P5_WAVES_PER_SIMD(1, NST >= 3 ? 1 : 2) void p5
     for (; s + 1 < n; ++s) step(P5Bool<true>(), s & 1);
     step(P5Bool<false>(), s & 1);
   }
+  // The trailing copies of the ring (re-fetches of the last K-step into free slots, issued to keep vmcnt a constant) may still be
+  // in flight here -- up to PFD - 1 K-steps of them -- and the LDS-staged epilogue writes the C tile over the first ring slots: a
+  // copy that lands after that corrupts the tile.  Which slots they target depends on the number of K-steps modulo the ring
+  // depth (K = 768 on the eight-slot ring hits slot 0), so the race showed only at some shapes and only under memory load (round 3:
+  // bf16 gradients of shared.weight / the first decoder norm at T5-base depth 12+12).  Drain them first.
+  P5_WAIT_VM(0);
   P5_BARRIER_LDS();     // all fragment reads retired before the epilogue reuses the ring
   gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
 }

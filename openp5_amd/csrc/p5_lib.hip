@@ -92,6 +92,7 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
     return P5_KCHECK();
   }
   if constexpr (sizeof(T) == 2 && BM == 128) {
+    if (mode == 0 && dma && g.ring && v2 == 0) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
     if (mode == 3 && dma && (v2 >= 3 || g.ring)) {
@@ -121,6 +122,53 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   return P5_KCHECK();
 }
 
+// ---- persistent ring GEMM (p5_gemm4.h): one launch over a group of problems, bf16 operands, K % (64 * splitk) == 0 ----
+static int g_opt_gemm_wide = getenv("P5_GEMM_WIDE") ? atoi(getenv("P5_GEMM_WIDE")) : 1;         // 256x128 persistent ring for wide outputs
+static int g_opt_gemm_wide_min_tiles = getenv("P5_GEMM_WIDE_MIN_TILES") ? atoi(getenv("P5_GEMM_WIDE_MIN_TILES")) : 160;
+static int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RING_N512")) : 1;   // ring kernel for N = d_model, K >= 1024
+static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
+static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
+enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2 };
+template <int BM, int BN, int WMW, int WNW, int NST, bool KS>
+static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
+  int units = 0;
+  for (int i = 0; i < grp.nprob; ++i) {
+    P5GemmArgs& g = grp.p[i];
+    if (g.splitk < 1) g.splitk = 1;
+    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm4: K must be a multiple of 64 x split-K");
+    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm4: operand alignment");
+    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm4: split-K needs the atomic epilogue");
+    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm4: accumulate epilogues need fp32 C");
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    g.g4_tiles_n = tn;
+    g.g4_nk = g.K / 64 / g.splitk;
+    grp.unit_begin[i] = units;
+    units += tm * tn * g.splitk;
+  }
+  grp.unit_begin[grp.nprob] = units;
+  grp.total_units = units;
+  int nwg = ((units + 7) / 8) * 8;
+  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
+  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
+  return P5_KCHECK();
+}
+static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
+  P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
+  if (ks) {
+    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 tiles");
+    if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, true>(grp, s);
+    if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
+    if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
+    return launch_gemm4_cfg<128, 128, 2, 2, 5, true>(grp, s);
+  }
+  if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, false>(grp, s);
+  if (cfg == P5_G4_128x256) return launch_gemm4_cfg<128, 256, 2, 4, 3, false>(grp, s);
+  if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, false>(grp, s);
+  if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, false>(grp, s);
+  if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, false>(grp, s);
+  return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
+}
+
 template <class T>
 static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   constexpr int EPF = TT<T>::EPF;
@@ -134,6 +182,27 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
   if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm: accumulate epilogues need fp32 C");
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
   const int force_tile = g_opt_gemm_tile;
+  if constexpr (sizeof(T) == 2) {
+    const bool kc = !g.a_ks && !g.b_ks && (g.K % 64) == 0 && g.splitk <= 1 && (g.lda % 64) == 0 && (g.ldb % 64) == 0 && !force_tile && !g_opt_gemm_v2;
+    // wide outputs: 256x128 tiles, eight waves, persistent three-slot ring (p5_gemm4.h) once there are enough of them to occupy most
+    // CUs -- 0.75 of the L2->LDS bytes per MAC of a 128x128 tile and two waves per SIMD to overlap LDS reads with MFMAs
+    // (tools/lab, round 3: 8192x2048x512 25.3 vs 27.6 us, 8192x3072x768 47 vs 54, 8192x4096x1024 73 vs 87 (128x128) / 125 (256x256
+    // eight-wave two-slot kernel), 8192^2 x 2048 252 vs 382 us)
+    if (kc && g_opt_gemm_wide && (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= g_opt_gemm_wide_min_tiles && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
+      P5GemmGroup grp;
+      memset(&grp, 0, sizeof(grp));
+      grp.nprob = 1;
+      grp.p[0] = g;
+      grp.p[0].splitk = 1;
+      return launch_gemm4(P5_G4_256x128, false, grp, s);
+    }
+    // narrow outputs (N = d_model) with a long reduction: one 128x128 tile per CU on the four-slot ring instead of 64x64 tiles
+    if (kc && g_opt_gemm_ring_n512 && t128 >= 128 && t128 <= 256 && g.K >= 1024 && g.epi != P5_EPI_ATOMIC) {
+      g.ring = 1;
+      g.splitk = 1;
+      return launch_gemm_tile<T, 128, 128>(g, s);
+    }
+  }
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
@@ -190,49 +259,6 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     }
   }
   return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
-}
-
-// ---- persistent ring GEMM (p5_gemm4.h): one launch over a group of problems, bf16 operands, K % (64 * splitk) == 0 ----
-static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 5;          // ring depth of the 128x128 configuration
-static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
-enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2 };
-template <int BM, int BN, int WMW, int WNW, int NST, bool KS>
-static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
-  int units = 0;
-  for (int i = 0; i < grp.nprob; ++i) {
-    P5GemmArgs& g = grp.p[i];
-    if (g.splitk < 1) g.splitk = 1;
-    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm4: K must be a multiple of 64 x split-K");
-    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm4: operand alignment");
-    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm4: split-K needs the atomic epilogue");
-    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm4: accumulate epilogues need fp32 C");
-    if (KS) P5_REQUIRE(g.c_f32 || true, "gemm4");
-    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    g.g4_tiles_n = tn;
-    g.g4_nk = g.K / 64 / g.splitk;
-    grp.unit_begin[i] = units;
-    units += tm * tn * g.splitk;
-  }
-  grp.unit_begin[grp.nprob] = units;
-  grp.total_units = units;
-  int nwg = ((units + 7) / 8) * 8;
-  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
-  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
-  return P5_KCHECK();
-}
-static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
-  P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
-  if (ks) {
-    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 tiles");
-    if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
-    if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
-    return launch_gemm4_cfg<128, 128, 2, 2, 5, true>(grp, s);
-  }
-  if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, false>(grp, s);
-  if (cfg == P5_G4_128x256) return launch_gemm4_cfg<128, 256, 2, 4, 3, false>(grp, s);
-  if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, false>(grp, s);
-  if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, false>(grp, s);
-  return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
 }
 
 template <class T>
@@ -295,6 +321,7 @@ __global__ __launch_bounds__(64) void p5_tr_probe_kernel(unsigned short* out, co
 // =====================================================================================================
 // engine
 // =====================================================================================================
+static constexpr int P5_NSETS = 6;      // >= 2 x (sub-layers of a decoder layer)
 struct ParamInfo { std::string name; int64_t off; int rows, cols; };
 struct AttnOff { int64_t q, k, v, o, ln; };
 struct LayerOff { AttnOff sa, ca; int64_t wi, wo, ff_ln; int64_t begin, end; };
@@ -360,8 +387,12 @@ struct P5Engine {
   void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
   // two sets of the temporaries the wgrad GEMMs read, alternated per sub-layer, so the side stream can run one
   // sub-layer behind the dgrad chain without a write-after-read hazard
-  void *dy2[2] = {nullptr, nullptr}, *dh2[2] = {nullptr, nullptr}, *du2[2] = {nullptr, nullptr}, *dqkv2[2] = {nullptr, nullptr},
-       *dkv2[2] = {nullptr, nullptr};
+  // (P5_NSETS sets: with the weight gradients of a whole layer deferred into ONE grouped launch at the end of the layer's backward --
+  // p5_gemm4.h -- the temporaries of all its sub-layers, and of the next layer's that run meanwhile, must stay intact)
+  void *dy2[P5_NSETS] = {}, *dh2[P5_NSETS] = {}, *du2[P5_NSETS] = {}, *dqkv2[P5_NSETS] = {}, *dkv2[P5_NSETS] = {};
+  P5ReduceMulti nr_pending;               // norm-weight partial sums of the current backward stage, reduced by one launch at its end
+  std::vector<P5GemmArgs> wg_pending;     // deferred weight-gradient problems (bf16, token count a multiple of 64)
+  unsigned wg_sets = 0;                   // bit p: a pending problem reads temporaries of set p
   void* dy_next = nullptr;
   void *kv_all = nullptr, *dkv_all = nullptr;   // cross-attention K/V (and their gradients) of all decoder layers, [M, n_dec*2*inner]
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
@@ -394,17 +425,19 @@ struct P5Engine {
   hipStream_t side = nullptr;
 #ifndef P5_EMU
   hipEvent_t ev_pool[32];
-  hipEvent_t side_done[2];
+  hipEvent_t set_ev[P5_NSETS];            // recorded behind the last weight-gradient launch that reads set p
+  hipEvent_t head_wg_ev;                  // ... behind the tied head's weight gradient (plain "+=" into shared.weight's gradient)
   hipEvent_t kv_ev[64];
-  bool side_done_valid[2] = {false, false};
+  bool set_ev_valid[P5_NSETS] = {};
+  bool head_wg_valid = false;
   int ev_next = 0;
 #endif
 };
 
 static void begin_sublayer(P5Engine* e) {
   e->sub++;
-  const int p = e->sub & 1;
-  e->dy = e->dy2[p]; e->dy_next = e->dy2[1 - p];
+  const int p = e->sub % P5_NSETS, pn = (e->sub + 1) % P5_NSETS;
+  e->dy = e->dy2[p]; e->dy_next = e->dy2[pn];
   e->dh = e->dh2[p]; e->du = e->du2[p]; e->dqkv = e->dqkv2[p]; e->dkv = e->dkv2[p];
 }
 // side stream waits for everything enqueued on `main` so far
@@ -424,14 +457,19 @@ static void join_side(P5Engine* e, hipStream_t main) {
   hipStreamWaitEvent(main, ev, 0);
 #endif
 }
-// called right before the norm backward that ends sub-layer `sub` (and overwrites the other dy set)
+static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head);
+// called right before the norm backward that ends sub-layer `sub`: it writes dy of the NEXT set, and the next sub-layer's data
+// gradients write the rest of that set -- whatever weight-gradient launch still reads it (P5_NSETS sub-layers ago) must be done
 static void end_sublayer_sync(P5Engine* e, hipStream_t main) {
+  if ((e->wg_sets >> ((e->sub + 1) % P5_NSETS)) & 1) wgrad_flush(e, main, false);   // (cannot happen with one flush per layer; kept for safety)
 #ifndef P5_EMU
   if (!e->side) return;
-  const int p = e->sub & 1;
-  hipEventRecord(e->side_done[p], e->side);          // all wgrads of this sub-layer are enqueued
-  e->side_done_valid[p] = true;
-  if (e->side_done_valid[1 - p]) hipStreamWaitEvent(main, e->side_done[1 - p], 0);   // wgrads of the previous sub-layer
+  const int p = e->sub % P5_NSETS, pn = (e->sub + 1) % P5_NSETS;
+  if (!((e->wg_sets >> p) & 1)) {                      // this sub-layer's weight gradients were launched one by one: they are all enqueued
+    hipEventRecord(e->set_ev[p], e->side);
+    e->set_ev_valid[p] = true;
+  }
+  if (e->set_ev_valid[pn]) { hipStreamWaitEvent(main, e->set_ev[pn], 0); e->set_ev_valid[pn] = false; }
 #endif
 }
 static hipStream_t wgrad_stream(P5Engine* e, hipStream_t main) {
@@ -614,9 +652,44 @@ static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* 
   return gemm<T>(s, dy, lddy, 1, x, ldx, 1, dW, K_in, N_out, K_in, M, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop());
 }
 
+// Weight gradients of the bf16 engine are DEFERRED: the problem is queued and the whole layer's queue goes out as one launch of the
+// persistent ring kernel (p5_gemm4.h) -- every 128x128 tile of every weight of the layer reduces over ALL tokens (no split-K, no
+// atomics, plain "dW += acc"; each weight has exactly one writer).  wgrad_flush is called at the end of every backward stage.
+static int g_opt_wgrad_group = getenv("P5_WGRAD_GROUP") ? atoi(getenv("P5_WGRAD_GROUP")) : 1;
+static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head) {
+  if (e->wg_pending.empty()) return 0;
+  hipStream_t s = wgrad_stream(e, main);        // (the side stream now waits for everything the main stream has been given)
+  size_t i = 0;
+  while (i < e->wg_pending.size()) {
+    P5GemmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    while (i < e->wg_pending.size() && grp.nprob < P5_MAX_GROUP) grp.p[grp.nprob++] = e->wg_pending[i++];
+    P5_TRY(launch_gemm4(P5_G4_128x128, true, grp, s));
+  }
+#ifndef P5_EMU
+  if (e->side) {
+    for (int p = 0; p < P5_NSETS; ++p)
+      if ((e->wg_sets >> p) & 1) { hipEventRecord(e->set_ev[p], s); e->set_ev_valid[p] = true; }
+    if (is_head) { hipEventRecord(e->head_wg_ev, s); e->head_wg_valid = true; }
+  }
+#endif
+  e->wg_pending.clear();
+  e->wg_sets = 0;
+  return 0;
+}
 template <class T>
 static int linear_wgrad(P5Engine* e, hipStream_t main, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
                         float alpha = 1.f) {
+  if (sizeof(T) == 2 && g_opt_wgrad_group && (M % 64) == 0 && (lddy % 8) == 0 && (ldx % 8) == 0 && ((uintptr_t)dy % 16) == 0 &&
+      ((uintptr_t)x % 16) == 0 && (K_in % 4) == 0) {
+    P5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dy; g.B = x; g.C = dW; g.M = N_out; g.N = K_in; g.K = M; g.lda = lddy; g.ldb = ldx; g.ldc = K_in;
+    g.a_ks = 1; g.b_ks = 1; g.epi = P5_EPI_ACCUM; g.c_f32 = 1; g.splitk = 1; g.alpha = alpha; g.drop = no_drop();
+    e->wg_pending.push_back(g);
+    if (e->sub >= 0) e->wg_sets |= 1u << (e->sub % P5_NSETS);
+    return 0;
+  }
   return linear_wgrad_on<T>(wgrad_stream(e, main), dy, lddy, x, ldx, dW, M, N_out, K_in, alpha);
 }
 
@@ -707,7 +780,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->dw_scratch = (float*)b.take((size_t)(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2) * 1024 * d * 4);
     e->dn = b.take(Mx * d * sz);
     e->dO = b.take(Mx * in * sz);
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < P5_NSETS; ++p) {
       e->dy2[p] = b.take(Mx * d * sz);
       e->dqkv2[p] = b.take(Mx * 3 * in * sz);
       e->dkv2[p] = nullptr;
@@ -860,6 +933,17 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
   return 0;
 }
 
+static int norm_flush(P5Engine* e, hipStream_t main) {
+  P5ReduceMulti& r = e->nr_pending;
+  if (r.n == 0) return 0;
+  int mx = 0;
+  for (int i = 0; i < r.n; ++i) mx = r.nrows[i] > mx ? r.nrows[i] : mx;
+  P5_LAUNCH(p5_reduce_rows_multi_kernel, dim3((r.d + 63) / 64, mx >= 64 ? 16 : 1, r.n), dim3(256), 0, wgrad_stream(e, main), r, e->G,
+            (const float*)e->dw_scratch);
+  r.n = 0;
+  return P5_KCHECK();
+}
+
 template <class T>
 static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_off, const float* rstd, int rows, P5Drop din, P5Drop dnext,
                          bool has_res_in = true) {
@@ -870,10 +954,16 @@ static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_o
   int nblk = 0;
   P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows, d, din,
                         dnext, part, &nblk));
-  // the per-workgroup partials are summed off the critical path
-  P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64, nblk >= 64 ? 16 : 1), dim3(256), 0, wgrad_stream(e, s), e->G + ln_off, (const float*)part,
-            nblk, d);
-  P5_TRY(P5_KCHECK());
+  // the per-workgroup partials are summed off the critical path, all norms of the stage in one launch (norm_flush)
+  {
+    P5ReduceMulti& r = e->nr_pending;
+    if (r.n == 4) P5_TRY(norm_flush(e, s));
+    r.d = d;
+    r.nrows[r.n] = nblk;
+    r.dst_off[r.n] = ln_off;
+    r.part_off[r.n] = part - e->dw_scratch;
+    r.n++;
+  }
   e->dres_cur = out;
   return 0;
 }
@@ -914,8 +1004,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     e->d_enc_started = false;
     e->sub = -1;
     e->norm_slot = 0;
+    e->nr_pending.n = 0;
 #ifndef P5_EMU
-    e->side_done_valid[0] = e->side_done_valid[1] = false;
+    for (int i = 0; i < P5_NSETS; ++i) e->set_ev_valid[i] = false;
+    e->head_wg_valid = false;
 #endif
     begin_sublayer(e);
 #ifndef P5_EMU
@@ -932,7 +1024,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_TRY(P5_KCHECK());
     const float alpha = 1.0f / sqrtf((float)d);
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
-    P5_TRY(gemm<T>(wgrad_stream(e, s), e->dlogits, e->Vp, 1, e->dec_hn, d, 1, e->G + e->off_E, d, c.vocab_size, d, Md, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+    P5_TRY(linear_wgrad<T>(e, s, e->dlogits, e->Vp, e->dec_hn, d, e->G + e->off_E, Md, c.vocab_size, d, alpha));
+    P5_TRY(wgrad_flush(e, s, true));
     {
       // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
       hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
@@ -976,7 +1069,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
-    return 0;
+    return wgrad_flush(e, s, false);     // the six weight gradients of the layer: one launch
   }
   if (stage == nd + 1) {
     {
@@ -984,12 +1077,18 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       // (K = n_dec * 2 * inner), both off the critical path on the side stream; the encoder backward joins it (stage nd + 2)
       const int ldkv = nd * 2 * in;
       P5_TRY(linear_wgrad<T>(e, s, e->dkv_all, ldkv, e->enc_out, d, e->G + e->dec[0].ca.k, M, ldkv, d));
+      P5_TRY(wgrad_flush(e, s, false));
       P5_TRY(dgrad_w<T>(e, e->side ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
                              nullptr, 0, 1.f, 1));
     }
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
               (const float*)(e->rel_partial + (size_t)REL_COPIES * c.rel_buckets * H), c.rel_buckets * H, REL_COPIES);
     P5_TRY(P5_KCHECK());
+#ifndef P5_EMU
+    // shared.weight's gradient: the tied head's weight gradient adds with plain read-modify-writes (side stream, stage 0); the
+    // embedding scatters (atomics, from here on) must not run beside it
+    if (e->side && e->head_wg_valid) { hipStreamWaitEvent(s, e->head_wg_ev, 0); e->head_wg_valid = false; }
+#endif
     P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, e->G + e->off_E, (float*)nullptr, (const float*)e->dres_cur,
               (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
     return P5_KCHECK();
@@ -1015,7 +1114,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
-    return 0;
+    return wgrad_flush(e, s, false);     // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens
   }
   if (stage == nd + ne + 3) {
     // the tail of the backward: nothing is left to overlap these with except each other -- the whole-word scatter and the
@@ -1506,6 +1605,9 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_cross")) g_opt_dec_cross = value;
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
+  else if (!strcmp(name, "wgrad_group")) g_opt_wgrad_group = value;
+  else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
+  else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
   else if (!strcmp(name, "g4_wgs")) g_opt_g4_wgs = value;
   else return fail("p5_set_option: unknown option");
@@ -1639,6 +1741,8 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   P5_REQUIRE(e->Md > 0, "p5_forward must run first");
   P5_TRY(e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
                          : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream));
+  P5_TRY(wgrad_flush(e, (hipStream_t)stream, false));      // (a stage never leaves weight gradients or norm partials pending:
+  P5_TRY(norm_flush(e, (hipStream_t)stream));               //  its gradient range is final once this call's work has run)
   // the side stream is now ordered after this stage's main-stream work (a bucket all-reduce enqueued behind the side
   // stream sees every gradient of the stage); after the last stage the main stream waits for the side stream
   fork_to_side(e, (hipStream_t)stream);
@@ -1671,7 +1775,8 @@ int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
 #ifndef P5_EMU
   if (side_stream && !e->side) {
     for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming);
-    for (int i = 0; i < 2; ++i) hipEventCreateWithFlags(&e->side_done[i], hipEventDisableTiming);
+    for (int i = 0; i < P5_NSETS; ++i) hipEventCreateWithFlags(&e->set_ev[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&e->head_wg_ev, hipEventDisableTiming);
     for (int i = 0; i < 64; ++i) hipEventCreateWithFlags(&e->kv_ev[i], hipEventDisableTiming);
   }
   e->side = (hipStream_t)side_stream;

@@ -130,7 +130,7 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0)
         be.check(lib.p5_op_gemm_group(tile_cfg, ks, len(probs), arr, P(rng), 5, drop_p, be.stream_ptr()), "gemm_group")
         sync(be)
     finally:
-        lib.p5_set_option(b"g4_nst", 5)
+        lib.p5_set_option(b"g4_nst", 3)
         lib.p5_set_option(b"g4_wgs", 256)
     worst = 0.0
     for Cd, ref, c_f32, K, tag in checks:

@@ -44,7 +44,7 @@ def test_gemm_pipelined_loop_wgrad(emu, stages, shape):
     cases.gemm_v2_case(emu, stages, *shape, 4, ks=1)
 
 
-@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16)])
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16), (2, 8)])
 def test_gemm_persistent_ring(emu, nst, wgs):
     """p5_gemm4.h, K-contiguous operands: several problems per launch, more units than workgroups (wgs = 8: every workgroup walks
     several units, the ring runs across unit boundaries), ragged M / N (row clamp, partial 8-column vectors), K from one K-step
@@ -61,7 +61,7 @@ def test_gemm_persistent_ring_8_waves(emu, cfg):
     cases.gemm_group_case(emu, cfg, 0, probs, wgs=8)
 
 
-@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8)])
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (2, 8)])
 def test_gemm_persistent_ring_wgrad(emu, nst, wgs):
     """p5_gemm4.h, both operands K-strided (weight gradients): grouped, no split-K with C += (epi 6), split-K with atomics (epi 4),
     plain store; ragged output shapes."""

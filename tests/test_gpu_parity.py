@@ -290,7 +290,7 @@ def test_bf16_gradients_dropout_on(hip):
     assert r["whole_rel"] <= 0.04 and r["whole_cos"] >= 0.999, r
 
 
-@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16)])
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (4, 16), (2, 8)])
 def test_gemm_persistent_ring(hip, nst, wgs):
     """p5_gemm4.h on the hardware (direct-to-LDS ring with counted vmcnt across work units, permuted-row fragments, swapped MFMA
     operands, register epilogue): same grouped cases as the host-emulation suite, every epilogue incl. dropout and split-K."""
@@ -308,7 +308,7 @@ def test_gemm_persistent_ring_step_shapes(hip, cfg):
         cases.gemm_group_case(hip, cfg, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], drop_p=0.1, seed=rep)
 
 
-@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8)])
+@pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (2, 8)])
 def test_gemm_persistent_ring_wgrad(hip, nst, wgs):
     probs = [(136, 200, 128, 6, 1, 1), (128, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (8, 8, 64, 4, 1, 1), (200, 72, 192, 0, 1, 1)]
     for rep in range(3):

@@ -109,7 +109,7 @@ static void bench(const char* name, const std::vector<Prob>& ps, const std::func
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------------
-template <int BM, int BN, int WMW, int WNW, int NST, bool KS, int ABL = 0>
+template <int BM, int BN, int WMW, int WNW, int NST, bool KS, int ABL = 0, int OCC = 1, int FLAGS = 0>
 static void launch_g4(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
   P5GemmGroup grp;
   memset(&grp, 0, sizeof(grp));
@@ -128,7 +128,7 @@ static void launch_g4(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
   grp.total_units = units;
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > max_wg) nwg = max_wg;
-  hipLaunchKernelGGL((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, ABL>), dim3(nwg), dim3(WMW * WNW * 64), 0, 0, grp);
+  hipLaunchKernelGGL((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, ABL, OCC, FLAGS>), dim3(nwg), dim3(WMW * WNW * 64), 0, 0, grp);
 }
 template <int BM, int BN>
 static void set_rect(P5GemmArgs& g) {     // the launcher's XCD rectangle choice (p5_lib.hip::launch_gemm_tile)
@@ -254,6 +254,64 @@ int main(int argc, char** argv) {
       }, true);
     }
     (void)old_sum;
+  }
+  if (!strcmp(which, "lab2") || !strcmp(which, "fwd2")) {
+    const int shapes[][3] = {{8192, 2048, 512}, {8192, 1536, 512}, {8192, 512, 2048}, {8192, 512, 512}, {8192, 3072, 768}, {8192, 768, 3072}, {8192, 4096, 1024},
+                             {8192, 8192, 2048}};
+    for (auto& s : shapes) {
+      Prob p = make_prob(s[0], s[1], s[2], 0, 0, P5_EPI_STORE, 11);
+      printf("FWD2 M=%d N=%d K=%d (bf16 C)\n", s[0], s[1], s[2]);
+      P5GemmArgs g = args_of(p);
+      bench("v1 128x128 2-stage", {p}, [&] { launch_v1<128, 128>(g); }, false);
+      bench("ring 128x128 NST=4 (gemm2)", {p}, [&] { launch_ring<128, 128, 4, false>(g); }, false);
+      if (s[1] >= 1024) bench("256x256 8 waves 2-stage (gemm3)", {p}, [&] { launch_256(g); }, false);
+      bench("g4 256x128 8w NST=3", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({g}); }, false);
+      bench("g4 256x128 8w NST=3 K-rotated", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false, 0, 1, 1>({g}); }, false);
+      bench("g4 128x128 NST=3 K-rotated", {p}, [&] { launch_g4<128, 128, 2, 2, 3, false, 0, 1, 1>({g}); }, false);
+      bench("g4 128x128 NST=2 two WGs/CU", {p}, [&] { launch_g4<128, 128, 2, 2, 2, false, 0, 2, 0>({g}, 512); }, false);
+      bench("g4 128x128 NST=2 two WGs/CU, one unit each", {p}, [&] { launch_g4<128, 128, 2, 2, 2, false, 0, 2, 0>({g}, 1 << 20); }, false);
+      bench("g5 256x256 4w (128x128 wave tiles) NST=2", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false>({g}); }, false);
+      bench("g5 256x256 4w NST=2 K-rotated", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 0, 1, 1>({g}); }, false);
+      if (s[1] == 2048 || s[1] == 8192) {
+        bench("  g5 abl: no MFMA", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 1>({g}); }, false);
+        bench("  g5 abl: no copies", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 2>({g}); }, false);
+        bench("  g5 abl: no frag reads", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 4>({g}); }, false);
+        bench("  g5 abl: no epilogue", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 8>({g}); }, false);
+        bench("  g5 abl: MFMA + reads", {p}, [&] { launch_g4<256, 256, 2, 2, 2, false, 10>({g}); }, false);
+      }
+      CK(hipFree(p.A)); CK(hipFree(p.B)); CK(hipFree(p.C)); CK(hipFree(p.ref));
+    }
+  }
+  if (!strcmp(which, "lab2") || !strcmp(which, "wgrad2")) {
+    const int shapes[][2] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}};
+    std::vector<Prob> ps;
+    for (auto& s : shapes) ps.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 23 + s[0]));
+    std::vector<P5GemmArgs> gs;
+    for (Prob& p : ps) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; gs.push_back(g); }
+    printf("WGRAD2 grouped (192 units of 128x128 over 8192 tokens)\n");
+    bench("g4 KS NST=3", ps, [&] { launch_g4<128, 128, 2, 2, 3, true>(gs); }, true);
+    bench("g4 KS NST=3 K-rotated", ps, [&] { launch_g4<128, 128, 2, 2, 3, true, 0, 1, 1>(gs); }, true);
+    bench("g4 KS NST=2 two WGs/CU (192 WGs)", ps, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>(gs, 512); }, true);
+    bench("g4 KS NST=2 two WGs/CU K-rotated", ps, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 1>(gs, 512); }, true);
+    std::vector<P5GemmArgs> gs2;
+    for (Prob& p : ps) gs2.push_back(args_of(p, 2));
+    bench("g4 KS NST=2 two WGs/CU split 2 atomics (384 WGs)", ps, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>(gs2, 512); }, true);
+    // two layers' worth in one launch (384 units: 1.5 rounds of 256 persistent workgroups)
+    std::vector<Prob> ps2 = ps;
+    for (auto& s : shapes) ps2.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 77 + s[0]));
+    std::vector<P5GemmArgs> g8;
+    for (Prob& p : ps2) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; g8.push_back(g); }
+    bench("g4 KS NST=3, TWO layers in one launch (384 units)", ps2, [&] { launch_g4<128, 128, 2, 2, 3, true>(g8); }, true);
+    bench("g4 KS NST=2 two WGs/CU, TWO layers (384 WGs)", ps2, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>(g8, 512); }, true);
+    // the tied head's weight gradient: [32100 x 512] over 512 tokens
+    Prob ph = make_prob(32100, 512, 512, 1, 1, P5_EPI_ATOMIC, 5);
+    printf("WGRAD2 head: 32100x512 over 512 tokens\n");
+    P5GemmArgs gh = args_of(ph, 1);
+    bench("v1 128x128 atomics (today)", {ph}, [&] { launch_v1<128, 128>(gh); }, true);
+    P5GemmArgs gha = args_of(ph, 1);
+    gha.epi = P5_EPI_ACCUM;
+    bench("g4 KS NST=3 C +=", {ph}, [&] { launch_g4<128, 128, 2, 2, 3, true>({gha}); }, true);
+    bench("g4 KS NST=2 two WGs/CU C +=", {ph}, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>({gha}, 512); }, true);
   }
   printf("done\n");
   return 0;
