@@ -154,7 +154,18 @@ def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, 
         o = model.generate(**kw)
     barrier(world)
     gdt = max_over_ranks(time.perf_counter() - g0, world, device)
-    timing = model.last_generate_timing() if hasattr(model, "last_generate_timing") else None
+    # device time of the decode loop alone (engine-side HIP events around it), taken on extra calls OUTSIDE the timed region
+    timing = None
+    if hasattr(model, "time_generate"):
+        model.time_generate(True)
+        enc, dec = [], []
+        for _ in range(3):
+            model.generate(**kw)
+            t = model.last_generate_timing()
+            enc.append(t["encode_ms"])
+            dec.append(t["decode_ms"])
+        model.time_generate(False)
+        timing = {"encode_ms": sorted(enc)[1], "decode_ms": sorted(dec)[1], "source": "HIP events recorded by p5_generate around its decode loop, median of 3 calls"}
     return gdt, int(o["sequences"].shape[1]), timing
 
 
@@ -186,6 +197,52 @@ def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def time_wgrad_group(be, M, d, F, inner, iters=30):
+    """average duration of the dominant kernel of the step: the four weight gradients of one encoder layer (dW_o[d,F], dW_i[F,d],
+    dW_attn_o[d,inner], dW_qkv[3 inner,d], each reduced over all M tokens) as ONE launch of the persistent ring kernel
+    (p5_gemm4_kernel<128,128,KS>, 192 tiles, no split-K, C += acc), HIP events on the launch stream.  Returns (seconds, flops, bytes)."""
+    import ctypes
+    from openp5_amd._abi import P5GemmProblem
+    shapes = [(d, F), (F, d), (d, inner), (3 * inner, d)]
+    arr = (P5GemmProblem * len(shapes))()
+    keep = []
+    flops = byts = 0.0
+    for i, (n_out, k_in) in enumerate(shapes):
+        A = torch.randn(M, n_out, device=be.device).to(torch.bfloat16)
+        Bm = torch.randn(M, k_in, device=be.device).to(torch.bfloat16)
+        C = torch.zeros(n_out, k_in, device=be.device, dtype=torch.float32)
+        keep += [A, Bm, C]
+        q = arr[i]
+        q.A, q.B, q.C, q.aux = A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux = n_out, k_in, M, n_out, k_in, k_in, 0
+        q.epi, q.c_f32, q.splitk, q.alpha = 6, 1, 1, 1.0
+        q.rowss, q.rowss_eps, q.ssq_out = None, 0.0, None
+        flops += 2.0 * M * n_out * k_in
+        byts += 2.0 * M * (n_out + k_in) + 2 * 4.0 * n_out * k_in      # both operands once (bf16) + read-modify-write of the fp32 gradient
+    s = torch.cuda.current_stream()
+    call = lambda: be.lib.p5_op_gemm_group(0, 1, len(shapes), arr, None, 0, 0.0, be.stream_ptr())  # noqa: E731
+    for _ in range(5):
+        be.check(call(), "gemm_group")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        call()
+    e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3, flops, byts
+
+
+def in_step_us(kernel_key):
+    """average in-step duration (us) of a kernel from profiles/in_step.json (written by profiles/summarize_rocpd.py --in-step from the
+    rocprofv3 kernel trace of `bench.py` itself, where the kernel shares the GPU with the other stream) -- None when not collected."""
+    path = os.path.join(ROOT, "profiles", "in_step.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_key)
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, shape):
     """HBM bytes per launch of `kernel` at `shape` from profiles/pmc_traffic.json (profiles/collect_pmc.sh: separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- None when not collected."""
@@ -199,6 +256,47 @@ def pmc_traffic(kernel, shape):
         return float(ent["traffic_bytes"]) if ent else None
     except Exception:
         return None
+
+
+def cpu_baseline_train_hf(seconds_budget=15.0):
+    """The reference's own CPU path where it can be built: STOCK HuggingFace T5ForConditionalGeneration (installed transformers,
+    eager attention, fp32) fed `shared(ids) + whole_word(ww)` as P5_T5.forward does (P5_T5.py:94-100), CE(reduction="none") + the
+    runner's masked mean (DistributedRunner.py:72-77), clip_grad_norm_ + HF-AdamW semantics + step.  None if transformers is missing."""
+    try:
+        from oracle import hf_ref, t5_oracle as O
+        cfg = O.T5Cfg.named("t5-small", dropout=0.0)
+        params = O.init_params(cfg, 2023)
+        m, wwe = hf_ref.build_hf(cfg, params)
+    except Exception:
+        return None
+    ncores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(ncores)
+    m.train()
+    plist = [p for p in list(m.parameters()) + list(wwe.parameters()) if p.requires_grad]
+    Mm = [torch.zeros_like(p) for p in plist]
+    Vv = [torch.zeros_like(p) for p in plist]
+    ids, ww, mask, labels, out_attn = synth_batch(4, 128, 8, "cpu", 1)
+    times, t_start, step = [], time.time(), 0
+    while True:
+        t0 = time.time()
+        nll, _ = hf_ref.hf_forward_nll(m, wwe, ids, ww, mask, labels)
+        loss = O.runner_loss(nll, out_attn)
+        grads = torch.autograd.grad(loss, plist, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, plist)]
+        _, coef = O.clip_coef(grads, 1.0)
+        step += 1
+        with torch.no_grad():
+            for p, g, mm, vv in zip(plist, grads, Mm, Vv):
+                O.adamw_hf_step(p, g * coef, mm, vv, step, 1e-3)
+        times.append(time.time() - t0)
+        if (time.time() - t_start > seconds_budget and len(times) >= 2) or len(times) >= 12 or time.time() - t_start > 3 * seconds_budget:
+            break
+    rest = times[1:] if len(times) > 1 else times
+    med = sorted(rest)[len(rest) // 2]
+    import transformers
+    return {"value": 4.0 / med, "unit": "samples/s", "cores": ncores, "kind": "reference",
+            "sample": f"{len(times)} train steps of stock HF T5ForConditionalGeneration (transformers {transformers.__version__}, eager, fp32 T5-small, B=4, L=128, T=8) "
+                      "driven as P5_T5.forward + the runner's loss / clip / AdamW do, median of all but the first"}
 
 
 def cpu_baseline_train(seconds_budget=15.0):
@@ -406,10 +504,16 @@ def main():
         Mg, Ng, Kg = B * L, c.d_ff, c.d_model
         t_k = time_gemm_kernel(be, Mg, Ng, Kg)
         ach = 2.0 * Mg * Ng * Kg / t_k / 1e12
-        t_w = time_gemm_kernel(be, Ng, Kg, Mg, wgrad=True)          # dW_i[F, d] over B*L tokens
-        ach_w = 2.0 * Mg * Ng * Kg / t_w / 1e12
-        k_fwd = "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>"
-        k_wg = "p5_gemm2_kernel<128,128,ring4,KS,KS>"
+        t_w, fl_w, by_w = time_wgrad_group(be, Mg, c.d_model, c.d_ff, inner)
+        ach_w = fl_w / t_w / 1e12
+        k_fwd = "p5_gemm4_kernel<256,128,8 waves,ring3,KC>"
+        k_wg = "p5_gemm4_kernel<128,128,4 waves,ring3,KS> x4 weight gradients of an encoder layer"
+        ddp = None
+        if world > 1:
+            half = str(getattr(model, "ddp_bucket_dtype", "fp32")).replace("torch.", "") in ("bf16", "bfloat16")
+            ddp = {"world_size": _dist().get_world_size(), "backend": _dist().get_backend(), "collective": "all_reduce(SUM) of contiguous gradient-arena "
+                   "buckets, one per backward stage, issued behind the stage on the side stream",
+                   "allreduce_bytes_per_step_per_rank": int(model._n) * (2 if half else 4), "bucket_dtype": "bf16" if half else "fp32"}
         line = {
             "metric": "train_samples_per_sec", "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -422,27 +526,31 @@ def main():
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
-            # dominant kernel of the step by time (profiles/README.md): the ring weight-gradient GEMM; `roofline_fwd` times the
-            # same FLOPs as the forward FFN up-projection.  Both are timed live with HIP events on the launch stream; inside the
-            # step the ring kernel shares the GPU with the main stream, so its in-step launches are longer (profiles/).
-            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [Ng, Kg, Mg], "achieved": ach_w, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_w / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(k_wg, (Ng, Kg, Mg)),
-                         "algorithmic_bytes": 2.0 * (Mg * Kg + Mg * Ng) + 4.0 * Ng * Kg, "avg_launch_us": t_w * 1e6},
+            "distributed": ddp,
+            # dominant kernel of the step by time (profiles/README.md): ONE launch = the four weight gradients of an encoder layer on
+            # the persistent ring kernel (6 of them per step, ~12 % of the kernel time); `roofline_fwd` is the FFN up-projection.  Both
+            # are timed live with HIP events on the launch stream (`avg_launch_us`: the kernel alone); `in_step_us` is the same
+            # kernel's average duration inside the step, where it shares the GPU with the other stream (from the rocprofv3 trace).
+            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]],
+                         "achieved": ach_w, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("wgrad_group", (Mg, c.d_model, c.d_ff)), "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes)",
+                         "algorithmic_bytes": by_w, "avg_launch_us": t_w * 1e6, "in_step_us": in_step_us("wgrad_group"),
+                         "flops_per_launch": fl_w},
             "roofline_fwd": {"bound": "mfma", "kernel": k_fwd, "shape": [Mg, Ng, Kg], "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / BF16_PEAK_TFLOPS, "traffic": pmc_traffic(k_fwd, (Mg, Ng, Kg)),
-                             "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng), "avg_launch_us": t_k * 1e6},
+                             "frac": ach / BF16_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "traffic_source": "profiles/pmc_traffic.json",
+                             "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng), "avg_launch_us": t_k * 1e6, "in_step_us": in_step_us("fwd_wide")},
         }
         if gen:
             S = gen["decoded_len"] - 1
-            step_ms = (timing or {}).get("decode_ms")
-            step_ms = step_ms / max(1, S) if step_ms else gen["ms_per_batch"] / max(1, S)
+            timed = (timing or {}).get("decode_ms")
+            step_ms = timed / max(1, S) if timed else gen["ms_per_batch"] / max(1, S)
             byts = gen_bytes_per_step(c.d_model, inner, c.d_ff, c.num_decoder_layers, V, 20, 10, L, S // 2 + 1)
             gbs = byts / (step_ms * 1e-3) / 1e9
             line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": byts, "ms_per_step": step_ms,
                                            "steps": S, "traffic": None,
-                                           "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d)); "
-                                                   "time = device time of the decode loop / steps when the engine reports it, else whole generate() / steps"}
+                                           "time_source": "device time of the decode loop (engine HIP events) / steps" if timed else "whole generate() / steps",
+                                           "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d))"}
         legs_on = [] if args.legs == "none" else (["configs", "task_mix"] if args.legs == "all" else args.legs.split(","))
         if world == 1:
             del model, opt
@@ -458,7 +566,7 @@ def main():
             if legs:
                 line["legs"] = legs
             if not args.no_cpu:
-                line["cpu_baseline"] = cpu_baseline_train()
+                line["cpu_baseline"] = cpu_baseline_train_hf() or cpu_baseline_train()      # stock HF when transformers is importable, else the oracle port
                 line["cpu_baseline_generation"] = cpu_baseline_generation()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -125,6 +125,10 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                 const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,
                 const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
+/* Device-time brackets of p5_generate for benchmarks: p5_generate_timing(e, 1, NULL, NULL) arms it; after a p5_generate call,
+ * p5_generate_timing(e, enable, &encode_ms, &decode_ms) WAITS for that call to finish and returns the time between its start and
+ * its first decode step (encoder pass + cross-attention K/V projection + beam state) and the time of the decode loop itself. */
+int p5_generate_timing(P5Engine* e, int enable, float* encode_ms, float* decode_ms);
 /* The same search step by step (p5_generate = begin + (max_len - 1) x step + finish), for callers that interleave their own
  * work with the steps or want to stop early:
  *   p5_decode_begin   encoder, cross-attention K/V of every decoder layer, beam state (HF `_expand_inputs_for_generation`,

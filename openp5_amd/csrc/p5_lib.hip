@@ -129,7 +129,7 @@ static int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_
 static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
 static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
 enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2 };
-template <int BM, int BN, int WMW, int WNW, int NST, bool KS>
+template <int BM, int BN, int WMW, int WNW, int NST, bool KS, int OCC = 1>
 static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   int units = 0;
   for (int i = 0; i < grp.nprob; ++i) {
@@ -148,22 +148,22 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   grp.unit_begin[grp.nprob] = units;
   grp.total_units = units;
   int nwg = ((units + 7) / 8) * 8;
-  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
-  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
+  if (nwg > g_opt_g4_wgs * OCC) nwg = g_opt_g4_wgs * OCC;
+  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
   return P5_KCHECK();
 }
 static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
   P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
   if (ks) {
     P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 tiles");
-    if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, true>(grp, s);
+    if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, true, 2>(grp, s);     // two-slot ring, two workgroups per CU
     if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
     if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
     return launch_gemm4_cfg<128, 128, 2, 2, 5, true>(grp, s);
   }
   if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, false>(grp, s);
   if (cfg == P5_G4_128x256) return launch_gemm4_cfg<128, 256, 2, 4, 3, false>(grp, s);
-  if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, false>(grp, s);
+  if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, false, 2>(grp, s);
   if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, false>(grp, s);
   if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, false>(grp, s);
   return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void p5_tr_probe_kernel(unsigned short* out, co
 // =====================================================================================================
 // engine
 // =====================================================================================================
-static constexpr int P5_NSETS = 6;      // >= 2 x (sub-layers of a decoder layer)
+static constexpr int P5_NSETS = 8;      // >= 2 x (sub-layers of a decoder layer), >= 2 x (sub-layers of the encoder layers grouped into one launch)
 struct ParamInfo { std::string name; int64_t off; int rows, cols; };
 struct AttnOff { int64_t q, k, v, o, ln; };
 struct LayerOff { AttnOff sa, ca; int64_t wi, wo, ff_ln; int64_t begin, end; };
@@ -393,6 +393,7 @@ struct P5Engine {
   P5ReduceMulti nr_pending;               // norm-weight partial sums of the current backward stage, reduced by one launch at its end
   std::vector<P5GemmArgs> wg_pending;     // deferred weight-gradient problems (bf16, token count a multiple of 64)
   unsigned wg_sets = 0;                   // bit p: a pending problem reads temporaries of set p
+  bool whole_backward = false;            // inside p5_backward (as opposed to stage-by-stage calls of a data-parallel caller)
   void* dy_next = nullptr;
   void *kv_all = nullptr, *dkv_all = nullptr;   // cross-attention K/V (and their gradients) of all decoder layers, [M, n_dec*2*inner]
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
@@ -417,6 +418,8 @@ struct P5Engine {
 #ifndef P5_EMU
   hipEvent_t zg_ev = nullptr;
   hipEvent_t tr_ev = nullptr;
+  hipEvent_t gen_ev[3] = {nullptr, nullptr, nullptr};   // p5_generate_timing: before the encoder pass / before the first / after the last decode step
+  bool gen_timing = false;
   hipGraphExec_t gen_graph_exec = nullptr;
   bool gen_graph_failed = false;
   GraphKey gen_graph_key;
@@ -457,11 +460,11 @@ static void join_side(P5Engine* e, hipStream_t main) {
   hipStreamWaitEvent(main, ev, 0);
 #endif
 }
-static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head);
+static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head, bool on_side);
 // called right before the norm backward that ends sub-layer `sub`: it writes dy of the NEXT set, and the next sub-layer's data
 // gradients write the rest of that set -- whatever weight-gradient launch still reads it (P5_NSETS sub-layers ago) must be done
 static void end_sublayer_sync(P5Engine* e, hipStream_t main) {
-  if ((e->wg_sets >> ((e->sub + 1) % P5_NSETS)) & 1) wgrad_flush(e, main, false);   // (cannot happen with one flush per layer; kept for safety)
+  if ((e->wg_sets >> ((e->sub + 1) % P5_NSETS)) & 1) wgrad_flush(e, main, false, false);   // (cannot happen with one flush per layer; kept for safety)
 #ifndef P5_EMU
   if (!e->side) return;
   const int p = e->sub % P5_NSETS, pn = (e->sub + 1) % P5_NSETS;
@@ -656,15 +659,26 @@ static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* 
 // persistent ring kernel (p5_gemm4.h) -- every 128x128 tile of every weight of the layer reduces over ALL tokens (no split-K, no
 // atomics, plain "dW += acc"; each weight has exactly one writer).  wgrad_flush is called at the end of every backward stage.
 static int g_opt_wgrad_group = getenv("P5_WGRAD_GROUP") ? atoi(getenv("P5_WGRAD_GROUP")) : 1;
-static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head) {
+// which grouped weight-gradient launches go to the side stream: bit 0 = tied head + decoder layers (they run beside the decoder's chain of
+// small, latency-bound kernels, which leaves most CUs idle), bit 1 = cross-attention K/V block + encoder layers (every main-stream
+// kernel of the encoder backward fills the GPU by itself: beside it a 90 us weight-gradient workgroup only blocks CUs -- measured
+// 5.07 ms per step with everything on the side stream, 4.74 ms with nothing on it)
+static int g_opt_wgrad_side = getenv("P5_WGRAD_SIDE") ? atoi(getenv("P5_WGRAD_SIDE")) : 1;
+static int g_opt_wgrad_wgs = getenv("P5_WGRAD_WGS") ? atoi(getenv("P5_WGRAD_WGS")) : 0;          // workgroups of a grouped weight-gradient launch (0 = one per unit, <= 256)
+static int g_opt_wgrad_layers = getenv("P5_WGRAD_LAYERS") ? atoi(getenv("P5_WGRAD_LAYERS")) : 1;  // encoder layers per grouped launch (p5_backward only; staged backward: 1)
+static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head, bool on_side = true) {
   if (e->wg_pending.empty()) return 0;
-  hipStream_t s = wgrad_stream(e, main);        // (the side stream now waits for everything the main stream has been given)
+  hipStream_t s = on_side ? wgrad_stream(e, main) : main;        // (side: it now waits for everything the main stream has been given)
   size_t i = 0;
   while (i < e->wg_pending.size()) {
     P5GemmGroup grp;
     memset(&grp, 0, sizeof(grp));
     while (i < e->wg_pending.size() && grp.nprob < P5_MAX_GROUP) grp.p[grp.nprob++] = e->wg_pending[i++];
-    P5_TRY(launch_gemm4(P5_G4_128x128, true, grp, s));
+    const int keep = g_opt_g4_wgs;
+    if (g_opt_wgrad_wgs > 0) g_opt_g4_wgs = g_opt_wgrad_wgs;
+    const int rc = launch_gemm4(P5_G4_128x128, true, grp, s);
+    g_opt_g4_wgs = keep;
+    P5_TRY(rc);
   }
 #ifndef P5_EMU
   if (e->side) {
@@ -1025,7 +1039,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const float alpha = 1.0f / sqrtf((float)d);
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
     P5_TRY(linear_wgrad<T>(e, s, e->dlogits, e->Vp, e->dec_hn, d, e->G + e->off_E, Md, c.vocab_size, d, alpha));
-    P5_TRY(wgrad_flush(e, s, true));
+    P5_TRY(wgrad_flush(e, s, true, (g_opt_wgrad_side & 1) != 0));
     {
       // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
       hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
@@ -1069,16 +1083,19 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
-    return wgrad_flush(e, s, false);     // the six weight gradients of the layer: one launch
+    return wgrad_flush(e, s, false, (g_opt_wgrad_side & 1) != 0);     // the six weight gradients of the layer: one launch
   }
   if (stage == nd + 1) {
     {
       // every layer's d(K/V) is in place: ONE weight-gradient GEMM for the contiguous K/V block and ONE dgrad for d(enc_out)
       // (K = n_dec * 2 * inner), both off the critical path on the side stream; the encoder backward joins it (stage nd + 2)
       const int ldkv = nd * 2 * in;
+      // weight gradient of the K/V block: with the side stream it goes out now; otherwise it stays queued and leaves with the top encoder
+      // layer's group (one launch).  d(enc_out) is on the critical path of the encoder backward either way.
       P5_TRY(linear_wgrad<T>(e, s, e->dkv_all, ldkv, e->enc_out, d, e->G + e->dec[0].ca.k, M, ldkv, d));
-      P5_TRY(wgrad_flush(e, s, false));
-      P5_TRY(dgrad_w<T>(e, e->side ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
+      const bool side2 = e->side && (g_opt_wgrad_side & 2) != 0;
+      if (side2 || !e->whole_backward) P5_TRY(wgrad_flush(e, s, false, side2));
+      P5_TRY(dgrad_w<T>(e, side2 ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
                              nullptr, 0, 1.f, 1));
     }
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
@@ -1114,7 +1131,11 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
-    return wgrad_flush(e, s, false);     // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens
+    // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens (or of 2 layers = 384 tiles when the
+    // whole backward runs in one call and nobody waits for per-layer gradient ranges)
+    const int per = e->whole_backward && g_opt_wgrad_layers > 1 ? (g_opt_wgrad_layers < 2 ? 1 : 2) : 1;
+    if (per == 1 || i == 0 || ((ne - i) % per) == 0) return wgrad_flush(e, s, false, (g_opt_wgrad_side & 2) != 0);
+    return 0;
   }
   if (stage == nd + ne + 3) {
     // the tail of the backward: nothing is left to overlap these with except each other -- the whole-word scatter and the
@@ -1606,6 +1627,9 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
   else if (!strcmp(name, "wgrad_group")) g_opt_wgrad_group = value;
+  else if (!strcmp(name, "wgrad_wgs")) g_opt_wgrad_wgs = value;
+  else if (!strcmp(name, "wgrad_side")) g_opt_wgrad_side = value;
+  else if (!strcmp(name, "wgrad_layers")) g_opt_wgrad_layers = value;
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
@@ -1741,8 +1765,10 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   P5_REQUIRE(e->Md > 0, "p5_forward must run first");
   P5_TRY(e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
                          : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream));
-  P5_TRY(wgrad_flush(e, (hipStream_t)stream, false));      // (a stage never leaves weight gradients or norm partials pending:
-  P5_TRY(norm_flush(e, (hipStream_t)stream));               //  its gradient range is final once this call's work has run)
+  if (!e->whole_backward || stage == p5_backward_num_stages(e) - 1) {
+    P5_TRY(wgrad_flush(e, (hipStream_t)stream, false, (g_opt_wgrad_side & 2) != 0));      // (a stage never leaves weight gradients or norm partials pending:
+    P5_TRY(norm_flush(e, (hipStream_t)stream));               //  its gradient range is final once this call's work has run)
+  }
   // the side stream is now ordered after this stage's main-stream work (a bucket all-reduce enqueued behind the side
   // stream sees every gradient of the stage); after the last stage the main stream waits for the side stream
   fork_to_side(e, (hipStream_t)stream);
@@ -1787,8 +1813,11 @@ int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
 }
 int p5_backward(P5Engine* e, const float* dnll, void* stream) {
   const int n = p5_backward_num_stages(e);
-  for (int s = 0; s < n; ++s) P5_TRY(p5_backward_stage(e, dnll, s, stream));
-  return 0;
+  e->whole_backward = true;       // nobody consumes per-stage gradient ranges: weight gradients may be grouped across stages
+  int rc = 0;
+  for (int s = 0; s < n && rc == 0; ++s) rc = p5_backward_stage(e, dnll, s, stream);
+  e->whole_backward = false;
+  return rc;
 }
 int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end) {
   const int nd = e->c.n_dec_layers, ne = e->c.n_enc_layers;
@@ -1820,6 +1849,14 @@ int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int 
   P5Engine tmp = *e;
   return layout_gen(&tmp, nullptr, B, L, K, max_len, max_children, excluded_words, nullptr);
 }
+static void gen_mark_begin(P5Engine* e, void* stream) {
+#ifndef P5_EMU
+  if (e->gen_timing) {
+    if (!e->gen_ev[0]) for (int i = 0; i < 3; ++i) hipEventCreate(&e->gen_ev[i]);
+    hipEventRecord(e->gen_ev[0], (hipStream_t)stream);
+  }
+#endif
+}
 int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
                     int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
                     const uint32_t* excluded_nodes, int excluded_words, int max_children, void* ws, int64_t ws_bytes, void* stream) {
@@ -1832,6 +1869,7 @@ int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_
   P5_REQUIRE(excluded_words >= 0 && (excluded_nodes || excluded_words == 0), "excluded_nodes / excluded_words");
   const int64_t need = layout_gen(e, nullptr, B, L, K, max_len, max_children, excluded_words, nullptr);
   P5_REQUIRE(ws_bytes >= need, "workspace too small");
+  gen_mark_begin(e, stream);
   e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
   return e->c.dtype == 1
              ? decode_begin_impl<bf16>(e, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes, excluded_words, max_children,
@@ -1851,10 +1889,38 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
                 const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream) {
   P5_TRY(p5_decode_begin(e, input_ids, whole_word_ids, attention_mask, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes,
                          excluded_words, max_children, ws, ws_bytes, stream));
+#ifndef P5_EMU
+  if (e->gen_timing) {        // device-time brackets of the decode loop (p5_generate_timing): two event records, nothing is waited for
+    if (!e->gen_ev[0]) for (int i = 0; i < 3; ++i) hipEventCreate(&e->gen_ev[i]);
+    hipEventRecord(e->gen_ev[1], (hipStream_t)stream);
+  }
+#endif
   // every step is enqueued without reading anything back (the search stops on the device); the caller bounds max_len by the
   // depth of the trie, so at most a step or two are no-ops
   for (int cur_len = 1; cur_len < max_len; ++cur_len) P5_TRY(p5_decode_step(e, stream));
+#ifndef P5_EMU
+  if (e->gen_timing) hipEventRecord(e->gen_ev[2], (hipStream_t)stream);
+#endif
   return p5_decode_finish(e, out_seq, out_score, out_len, stream);
+}
+int p5_generate_timing(P5Engine* e, int enable, float* encode_ms, float* decode_ms) {
+#ifndef P5_EMU
+  if (encode_ms || decode_ms) {
+    P5_REQUIRE(e->gen_timing && e->gen_ev[0], "generate_timing: enable it before the p5_generate call to be measured");
+    P5_REQUIRE(hipEventSynchronize(e->gen_ev[2]) == hipSuccess, "generate_timing: event sync failed");
+    float a = 0.f, b = 0.f;
+    hipEventElapsedTime(&a, e->gen_ev[0], e->gen_ev[1]);
+    hipEventElapsedTime(&b, e->gen_ev[1], e->gen_ev[2]);
+    if (encode_ms) *encode_ms = a;
+    if (decode_ms) *decode_ms = b;
+  }
+  e->gen_timing = enable != 0;
+#else
+  if (encode_ms) *encode_ms = 0.f;
+  if (decode_ms) *decode_ms = 0.f;
+  (void)enable;
+#endif
+  return 0;
 }
 int p5_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L,
               void* enc_out, void* ws, int64_t ws_bytes, void* stream) {

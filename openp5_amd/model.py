@@ -118,7 +118,11 @@ class _P5LossFn(torch.autograd.Function):
 
 class P5T5Native(nn.Module):
     LUT_HALF = 512
-    use_side_stream = True
+    # Engine-internal second HIP stream (weight gradients, K/V projections, clears off the main stream).  OFF since round 3: with
+    # the layer-grouped weight-gradient launches every phase of the encoder backward fills the GPU from ONE stream, and the ~50
+    # cross-stream event waits per step cost more than the overlap returns (MI355X, C2 step: 4.74 ms without, 5.07-5.4 ms with).
+    # Data-parallel gradient exchange uses its own communication stream either way (`_engine_backward`).
+    use_side_stream = False
     use_transposed_weights = True     # bf16: keep W^T of the layer weights for the data gradients (p5_engine_bind_transposed)
     fuse_decode_norms = True      # generate(): fold the decoder RMSNorms into the GEMMs around them
 
@@ -145,6 +149,7 @@ class P5T5Native(nn.Module):
         self.ddp_bucket_dtype = "fp32"   # "bf16": gradient buckets travel as bf16 (half the bytes on the xGMI links)
         self._pending = []
         self._side = None
+        self._comm = None
         self._fold = None
         self._fold_dirty = True
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
@@ -467,9 +472,16 @@ class P5T5Native(nn.Module):
                 self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
                 lib.p5_backward_stage_range(eng, st, ctypes.byref(b), ctypes.byref(e))
                 if e.value > b.value:
-                    # enqueue behind the side stream when there is one: it is ordered after this stage's main-stream work
-                    # AND carries the stage's weight-gradient GEMMs
-                    ctx = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
+                    # the bucket's all-reduce goes to a communication stream ordered after this stage's work (the engine's side
+                    # stream when it has one -- it also carries the stage's weight gradients -- else a stream of our own that
+                    # waits for the main stream here), so that it overlaps the following stages
+                    comm = self._side
+                    if comm is None and self._flat.is_cuda:
+                        if self._comm is None:
+                            self._comm = torch.cuda.Stream(device=self._be.device)
+                        comm = self._comm
+                        comm.wait_stream(torch.cuda.current_stream())
+                    ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
                     with ctx:
                         seg = self._grads[b.value:e.value]
                         buf = seg.to(torch.bfloat16) if half else seg       # bf16 bucket: cast, reduce, cast back (below)
@@ -481,10 +493,11 @@ class P5T5Native(nn.Module):
                         buf.record_stream(torch.cuda.current_stream())      # allocated on the side stream, read here
                     seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
             self._pending = []
-            if self._side is not None:
-                # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
-                # stream they were issued from (gloo on device tensors) need the explicit edge side -> main
-                torch.cuda.current_stream().wait_stream(self._side)
+            for cs in (self._side, self._comm):
+                if cs is not None:
+                    # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
+                    # stream they were issued from (gloo on device tensors) need the explicit edge comm -> main
+                    torch.cuda.current_stream().wait_stream(cs)
         else:
             self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
         for name, p in self.named_parameters():
@@ -608,6 +621,21 @@ class P5T5Native(nn.Module):
         if return_dict_in_generate:
             return {"sequences": sequences, "sequences_scores": scores if output_scores else None}
         return sequences
+
+    def time_generate(self, enable: bool = True):
+        """Benchmark aid: arm (or disarm) the engine's device-time brackets around the next `generate` calls (two event records per
+        call, nothing is waited for until `last_generate_timing` is read)."""
+        self._be.check(self._lib.p5_generate_timing(self._engine, 1 if enable else 0, None, None), "p5_generate_timing")
+        self._gen_timed = bool(enable)
+
+    def last_generate_timing(self):
+        """{"encode_ms", "decode_ms"} of the most recent `generate` call made while `time_generate()` was armed: device time of the
+        encoder pass + cross-attention K/V projections, and of the decode loop alone (waits for that call to finish).  None if not armed."""
+        if not getattr(self, "_gen_timed", False):
+            return None
+        a, b = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        self._be.check(self._lib.p5_generate_timing(self._engine, 1, ctypes.byref(a), ctypes.byref(b)), "p5_generate_timing")
+        return {"encode_ms": float(a.value), "decode_ms": float(b.value)}
 
     def _explore_callable(self, fn, B, max_length):
         """Compat path for an arbitrary prefix_allowed_tokens_fn(batch_id, prefix): enumerate it breadth-first into one
