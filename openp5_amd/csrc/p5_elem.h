@@ -12,7 +12,7 @@
 template <class T>
 __global__ __launch_bounds__(256) void p5_embed_fwd_kernel(T* __restrict__ out, const T* __restrict__ E, const T* __restrict__ WW,
                                                           const int64_t* __restrict__ ids, const int64_t* __restrict__ ww,
-                                                          int rows, int d, P5Drop drop) {
+                                                          int rows, int d, P5Drop drop, float* __restrict__ ssq_part = nullptr) {
   constexpr int EPF = TT<T>::EPF;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -34,7 +34,17 @@ __global__ __launch_bounds__(256) void p5_embed_fwd_kernel(T* __restrict__ out, 
       for (int e = 0; e < EPF; ++e)
         x[e] = p5_keep(seed, drop.site_key, (uint32_t)(row * d + c * EPF + e), drop.thr) ? x[e] * drop.scale : 0.f;
     }
-    st16(out + (size_t)row * d + c * EPF, pack16<T>(x));
+    const u32x4 packed = pack16<T>(x);
+    st16(out + (size_t)row * d + c * EPF, packed);
+    if (ssq_part) {      // (uniform) T5LayerNorm statistic of the row as stored, per 64-column group (p5_gemm.h `rowss_nt`): 64 / EPF adjacent lanes
+      float w[8], ss = 0.f;
+      unpack16<T>(packed, w);
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) ss += w[e] * w[e];
+#pragma unroll
+      for (int m = 64 / EPF / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      if ((lane % (64 / EPF)) == 0) ssq_part[(size_t)row * (d / 64) + (c * EPF) / 64] = ss;
+    }
   }
 }
 
@@ -145,7 +155,8 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
                                                             float* __restrict__ dw, const T* __restrict__ dy,
                                                             const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
-                                                            int rows, int d, P5Drop drop_in, P5Drop drop_next, float* __restrict__ dw_partial) {
+                                                            int rows, int d, P5Drop drop_in, P5Drop drop_next, float* __restrict__ dw_partial,
+                                                            const float* __restrict__ ssq_part = nullptr, T* __restrict__ n_out = nullptr, float eps = 0.f) {
   constexpr int EPF = TT<T>::EPF;
   constexpr int RU = NCH <= 2 ? 2 : 1;             // rows in flight per wave
   __shared__ float sdw[4][NCH * 64 * EPF];
@@ -170,7 +181,23 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const int row = row0 + u * stride;
-      rstd[u] = row < rows ? rstd_in[row] : 0.f;
+      if (ssq_part) {      // (uniform) the forward carried the statistic as d/64 partial sums of squares per row (norm folded into the GEMMs)
+        float ss = 0.f;
+        if (row < rows) {
+          const float* sp = ssq_part + (size_t)row * (d / 64);
+          if (((d / 64) & 3) == 0) {
+            for (int t = 0; t < d / 64; t += 4) {
+              const f32x4 v = *(const f32x4*)(sp + t);
+              ss = (((ss + v[0]) + v[1]) + v[2]) + v[3];
+            }
+          } else {
+            for (int t = 0; t < d / 64; ++t) ss += sp[t];
+          }
+        }
+        rstd[u] = row < rows ? rsqrtf(ss / (float)d + eps) : 0.f;
+      } else {
+        rstd[u] = row < rows ? rstd_in[row] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = lane + i * 64;
@@ -190,14 +217,17 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_bwd_kernel(float* __restrict__
       for (int i = 0; i < NCH; ++i) {
         const int c = lane + i * 64;
         if (c < npc) {
+          float nrm[8];
 #pragma unroll
           for (int e = 0; e < EPF; ++e) {
             if (din) dyv[u][i][e] = p5_keep(seed_in, drop_in.site_key, (uint32_t)(row * d + c * EPF + e), drop_in.thr) ? dyv[u][i][e] * drop_in.scale : 0.f;
             xh[u][i][e] *= rstd[u];
+            if (n_out) nrm[e] = wv[i][e] * to_f<T>(from_f<T>(xh[u][i][e]));     // the forward norm's output, which the folded forward never wrote
             dwacc[i][e] += dyv[u][i][e] * xh[u][i][e];
             dyv[u][i][e] *= wv[i][e];
             dot += dyv[u][i][e] * xh[u][i][e];
           }
+          if (n_out) st16(n_out + (size_t)row * d + c * EPF, pack16<T>(nrm));
         }
       }
       dot = wave_sum(dot) / (float)d;

@@ -51,6 +51,10 @@ struct P5GemmArgs {
   float alpha;
   P5Drop drop;
   int g4_tiles_n, g4_nk;   // p5_gemm4.h launcher-internal: tiles along N, K-steps (of 64) per work unit
+  // T5LayerNorm folded into the TRAINING GEMMs (bf16 engine): the row statistic travels as `nt` partial sums of squares per row, one
+  // per 64-column group of the residual stream, each written by exactly one wave with a plain store (no atomics, no clearing, same
+  // bits every run) and summed in a fixed order by the consumer.  0 = the decode step's scalar-per-row form (atomic accumulate).
+  int rowss_nt, ssq_nt;
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets
@@ -246,6 +250,26 @@ __device__ static __forceinline__ u32x4 frag_load(const char* lds, int t0, int l
   }
 }
 
+// acc scale of an output row whose A row is an un-normalised residual-stream row: rsqrt(mean(x^2) + eps) from the carried statistic
+__device__ static __forceinline__ float gemm_row_rstd(const P5GemmArgs& g, int row) {
+  float ss;
+  if (g.rowss_nt > 0) {
+    const float* p = g.rowss + (size_t)row * g.rowss_nt;
+    if ((g.rowss_nt & 3) == 0) {          // d_model a multiple of 256: 16-byte loads, summed in index order like the scalar loop
+      ss = 0.f;
+      for (int t = 0; t < g.rowss_nt; t += 4) {
+        const f32x4 v = *(const f32x4*)(p + t);
+        ss = (((ss + v[0]) + v[1]) + v[2]) + v[3];
+      }
+    } else {
+      ss = 0.f;
+      for (int t = 0; t < g.rowss_nt; ++t) ss += p[t];
+    }
+  } else {
+    ss = g.rowss[row];
+  }
+  return rsqrtf(ss * g.rowss_invd + g.rowss_eps);
+}
 __device__ static __forceinline__ float gemm_epi_apply(const P5GemmArgs& g, float v, float auxv, uint32_t seed, bool do_drop, int row,
                                                        int col) {
   if (g.epi == P5_EPI_RELU_DROP) {
@@ -299,7 +323,7 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         for (int r = 0; r < 4; ++r) {
           const int lr = wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
           float sc = g.alpha;
-          if (g.rowss) sc *= rsqrtf(g.rowss[(m0 + lr) < g.M ? (m0 + lr) : (g.M - 1)] * g.rowss_invd + g.rowss_eps);
+          if (g.rowss) sc *= gemm_row_rstd(g, (m0 + lr) < g.M ? (m0 + lr) : (g.M - 1));
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int lc = wn * (BN / WNW) + j * 16 + (lane & 15);
@@ -334,9 +358,16 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         }
         if (g.ssq_out) {      // (uniform branch) the PPR lanes of a tile row are adjacent: one atomic per tile row
           static_assert(PPR <= 64 && (PPR & (PPR - 1)) == 0, "pieces per row: power of two within a wave");
+          if (g.ssq_nt > 0) {   // one partial per 64-column group (8 adjacent lanes), plain store: exactly one writer
+            static_assert(PPR >= 8 || BN < 64, "a 64-column group is 8 pieces");
 #pragma unroll
-          for (int m = PPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-          if (pc == 0 && row < g.M) atomicAdd(g.ssq_out + row, ss);
+            for (int m = (PPR < 8 ? PPR : 8) / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+            if ((pc & 7) == 0 && row < g.M && col < g.N) g.ssq_out[(size_t)row * g.ssq_nt + (col >> 6)] = ss;
+          } else {
+#pragma unroll
+            for (int m = PPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+            if (pc == 0 && row < g.M) atomicAdd(g.ssq_out + row, ss);
+          }
         }
       }
       return;
@@ -357,7 +388,7 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
         float auxv = 0.f;
         if (g.aux) auxv = to_f<T>(((const T*)g.aux)[(size_t)row * g.ldaux + col]);
         float sc = g.alpha;
-        if (g.rowss) sc *= rsqrtf(g.rowss[row] * g.rowss_invd + g.rowss_eps);
+        if (g.rowss) sc *= gemm_row_rstd(g, row);
         const float v = gemm_epi_apply(g, acc[i][j][r] * sc, auxv, seed, do_drop, row, col);
         if (g.ssq_out) {
           const float w = g.c_f32 ? v : to_f<T>(from_f<T>(v));

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(WMW* WNW * 64) P5_WAVES_PER_SIMD(WMW* WNW / 4 * OCC
       // lane owns 8 consecutive columns of a row per pair of MFMA tiles (2h, 2h+1): one 16-byte bf16 store (two for fp32)
       const bool row_ok = row < g.M;
       float sc = g.alpha;
-      if (g.rowss) sc *= rsqrtf(g.rowss[row_ok ? row : g.M - 1] * g.rowss_invd + g.rowss_eps);
+      if (g.rowss) sc *= gemm_row_rstd(g, row_ok ? row : g.M - 1);
       float ss = 0.f;
 #pragma unroll
       for (int h = 0; h < TN / 2; ++h) {
@@ -365,9 +365,16 @@ __global__ __launch_bounds__(WMW* WNW * 64) P5_WAVES_PER_SIMD(WMW* WNW / 4 * OCC
         }
       }
       if (g.ssq_out) {          // (uniform branch) the four lane groups hold the row's columns of this wave
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        if (gl == 0 && row_ok) atomicAdd(g.ssq_out + row, ss);
+        if (g.ssq_nt > 0 && WTN == 64) {     // this wave IS the only writer of the row's partial for its 64-column group
+          ss += __shfl_xor(ss, 16);
+          ss += __shfl_xor(ss, 32);
+          const int cg = (u.n0 + wn * WTN) >> 6;
+          if (gl == 0 && row_ok && cg < g.ssq_nt) g.ssq_out[(size_t)row * g.ssq_nt + cg] = ss;
+        } else {
+          ss += __shfl_xor(ss, 16);
+          ss += __shfl_xor(ss, 32);
+          if (gl == 0 && row_ok) atomicAdd(g.ssq_out + row, ss);
+        }
       }
     }
   };

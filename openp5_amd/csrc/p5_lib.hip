@@ -42,6 +42,7 @@ static int kcheck(const char* where) {
 // =====================================================================================================
 // tuning knobs (p5_set_option / environment): gemm_v2 = LDS stages (2 or 3) of the hand-pipelined main loop, 0 = v1 loop
 static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0;
+static int g_opt_wgrad_group = getenv("P5_WGRAD_GROUP") ? atoi(getenv("P5_WGRAD_GROUP")) : 1;   // layer-grouped deferred weight gradients (bf16)
 static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
 static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
 static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
@@ -155,7 +156,8 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
 static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
   P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
   if (ks) {
-    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 tiles");
+    if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, true>(grp, s);
+    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 or 256x128 tiles");
     if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, true, 2>(grp, s);     // two-slot ring, two workgroups per CU
     if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
     if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
@@ -330,6 +332,7 @@ struct LayerSave {
   void *x_sa, *n_sa, *qkv, *o_sa; float *rstd_sa, *lse_sa;
   void *x_ca, *n_ca, *q_ca, *kv_ca, *o_ca; float *rstd_ca, *lse_ca;
   void *x_ff, *n_ff, *u_ff, *h_ff; float *rstd_ff;
+  float *ssq_sa, *ssq_ca, *ssq_ff;     // [rows, d/64] partial sums of squares of x_sa / x_ca / x_ff (norm folded into the GEMMs)
 };
 
 struct Bump {
@@ -382,7 +385,8 @@ struct P5Engine {
   std::vector<LayerSave> es, ds;
   void *enc_x0 = nullptr, *enc_xf = nullptr, *enc_out = nullptr; float* enc_rstd_f = nullptr;
   int64_t* dec_ids = nullptr; void *dec_x0 = nullptr, *dec_xf = nullptr, *dec_hn = nullptr; float* dec_rstd_f = nullptr;
-  float *logits = nullptr, *lse_tok = nullptr;
+  float *logits = nullptr, *lse_tok = nullptr, *ssq_scratch = nullptr;
+  void* Sf = nullptr;              // folded bf16 weight copy W diag(ln) for q/k/v, wi, cross-attention q (same arena offsets; behind St)
   float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr, *rel_partial = nullptr;
   void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
   // two sets of the temporaries the wgrad GEMMs read, alternated per sub-layer, so the side stream can run one
@@ -618,6 +622,21 @@ static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, 
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
   g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = rowss_eps; g.ssq_out = ssq_out;
+  g.rowss_nt = 0; g.ssq_nt = 0; g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0;
+  return launch_gemm<T>(g, s);
+}
+// TRAINING forward with T5LayerNorm folded in (bf16 engine): y = rstd(x) * (x Wf^T), Wf = W diag(ln) from the folded
+// weight copy, rstd from the d/64 partial sums of squares per row that the PRODUCER of x left behind (`rowss`); `ssq_out`: this
+// GEMM's own output is a residual-stream row whose partial sums the next folded GEMM needs.
+template <class T>
+static int gemm_nf(hipStream_t s, const void* A, int lda, const void* Bm, int ldb, void* C, int ldc, int M, int N, int K, int epi, const void* aux,
+                   int ldaux, P5Drop drop, const float* rowss, float eps, float* ssq_out, int d_model) {
+  P5GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+  g.epi = epi; g.alpha = 1.f; g.drop = drop;
+  g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = eps; g.rowss_nt = rowss ? d_model / 64 : 0;
+  g.ssq_out = ssq_out; g.ssq_nt = ssq_out ? d_model / 64 : 0;
   return launch_gemm<T>(g, s);
 }
 // decode step: y = rmsnorm(x) W^T with the norm weight folded into Wf and the row statistic taken from `rowss` (sum of squares
@@ -658,14 +677,15 @@ static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* 
 // Weight gradients of the bf16 engine are DEFERRED: the problem is queued and the whole layer's queue goes out as one launch of the
 // persistent ring kernel (p5_gemm4.h) -- every 128x128 tile of every weight of the layer reduces over ALL tokens (no split-K, no
 // atomics, plain "dW += acc"; each weight has exactly one writer).  wgrad_flush is called at the end of every backward stage.
-static int g_opt_wgrad_group = getenv("P5_WGRAD_GROUP") ? atoi(getenv("P5_WGRAD_GROUP")) : 1;
 // which grouped weight-gradient launches go to the side stream: bit 0 = tied head + decoder layers (they run beside the decoder's chain of
 // small, latency-bound kernels, which leaves most CUs idle), bit 1 = cross-attention K/V block + encoder layers (every main-stream
 // kernel of the encoder backward fills the GPU by itself: beside it a 90 us weight-gradient workgroup only blocks CUs -- measured
 // 5.07 ms per step with everything on the side stream, 4.74 ms with nothing on it)
 static int g_opt_wgrad_side = getenv("P5_WGRAD_SIDE") ? atoi(getenv("P5_WGRAD_SIDE")) : 1;
+static int g_opt_wgrad_wide = getenv("P5_WGRAD_WIDE") ? atoi(getenv("P5_WGRAD_WIDE")) : 1;
+static int g_opt_wgrad_wide_min = getenv("P5_WGRAD_WIDE_MIN") ? atoi(getenv("P5_WGRAD_WIDE_MIN")) : 160;
 static int g_opt_wgrad_wgs = getenv("P5_WGRAD_WGS") ? atoi(getenv("P5_WGRAD_WGS")) : 0;          // workgroups of a grouped weight-gradient launch (0 = one per unit, <= 256)
-static int g_opt_wgrad_layers = getenv("P5_WGRAD_LAYERS") ? atoi(getenv("P5_WGRAD_LAYERS")) : 1;  // encoder layers per grouped launch (p5_backward only; staged backward: 1)
+static int g_opt_wgrad_layers = getenv("P5_WGRAD_LAYERS") ? atoi(getenv("P5_WGRAD_LAYERS")) : 2;  // encoder layers per grouped launch (p5_backward only; staged backward: 1)
 static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head, bool on_side = true) {
   if (e->wg_pending.empty()) return 0;
   hipStream_t s = on_side ? wgrad_stream(e, main) : main;        // (side: it now waits for everything the main stream has been given)
@@ -673,10 +693,18 @@ static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head, bool on_side
   while (i < e->wg_pending.size()) {
     P5GemmGroup grp;
     memset(&grp, 0, sizeof(grp));
-    while (i < e->wg_pending.size() && grp.nprob < P5_MAX_GROUP) grp.p[grp.nprob++] = e->wg_pending[i++];
+    long u256 = 0;
+    while (i < e->wg_pending.size() && grp.nprob < P5_MAX_GROUP) {
+      const P5GemmArgs& q = e->wg_pending[i];
+      u256 += (long)((q.M + 255) / 256) * ((q.N + 127) / 128);
+      grp.p[grp.nprob++] = e->wg_pending[i++];
+    }
     const int keep = g_opt_g4_wgs;
     if (g_opt_wgrad_wgs > 0) g_opt_g4_wgs = g_opt_wgrad_wgs;
-    const int rc = launch_gemm4(P5_G4_128x128, true, grp, s);
+    // 256x128 tiles (eight waves) once the group has enough of them to occupy most CUs: 3/4 of the operand bytes per MAC copied
+    // into LDS -- which is what bounds these launches (tools/lab: two encoder layers 130 us vs 163 us on 128x128 tiles; one
+    // layer alone has only 96 such tiles and stays on 128x128: 85 vs 102 us)
+    const int rc = launch_gemm4(g_opt_wgrad_wide && u256 >= g_opt_wgrad_wide_min ? P5_G4_256x128 : P5_G4_128x128, true, grp, s);
     g_opt_g4_wgs = keep;
     P5_TRY(rc);
   }
@@ -716,14 +744,14 @@ static int rmsnorm_fwd(hipStream_t s, void* y, float* rstd, const void* x, const
 template <class T>
 static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
                        const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext, float* dw_partial = nullptr,
-                       int* nblocks_out = nullptr) {
+                       int* nblocks_out = nullptr, const float* ssq_part = nullptr, void* n_out = nullptr, float eps = 0.f) {
   P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   if (nblocks_out) *nblocks_out = blocks;
   const int nch = (d / TT<T>::EPF + 63) / 64;          // 16-byte pieces per lane
 #define P5_NBWD(N) P5_LAUNCH((p5_rmsnorm_bwd_kernel<T, N>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd, \
-                             dres_in, rows, d, din, dnext, dw_partial)
+                             dres_in, rows, d, din, dnext, dw_partial, ssq_part, (T*)n_out, eps)
   if (nch <= 1) P5_NBWD(1);
   else if (nch == 2) P5_NBWD(2);
   else P5_NBWD(4);
@@ -747,6 +775,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
   for (auto& l : e->es) {
     l.x_sa = xprev;
     l.n_sa = b.take(M * d * sz); l.rstd_sa = (float*)b.take(M * 4);
+    l.ssq_sa = (float*)b.take(M * (d / 64) * 4); l.ssq_ff = (float*)b.take(M * (d / 64) * 4); l.ssq_ca = nullptr;
     l.qkv = b.take(M * 3 * in * sz); l.o_sa = b.take(M * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * L * 4);
     l.x_ff = b.take(M * d * sz);
     l.n_ff = b.take(M * d * sz); l.rstd_ff = (float*)b.take(M * 4);
@@ -755,6 +784,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     xprev = b.take(M * d * sz);
   }
   e->enc_xf = xprev;
+  e->ssq_scratch = (float*)b.take((M > Md ? M : Md) * (d / 64) * 4);     // statistics of rows nobody normalises through a GEMM (stack outputs)
   e->enc_rstd_f = (float*)b.take(M * 4);
   e->enc_out = b.take(M * d * sz);
   if (T > 0) {
@@ -764,6 +794,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     for (auto& l : e->ds) {
       l.x_sa = xprev;
       l.n_sa = b.take(Md * d * sz); l.rstd_sa = (float*)b.take(Md * 4);
+      l.ssq_sa = (float*)b.take(Md * (d / 64) * 4); l.ssq_ca = (float*)b.take(Md * (d / 64) * 4); l.ssq_ff = (float*)b.take(Md * (d / 64) * 4);
       l.qkv = b.take(Md * 3 * in * sz); l.o_sa = b.take(Md * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * T * 4);
       l.x_ca = b.take(Md * d * sz);
       l.n_ca = b.take(Md * d * sz); l.rstd_ca = (float*)b.take(Md * 4);
@@ -809,20 +840,37 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
 }
 
 // ---- shared sub-layer forward helpers -----------------------------------------------------------------
+// T5LayerNorm of the TRAINING forward folded into the GEMMs around it (bf16 engine with the folded weight copy bound): the producer of a
+// residual-stream row leaves d/64 partial sums of squares behind, the consuming projection multiplies the raw row with W diag(ln) and
+// scales its accumulator rows by rstd.  The normalised rows the weight gradients need are written by the norm BACKWARD kernel.
+static int g_opt_norm_fuse = getenv("P5_NORM_FUSE") ? atoi(getenv("P5_NORM_FUSE")) : 1;
+// (the weight gradients must be the deferred, layer-grouped ones: they run after the sub-layer's norm backward has written n)
+template <class T> static bool norm_fused(const P5Engine* e) {
+  return sizeof(T) == 2 && e->Sf != nullptr && g_opt_norm_fuse != 0 &&
+         (e->Md == 0 || (g_opt_wgrad_group != 0 && (e->M % 64) == 0 && (e->Md % 64) == 0));
+}
+template <class T> static const T* Wnf(const P5Engine* e, int64_t off) { return (const T*)((const bf16*)e->Sf + off); }
+
+// xout = x_ff + drop(wo(act(wi(norm(x_ff)))));  ssq_next: where to leave the statistics of xout (fused mode)
 template <class T>
-static int ffn_fwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, void* xout, int rows, int stack, int li) {
+static int ffn_fwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, void* xout, int rows, int stack, int li, float* ssq_next) {
   const P5Config& c = e->c;
   const int d = c.d_model, F = c.d_ff;
-  P5_TRY(rmsnorm_fwd<T>(s, l.n_ff, l.rstd_ff, l.x_ff, e->P + lo.ff_ln, rows, d, c.eps, no_drop()));
+  const bool nf = norm_fused<T>(e);
+  if (!nf) P5_TRY(rmsnorm_fwd<T>(s, l.n_ff, l.rstd_ff, l.x_ff, e->P + lo.ff_ln, rows, d, c.eps, no_drop()));
   if (c.gated_gelu) {
-    P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.u_ff, 2 * F, rows, 2 * F, d));
+    if (nf) P5_TRY(gemm_nf<T>(s, l.x_ff, d, Wnf<T>(e, lo.wi), d, l.u_ff, 2 * F, rows, 2 * F, d, P5_EPI_STORE, nullptr, 0, no_drop(), l.ssq_ff, c.eps, nullptr, d));
+    else P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.u_ff, 2 * F, rows, 2 * F, d));
     const size_t n = (size_t)rows * F;
     P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
               (T*)l.h_ff, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
     P5_TRY(P5_KCHECK());
+  } else if (nf) {
+    P5_TRY(gemm_nf<T>(s, l.x_ff, d, Wnf<T>(e, lo.wi), d, l.h_ff, F, rows, F, d, P5_EPI_RELU_DROP, nullptr, 0, mk_drop(e, stack, li, 5), l.ssq_ff, c.eps, nullptr, d));
   } else {
     P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.h_ff, F, rows, F, d, P5_EPI_RELU_DROP, nullptr, 0, 1.f, 0, mk_drop(e, stack, li, 5)));
   }
+  if (nf) return gemm_nf<T>(s, l.h_ff, F, Wc<T>(e, lo.wo), F, xout, d, rows, d, F, P5_EPI_RESID_DROP, l.x_ff, d, mk_drop(e, stack, li, 6), nullptr, 0.f, ssq_next, d);
   return linear_fwd<T>(s, l.h_ff, F, Wc<T>(e, lo.wo), xout, d, rows, d, F, P5_EPI_RESID_DROP, l.x_ff, d, 1.f, 0, mk_drop(e, stack, li, 6));
 }
 
@@ -830,15 +878,21 @@ template <class T>
 static int encoder_fwd(P5Engine* e, hipStream_t s) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M;
+  const bool nf = norm_fused<T>(e);
   P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, (T*)e->enc_x0, Wc<T>(e, e->off_E), Wc<T>(e, e->off_WW), e->ids,
-            e->ww, M, d, mk_drop(e, 0, 0, 0));
+            e->ww, M, d, mk_drop(e, 0, 0, 0), nf ? e->es[0].ssq_sa : (float*)nullptr);
   P5_TRY(P5_KCHECK());
   for (int i = 0; i < c.n_enc_layers; ++i) {
     const LayerOff& lo = e->enc[i];
     LayerSave& l = e->es[i];
     void* xnext = (i + 1 < c.n_enc_layers) ? e->es[i + 1].x_sa : e->enc_xf;
-    P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, M, d, c.eps, no_drop()));
-    P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, M, 3 * in, d));
+    float* ssq_next = (i + 1 < c.n_enc_layers) ? e->es[i + 1].ssq_sa : e->ssq_scratch;
+    if (nf) {
+      P5_TRY(gemm_nf<T>(s, l.x_sa, d, Wnf<T>(e, lo.sa.q), d, l.qkv, 3 * in, M, 3 * in, d, P5_EPI_STORE, nullptr, 0, no_drop(), l.ssq_sa, c.eps, nullptr, d));
+    } else {
+      P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, M, d, c.eps, no_drop()));
+      P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, M, 3 * in, d));
+    }
     P5AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa;
@@ -846,8 +900,9 @@ static int encoder_fwd(P5Engine* e, hipStream_t s) {
     a.B = e->B; a.H = H; a.Lq = e->L; a.Lk = e->L; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.causal = 0;
     a.drop = mk_drop(e, 0, i, 1);
     P5_TRY(launch_attn_fwd<T>(a, s));
-    P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 0, i, 2)));
-    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, M, 0, i));
+    if (nf) P5_TRY(gemm_nf<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), in, l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, mk_drop(e, 0, i, 2), nullptr, 0.f, l.ssq_ff, d));
+    else P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 0, i, 2)));
+    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, M, 0, i, ssq_next));
   }
   return rmsnorm_fwd<T>(s, e->enc_out, e->enc_rstd_f, e->enc_xf, e->P + e->off_enc_fln, M, d, c.eps, mk_drop(e, 0, 0, 7));
 }
@@ -875,16 +930,22 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
   }
   P5_LAUNCH(p5_shift_right_kernel, dim3((Md + 255) / 256), dim3(256), 0, s, e->dec_ids, e->labels, e->B, e->T, (int64_t)c.pad_id);
   P5_TRY(P5_KCHECK());
+  const bool nf = norm_fused<T>(e);
   P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, (T*)e->dec_x0, Wc<T>(e, e->off_E), (const T*)nullptr,
-            (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
+            (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0), nf ? e->ds[0].ssq_sa : (float*)nullptr);
   P5_TRY(P5_KCHECK());
   for (int i = 0; i < c.n_dec_layers; ++i) {
     const LayerOff& lo = e->dec[i];
     LayerSave& l = e->ds[i];
     void* xnext = (i + 1 < c.n_dec_layers) ? e->ds[i + 1].x_sa : e->dec_xf;
+    float* ssq_next = (i + 1 < c.n_dec_layers) ? e->ds[i + 1].ssq_sa : e->ssq_scratch;
     // self attention (causal, unidirectional buckets)
-    P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, Md, d, c.eps, no_drop()));
-    P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, Md, 3 * in, d));
+    if (nf) {
+      P5_TRY(gemm_nf<T>(s, l.x_sa, d, Wnf<T>(e, lo.sa.q), d, l.qkv, 3 * in, Md, 3 * in, d, P5_EPI_STORE, nullptr, 0, no_drop(), l.ssq_sa, c.eps, nullptr, d));
+    } else {
+      P5_TRY(rmsnorm_fwd<T>(s, l.n_sa, l.rstd_sa, l.x_sa, e->P + lo.sa.ln, Md, d, c.eps, no_drop()));
+      P5_TRY(linear_fwd<T>(s, l.n_sa, d, Wc<T>(e, lo.sa.q), l.qkv, 3 * in, Md, 3 * in, d));
+    }
     P5AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = l.qkv; a.K = (const T*)l.qkv + in; a.V = (const T*)l.qkv + 2 * in; a.O = l.o_sa; a.lse = l.lse_sa;
@@ -892,10 +953,15 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
     a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->T; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.causal = 1;
     a.drop = mk_drop(e, 1, i, 1);
     P5_TRY(launch_attn_fwd<T>(a, s));
-    P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ca, d, Md, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 1, i, 2)));
-    // cross attention (zero position bias + encoder padding mask)
-    P5_TRY(rmsnorm_fwd<T>(s, l.n_ca, l.rstd_ca, l.x_ca, e->P + lo.ca.ln, Md, d, c.eps, no_drop()));
-    P5_TRY(linear_fwd<T>(s, l.n_ca, d, Wc<T>(e, lo.ca.q), l.q_ca, in, Md, in, d));
+    if (nf) {
+      P5_TRY(gemm_nf<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), in, l.x_ca, d, Md, d, in, P5_EPI_RESID_DROP, l.x_sa, d, mk_drop(e, 1, i, 2), nullptr, 0.f, l.ssq_ca, d));
+      // cross attention (zero position bias + encoder padding mask)
+      P5_TRY(gemm_nf<T>(s, l.x_ca, d, Wnf<T>(e, lo.ca.q), d, l.q_ca, in, Md, in, d, P5_EPI_STORE, nullptr, 0, no_drop(), l.ssq_ca, c.eps, nullptr, d));
+    } else {
+      P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ca, d, Md, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 1, i, 2)));
+      P5_TRY(rmsnorm_fwd<T>(s, l.n_ca, l.rstd_ca, l.x_ca, e->P + lo.ca.ln, Md, d, c.eps, no_drop()));
+      P5_TRY(linear_fwd<T>(s, l.n_ca, d, Wc<T>(e, lo.ca.q), l.q_ca, in, Md, in, d));
+    }
 #ifndef P5_EMU
     if (e->side && (i == 0 || (i == 1 && nd_ > 1))) hipStreamWaitEvent(s, e->kv_ev[i], 0);   // K/V projections were issued on the side stream up front
 #endif
@@ -905,8 +971,9 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
     a.B = e->B; a.H = H; a.Lq = e->T; a.Lk = e->L; a.ldq = in; a.ldk = a.ldv = ldkv; a.ldo = in; a.causal = 0;
     a.drop = mk_drop(e, 1, i, 3);
     P5_TRY(launch_attn_fwd<T>(a, s));
-    P5_TRY(linear_fwd<T>(s, l.o_ca, in, Wc<T>(e, lo.ca.o), l.x_ff, d, Md, d, in, P5_EPI_RESID_DROP, l.x_ca, d, 1.f, 0, mk_drop(e, 1, i, 4)));
-    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, Md, 1, i));
+    if (nf) P5_TRY(gemm_nf<T>(s, l.o_ca, in, Wc<T>(e, lo.ca.o), in, l.x_ff, d, Md, d, in, P5_EPI_RESID_DROP, l.x_ca, d, mk_drop(e, 1, i, 4), nullptr, 0.f, l.ssq_ff, d));
+    else P5_TRY(linear_fwd<T>(s, l.o_ca, in, Wc<T>(e, lo.ca.o), l.x_ff, d, Md, d, in, P5_EPI_RESID_DROP, l.x_ca, d, 1.f, 0, mk_drop(e, 1, i, 4)));
+    P5_TRY(ffn_fwd<T>(e, s, lo, l, xnext, Md, 1, i, ssq_next));
   }
   P5_TRY(rmsnorm_fwd<T>(s, e->dec_hn, e->dec_rstd_f, e->dec_xf, e->P + e->off_dec_fln, Md, d, c.eps, mk_drop(e, 1, 0, 7)));
   // tied head, d^-0.5 rescale folded into alpha (P5_T5.py:352-361)
@@ -960,14 +1027,14 @@ static int norm_flush(P5Engine* e, hipStream_t main) {
 
 template <class T>
 static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_off, const float* rstd, int rows, P5Drop din, P5Drop dnext,
-                         bool has_res_in = true) {
+                         bool has_res_in = true, const float* ssq = nullptr, void* n_out = nullptr) {
   float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
   end_sublayer_sync(e, s);
   const int d = e->c.d_model;
   float* part = e->dw_scratch + (size_t)(e->norm_slot++) * 1024 * d;
   int nblk = 0;
   P5_TRY(rmsnorm_bwd<T>(s, out, e->dy_next, e->G + ln_off, e->dn, x, e->P + ln_off, rstd, has_res_in ? e->dres_cur : nullptr, rows, d, din,
-                        dnext, part, &nblk));
+                        dnext, part, &nblk, ssq, n_out, e->c.eps));
   // the per-workgroup partials are summed off the critical path, all norms of the stage in one launch (norm_flush)
   {
     P5ReduceMulti& r = e->nr_pending;
@@ -1062,7 +1129,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     LayerSave& l = e->ds[i];
     begin_sublayer(e);
     P5_TRY(ffn_bwd<T>(e, s, lo, l, Md, 1, i));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4)));
+    const bool nf = norm_fused<T>(e);
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
     // cross attention
     begin_sublayer(e);
     P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
@@ -1078,11 +1146,12 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_TRY(launch_attn_bwd<T>(a, s));
     P5_TRY(linear_wgrad<T>(e, s, e->dqkv, in, l.n_ca, d, e->G + lo.ca.q, Md, in, d));
     P5_TRY(dgrad_w<T>(e, s, e->dqkv, in, lo.ca.q, e->dn, d, Md, in, d));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2)));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2), true, nf ? l.ssq_ca : nullptr, nf ? l.n_ca : nullptr));
     // self attention
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
+                            nf ? l.n_sa : nullptr));
     return wgrad_flush(e, s, false, (g_opt_wgrad_side & 1) != 0);     // the six weight gradients of the layer: one launch
   }
   if (stage == nd + 1) {
@@ -1127,14 +1196,17 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     LayerSave& l = e->es[i];
     begin_sublayer(e);
     P5_TRY(ffn_bwd<T>(e, s, lo, l, M, 0, i));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2)));
+    const bool nf = norm_fused<T>(e);
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
+    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
+                            nf ? l.n_sa : nullptr));
     // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens (or of 2 layers = 384 tiles when the
     // whole backward runs in one call and nobody waits for per-layer gradient ranges)
-    const int per = e->whole_backward && g_opt_wgrad_layers > 1 ? (g_opt_wgrad_layers < 2 ? 1 : 2) : 1;
-    if (per == 1 || i == 0 || ((ne - i) % per) == 0) return wgrad_flush(e, s, false, (g_opt_wgrad_side & 2) != 0);
+    // (the top layer's group also carries the cross-attention K/V block queued in the previous stage: 5 problems; then pairs of layers)
+    const bool pairs = e->whole_backward && g_opt_wgrad_layers > 1;
+    if (!pairs || i == 0 || e->wg_pending.size() >= 5) return wgrad_flush(e, s, false, (g_opt_wgrad_side & 2) != 0);
     return 0;
   }
   if (stage == nd + ne + 3) {
@@ -1567,6 +1639,32 @@ static int refresh_fold(P5Engine* e, hipStream_t s) {
   return fold(e->fold_E, e->off_E, e->off_dec_fln, c.vocab_size);
 }
 
+// out[w_off + r*d + c] = bf16(P[w_off + r*d + c] * P[ln_off + c]) for every listed weight: 8 rows per workgroup, one launch for the model
+struct P5FoldTab {
+  int n, d;
+  struct D { long long w_off, ln_off; int rows, blk0; } e[160];
+};
+__global__ __launch_bounds__(256) void p5_fold_rows_kernel(bf16* __restrict__ out, const float* __restrict__ P, P5FoldTab tab) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = tab.n - 1;             // last descriptor with blk0 <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.e[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const long long w_off = tab.e[lo].w_off, ln_off = tab.e[lo].ln_off;
+  const int rows = tab.e[lo].rows, r0 = (b - tab.e[lo].blk0) * 8, d = tab.d;
+  for (int i = threadIdx.x; i < 8 * (d / 8); i += 256) {
+    const int r = r0 + i / (d / 8), c = (i % (d / 8)) * 8;
+    if (r >= rows) continue;
+    float w[8], l[8], o[8];
+    ldf<8>(P + w_off + (size_t)r * d + c, w);
+    ldf<8>(P + ln_off + c, l);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = w[q] * l[q];
+    st16(out + w_off + (size_t)r * d + c, pack16<bf16>(o));
+  }
+}
+
 // out[c, r] = in[r, c] for every [rows, cols] block of the descriptor table (64 x 64 tiles through LDS, 16-byte row accesses)
 struct P5TrDesc { int64_t off; int rows, cols, tile0; };
 __global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restrict__ out, const bf16* __restrict__ in, const P5TrDesc* __restrict__ tab,
@@ -1627,7 +1725,9 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
   else if (!strcmp(name, "wgrad_group")) g_opt_wgrad_group = value;
+  else if (!strcmp(name, "norm_fuse")) g_opt_norm_fuse = value;
   else if (!strcmp(name, "wgrad_wgs")) g_opt_wgrad_wgs = value;
+  else if (!strcmp(name, "wgrad_wide")) g_opt_wgrad_wide = value;
   else if (!strcmp(name, "wgrad_side")) g_opt_wgrad_side = value;
   else if (!strcmp(name, "wgrad_layers")) g_opt_wgrad_layers = value;
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
@@ -1685,17 +1785,20 @@ int p5_refresh_decode_fold(P5Engine* e, void* stream) {
   return e->c.dtype == 1 ? refresh_fold<bf16>(e, (hipStream_t)stream) : refresh_fold<float>(e, (hipStream_t)stream);
 }
 
-int64_t p5_transposed_bytes(const P5Engine* e) {
-  return (int64_t)e->n_params * 2 + 256 + (int64_t)e->tr_list.size() * (int64_t)sizeof(P5TrDesc);
-}
+// buffer layout: [W^T copy: n_params bf16][256-byte aligned descriptor table][256-byte aligned folded copy W diag(ln): n_params bf16]
+static size_t tr_table_off(const P5Engine* e) { return ((size_t)e->n_params * 2 + 255) & ~(size_t)255; }
+static size_t tr_fold_off(const P5Engine* e) { return (tr_table_off(e) + e->tr_list.size() * sizeof(P5TrDesc) + 255) & ~(size_t)255; }
+int64_t p5_transposed_bytes(const P5Engine* e) { return (int64_t)(tr_fold_off(e) + (size_t)e->n_params * 2 + 256); }
 int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream) {
   e->St = buf;
+  e->Sf = nullptr;
   if (!buf) return 0;
   P5_REQUIRE(e->c.dtype == 1, "the transposed weight copy serves the bf16 mode only");
   // the descriptor table lives behind the copy itself (the library allocates nothing)
   std::vector<P5TrDesc> tab;
   for (auto& t : e->tr_list) tab.push_back({t.off, t.rows, t.cols, t.tile0});
-  char* at = (char*)buf + (((size_t)e->n_params * 2 + 255) & ~(size_t)255);
+  char* at = (char*)buf + tr_table_off(e);
+  e->Sf = (char*)buf + tr_fold_off(e);
 #ifndef P5_EMU
   P5_REQUIRE(hipMemcpyAsync(at, tab.data(), tab.size() * sizeof(P5TrDesc), hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess, "descriptor upload");
   hipStreamSynchronize((hipStream_t)stream);      // (tab is a host temporary; one-time set-up call)
@@ -1715,9 +1818,31 @@ int p5_refresh_transposed(P5Engine* e, void* stream) {
 #ifndef P5_EMU
   if (e->side) { fork_to_side(e, main); s = e->side; }
 #endif
-  const P5TrDesc* tab = (const P5TrDesc*)((char*)e->St + (((size_t)e->n_params * 2 + 255) & ~(size_t)255));
+  const P5TrDesc* tab = (const P5TrDesc*)((char*)e->St + tr_table_off(e));
   P5_LAUNCH(p5_transpose_blocks_kernel, dim3(e->tr_tiles), dim3(256), 0, s, (bf16*)e->St, (const bf16*)e->S, tab, (int)e->tr_list.size());
   P5_TRY(P5_KCHECK());
+  if (e->Sf) {
+    // W diag(ln) of every projection that consumes a T5LayerNorm output (q/k/v, wi, cross-attention q), from the fp32 masters, at the
+    // weights' own arena offsets -- what the training forward multiplies the raw residual stream with (norm_fused)
+    const P5Config& c = e->c;
+    const int d = c.d_model, in = e->inner;
+    const int wi_rows = (c.gated_gelu ? 2 : 1) * c.d_ff;
+    P5FoldTab tab;
+    tab.n = 0; tab.d = d;
+    int blocks = 0;
+    auto add = [&](int64_t w_off, int64_t ln_off, int rows) {
+      P5FoldTab::D& q = tab.e[tab.n++];
+      q.w_off = w_off; q.ln_off = ln_off; q.rows = rows; q.blk0 = blocks;
+      blocks += (rows + 7) / 8;
+    };
+    P5_REQUIRE(2 * c.n_enc_layers + 3 * c.n_dec_layers <= 160, "fold table");
+    for (int i = 0; i < c.n_enc_layers; ++i) { add(e->enc[i].sa.q, e->enc[i].sa.ln, 3 * in); add(e->enc[i].wi, e->enc[i].ff_ln, wi_rows); }
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      add(e->dec[i].sa.q, e->dec[i].sa.ln, 3 * in); add(e->dec[i].ca.q, e->dec[i].ca.ln, in); add(e->dec[i].wi, e->dec[i].ff_ln, wi_rows);
+    }
+    P5_LAUNCH(p5_fold_rows_kernel, dim3(blocks), dim3(256), 0, s, (bf16*)e->Sf, (const float*)e->P, tab);
+    P5_TRY(P5_KCHECK());
+  }
 #ifndef P5_EMU
   if (e->tr_ev) hipEventRecord(e->tr_ev, s);
 #endif
@@ -1947,7 +2072,8 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
-  g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr;
+  g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr; g.rowss_nt = 0; g.ssq_nt = 0;
+  g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0;
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
 }
 int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,

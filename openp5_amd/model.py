@@ -289,7 +289,8 @@ class P5T5Native(nn.Module):
         self._tr_dirty = True
 
     def _sync_transposed(self):
-        """W^T of the layer weights for the next backward (enqueued on the side stream: it overlaps the forward)."""
+        """W^T of the layer weights for the next backward, and W diag(ln) of the projections behind a T5LayerNorm for the next forward
+        (both live in the buffer bound with p5_engine_bind_transposed; one refresh call after every parameter change)."""
         if self._shadow_t is not None and self._tr_dirty:
             self._be.check(self._lib.p5_refresh_transposed(self._engine, self._be.stream_ptr()), "p5_refresh_transposed")
             self._tr_dirty = False
@@ -595,6 +596,7 @@ class P5T5Native(nn.Module):
         if roots is not None:
             roots_t = torch.as_tensor(roots, dtype=torch.int32, device=dev).contiguous()
         self._sync_shadow()
+        self._sync_transposed()     # (also refreshes the folded copy W diag(ln) the encoder pass multiplies the raw residual stream with)
         self._sync_decode_fold()
         maxc = max(1, trie.max_children)
         excl_t, excl_words = None, 0

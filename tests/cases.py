@@ -483,16 +483,35 @@ def golden_case(be, name, dtype="fp32", nll_tol=3e-5, grad_tol=3e-4, score_tol=2
     compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), fx["sequences"], fx["sequences_scores"], score_tol)
 
 
-def compare_generation(seq, score, seq_ref, score_ref, score_tol, eos=1):
-    """Token-exact up to and including the first EOS (HF 5.15 pads with eos, HF 4.26 / this path with pad=0)."""
+def compare_generation(seq, score, seq_ref, score_ref, score_tol, eos=1, tie_tol=0.0, K=None):
+    """Token-exact up to and including the first EOS (HF 5.15 pads with eos, HF 4.26 / this path with pad=0).
+    tie_tol > 0 (bf16 engine against the fp32 oracle; K = rows per batch item): a row may hold a different hypothesis if the
+    reference ranks that hypothesis within tie_tol of this row's reference score (a swap between near-ties), or -- when the
+    reference's top-K does not contain it -- if this row is within tie_tol of the reference's K-th score (a boundary item)."""
     assert seq.shape[0] == seq_ref.shape[0]
-    assert (score - score_ref).abs().max().item() <= score_tol, (score, score_ref)
+    if tie_tol <= 0:
+        assert (score - score_ref).abs().max().item() <= score_tol, (score, score_ref)
+
+    def cut(t):
+        t = t.tolist()
+        e_ = t.index(eos) if eos in t else len(t) - 1
+        return t[:e_ + 1], t[e_ + 1:]
     for r in range(seq.shape[0]):
-        a, b = seq[r].tolist(), seq_ref[r].tolist()
-        ea = a.index(eos) if eos in a else len(a) - 1
-        eb = b.index(eos) if eos in b else len(b) - 1
-        assert a[:ea + 1] == b[:eb + 1], f"row {r}: {a} vs {b}"
-        assert all(t == 0 for t in a[ea + 1:]), f"row {r} not pad-filled: {a}"
+        (a, pad), (b, _) = cut(seq[r]), cut(seq_ref[r])
+        assert all(t == 0 for t in pad), f"row {r} not pad-filled: {seq[r].tolist()}"
+        if a == b:
+            assert abs(float(score[r]) - float(score_ref[r])) <= score_tol, (r, score, score_ref)
+            continue
+        assert tie_tol > 0 and K, f"row {r}: {a} vs {b}"
+        g0 = r // K * K
+        group = [cut(seq_ref[q])[0] for q in range(g0, g0 + K)]
+        if a in group:
+            q = g0 + group.index(a)
+            assert abs(float(score[r]) - float(score_ref[q])) <= score_tol, f"row {r}: score of a hypothesis both searches return differs"
+        else:
+            # a low-precision search prunes differently where an intermediate decision of the reference was a near-tie: it may keep a
+            # hypothesis the reference dropped -- legitimate only if that hypothesis scores at least as well as the one it displaces
+            assert float(score[r]) >= float(score_ref[r]) - tie_tol, f"row {r}: {a} is not in the reference's top-{K} and scores worse"
 
 
 def make_items(n_items, seed, lo=7, hi=40, prefix=(0, 5, 6), minlen=2, maxlen=4):
@@ -525,7 +544,7 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
                      num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True)
     with torch.no_grad():
         s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, max_len)
-    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
+    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol, tie_tol=0.05 if dtype == "bf16" else 0.0, K=K)
     return out
 
 

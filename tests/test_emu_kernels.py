@@ -61,6 +61,12 @@ def test_gemm_persistent_ring_8_waves(emu, cfg):
     cases.gemm_group_case(emu, cfg, 0, probs, wgs=8)
 
 
+def test_gemm_persistent_ring_wgrad_256x128(emu):
+    """the eight-wave 256x128 configuration on K-strided operands (two encoder layers' weight gradients per launch)."""
+    probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1)]
+    cases.gemm_group_case(emu, 1, 1, probs, wgs=8)
+
+
 @pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (2, 8)])
 def test_gemm_persistent_ring_wgrad(emu, nst, wgs):
     """p5_gemm4.h, both operands K-strided (weight gradients): grouped, no split-K with C += (epi 6), split-K with atomics (epi 4),
@@ -211,6 +217,27 @@ def test_dec_cross_attn(emu, dtype, variant, shape):
     """single-token cross-attention of the beams of an item (HF modeling_t5.py:404-432 with zero position bias): the matrix-core
     kernel and the scalar kernel against float64, incl. ragged L, > 16 beams (two row tiles) and L = 512 (four key chunks)."""
     cases.dec_cross_attn_case(emu, dtype, variant, *shape)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_model_bf16_norm_folded_into_gemms(emu, dropout):
+    """bf16 training step with T5LayerNorm folded into the GEMMs (token counts that are multiples of 64 take that path): the producer of a
+    residual-stream row leaves per-64-column partial sums of squares, the consuming projection multiplies the raw row with W diag(ln) and
+    scales by rstd, the norm backward rebuilds n for the deferred weight gradients.  Against the fp32 oracle, and against the
+    engine's own unfolded path (same bounds)."""
+    cfg = O.T5Cfg.named("tiny")
+    res = {}
+    try:
+        for nf in (1, 0):
+            emu.check(emu.lib.p5_set_option(b"norm_fuse", nf), "opt")
+            r = cases.bf16_gradient_case(emu, cfg, 4, 16, 16, dropout=dropout)
+            res[nf] = r
+            assert r["nll_max"] <= 0.08 and r["loss_err"] <= 0.03, (nf, r)
+            assert r["worst_rel"][0] <= 0.15 and r["worst_cos"][0] >= 0.99, (nf, r)
+            assert r["whole_rel"] <= 0.06 and r["whole_cos"] >= 0.998, (nf, r)
+    finally:
+        emu.lib.p5_set_option(b"norm_fuse", 1)
+    assert abs(res[1]["whole_rel"] - res[0]["whole_rel"]) <= 0.02, res
 
 
 @pytest.mark.parametrize("dtype,d_model,heads", [("fp32", 64, 1), ("fp32", 64, 2), ("fp32", 192, 2), ("bf16", 64, 1)])

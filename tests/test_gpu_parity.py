@@ -315,6 +315,14 @@ def test_gemm_persistent_ring_wgrad(hip, nst, wgs):
         cases.gemm_group_case(hip, 0, 1, probs, nst=nst, wgs=wgs, seed=rep)
 
 
+def test_gemm_persistent_ring_wgrad_256x128(hip):
+    probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1)]
+    for rep in range(3):
+        cases.gemm_group_case(hip, 1, 1, probs, wgs=8, seed=rep)
+    two_layers = [(512, 2048, 8192, 6, 1, 1), (2048, 512, 8192, 6, 1, 1), (512, 512, 8192, 6, 1, 1), (1536, 512, 8192, 6, 1, 1)] * 2
+    cases.gemm_group_case(hip, 1, 1, two_layers)
+
+
 def test_gemm_persistent_ring_wgrad_layer_group(hip):
     """the four weight gradients of one T5-small encoder layer over 8192 tokens as ONE launch, no split-K, C += acc."""
     probs = [(512, 2048, 8192, 6, 1, 1), (2048, 512, 8192, 6, 1, 1), (512, 512, 8192, 6, 1, 1), (1536, 512, 8192, 6, 1, 1)]

@@ -313,6 +313,26 @@ int main(int argc, char** argv) {
     bench("g4 KS NST=3 C +=", {ph}, [&] { launch_g4<128, 128, 2, 2, 3, true>({gha}); }, true);
     bench("g4 KS NST=2 two WGs/CU C +=", {ph}, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>({gha}, 512); }, true);
   }
+  if (!strcmp(which, "lab3")) {
+    const int shapes[][2] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}};
+    std::vector<Prob> ps;
+    for (auto& s : shapes) ps.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 23 + s[0]));
+    std::vector<Prob> ps2 = ps;
+    for (auto& s : shapes) ps2.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 77 + s[0]));
+    std::vector<P5GemmArgs> g4, g8;
+    for (Prob& p : ps) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; g4.push_back(g); }
+    for (Prob& p : ps2) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; g8.push_back(g); }
+    printf("WGRAD3: one layer (4 problems) / two layers (8 problems) per launch\n");
+    bench("128x128 4w NST=3, one layer (192 units)", ps, [&] { launch_g4<128, 128, 2, 2, 3, true>(g4); }, true);
+    bench("256x128 8w NST=3, one layer (96 units)", ps, [&] { launch_g4<256, 128, 4, 2, 3, true>(g4); }, true);
+    bench("128x256 8w NST=3, one layer (96 units)", ps, [&] { launch_g4<128, 256, 2, 4, 3, true>(g4); }, true);
+    bench("128x128 4w NST=3, two layers (384 units)", ps2, [&] { launch_g4<128, 128, 2, 2, 3, true>(g8); }, true);
+    bench("128x128 4w NST=2 2 WGs/CU, two layers", ps2, [&] { launch_g4<128, 128, 2, 2, 2, true, 0, 2, 0>(g8, 512); }, true);
+    bench("256x128 8w NST=3, two layers (192 units)", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true>(g8); }, true);
+    bench("128x256 8w NST=3, two layers (192 units)", ps2, [&] { launch_g4<128, 256, 2, 4, 3, true>(g8); }, true);
+    bench("  abl 256x128 two layers: copies only", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 5>(g8); }, true);
+    bench("  abl 256x128 two layers: MFMA + reads", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 10>(g8); }, true);
+  }
   printf("done\n");
   return 0;
 }
