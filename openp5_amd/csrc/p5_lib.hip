@@ -1821,6 +1821,10 @@ int p5_refresh_transposed(P5Engine* e, void* stream) {
   const P5TrDesc* tab = (const P5TrDesc*)((char*)e->St + tr_table_off(e));
   P5_LAUNCH(p5_transpose_blocks_kernel, dim3(e->tr_tiles), dim3(256), 0, s, (bf16*)e->St, (const bf16*)e->S, tab, (int)e->tr_list.size());
   P5_TRY(P5_KCHECK());
+#ifndef P5_EMU
+  if (e->tr_ev) hipEventRecord(e->tr_ev, s);       // (W^T is first read by the backward; the folded copy below by the very next forward)
+#endif
+  s = main;          // the folded copy is read by the very next forward: always on the caller's stream
   if (e->Sf) {
     // W diag(ln) of every projection that consumes a T5LayerNorm output (q/k/v, wi, cross-attention q), from the fp32 masters, at the
     // weights' own arena offsets -- what the training forward multiplies the raw residual stream with (norm_fused)
@@ -1843,9 +1847,6 @@ int p5_refresh_transposed(P5Engine* e, void* stream) {
     P5_LAUNCH(p5_fold_rows_kernel, dim3(blocks), dim3(256), 0, s, (bf16*)e->Sf, (const float*)e->P, tab);
     P5_TRY(P5_KCHECK());
   }
-#ifndef P5_EMU
-  if (e->tr_ev) hipEventRecord(e->tr_ev, s);
-#endif
   e->tr_pending = true;
   return 0;
 }
@@ -1913,7 +1914,7 @@ int p5_engine_clear_grads(P5Engine* e, void* stream) {
 #endif
   if (hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s) != 0) return fail("clear_grads: hipMemsetAsync failed");
 #ifndef P5_EMU
-  if (e->side) {
+  if (s != main) {
     if (!e->zg_ev) hipEventCreateWithFlags(&e->zg_ev, hipEventDisableTiming);
     hipEventRecord(e->zg_ev, s);
     e->zg_pending = true;

@@ -18,6 +18,7 @@ contiguous buckets issued while the backward is still running.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes
 import math
 from dataclasses import dataclass
