@@ -284,6 +284,8 @@ __device__ static __forceinline__ float gemm_epi_apply(const P5GemmArgs& g, floa
   return v;
 }
 
+template <int V> struct P5EpiTag { static constexpr int value = V; };
+
 template <class T, int BM, int BN, int LDSB, int NT = 256, int WNW = 2>
 __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 (&acc)[BM / (16 * (NT / 64 / WNW))][BN / (16 * WNW)], char* lds,
                                                      int m0, int n0, int tid) {
@@ -331,45 +333,75 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
           }
         }
       __syncthreads();
+      // The epilogue kind is a compile-time constant of the store loop (EK: 0 store, 1 ReLU, 2 ReLU + dropout, 3 + residual,
+      // 4 dropout + residual, 5 ReLU' mask), chosen once per tile: a per-element `if (g.epi == ...)` chain compiles to scalar
+      // branches -- the dropout hash keeps hipcc from if-converting it -- about five per element (p5_gemm5.h, round 3), and the
+      // descriptor fields it uses are read once here instead of where they are used.
+      const int eM = g.M, eN = g.N, eldc = g.ldc, eldaux = g.ldaux, essq_nt = g.ssq_nt, eepi = g.epi;
+      float* const essq = g.ssq_out;
+      const bf16* const eaux = (const bf16*)g.aux;
+      bf16* const eC = (bf16*)g.C;
+      const uint32_t ethr = g.drop.thr;
+      const float escale = g.drop.scale;
+      const uint32_t hseed = p5_mix32(seed + g.drop.site_key);
+      auto pieces = [&](auto ek) {
+        constexpr int EK = decltype(ek)::value;
 #pragma unroll
-      for (int i = 0; i < NPIECE; ++i) {
-        const int p = tid + i * NT;
-        const int lr = p / PPR, pc = p % PPR;
-        const int row = m0 + lr, col = n0 + pc * 8;
-        const bool ok = row < g.M && col < g.N;
-        float ss = 0.f;
-        if (ok) {
-          float v[8];
-          unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
-          if (g.epi != P5_EPI_STORE) {
-            float av[8];
-            if (g.aux) unpack16<bf16>(PRE ? auxr[PRE ? i : 0] : ld16((const bf16*)g.aux + (size_t)row * g.ldaux + col), av);
+        for (int i = 0; i < NPIECE; ++i) {
+          const int p = tid + i * NT;
+          const int lr = p / PPR, pc = p % PPR;
+          const int row = m0 + lr, col = n0 + pc * 8;
+          const bool ok = row < eM && col < eN;
+          float ss = 0.f;
+          if (ok) {
+            float v[8];
+            unpack16<bf16>(ld16(lds + lr * CST + pc * 16), v);
+            if constexpr (EK != 0) {
+              float av[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], g.aux ? av[e] : 0.f, seed, do_drop, row, col + e);
+              for (int e = 0; e < 8; ++e) av[e] = 0.f;
+              if constexpr (EK >= 3) {
+                if (eaux) unpack16<bf16>(PRE ? auxr[PRE ? i : 0] : ld16(eaux + (size_t)row * eldaux + col), av);
+              }
+              const uint32_t idx0 = (uint32_t)(row * eN + col);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                if constexpr (EK == 1 || EK == 2) x = x > 0.f ? x : 0.f;
+                if constexpr (EK == 2 || EK == 4) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= ethr ? x * escale : 0.f;
+                if constexpr (EK == 3 || EK == 4) x += av[e];
+                if constexpr (EK == 5) x = av[e] > 0.f ? x : 0.f;
+                v[e] = x;
+              }
+            }
+            const u32x4 packed = pack16<bf16>(v);
+            st16(eC + (size_t)row * eldc + col, packed);
+            if (essq) {    // sum of squares of the row as stored
+              float w[8];
+              unpack16<bf16>(packed, w);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ss += w[e] * w[e];
+            }
           }
-          const u32x4 packed = pack16<bf16>(v);
-          st16((bf16*)g.C + (size_t)row * g.ldc + col, packed);
-          if (g.ssq_out) {    // sum of squares of the row as stored
-            float w[8];
-            unpack16<bf16>(packed, w);
+          if (essq) {      // (uniform branch) the PPR lanes of a tile row are adjacent: one atomic per tile row
+            static_assert(PPR <= 64 && (PPR & (PPR - 1)) == 0, "pieces per row: power of two within a wave");
+            if (essq_nt > 0) {   // one partial per 64-column group (8 adjacent lanes), plain store: exactly one writer
+              static_assert(PPR >= 8 || BN < 64, "a 64-column group is 8 pieces");
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += w[e] * w[e];
+              for (int m = (PPR < 8 ? PPR : 8) / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+              if ((pc & 7) == 0 && ok) essq[(size_t)row * essq_nt + (col >> 6)] = ss;
+            } else {
+#pragma unroll
+              for (int m = PPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+              if (pc == 0 && row < eM) atomicAdd(essq + row, ss);
+            }
           }
         }
-        if (g.ssq_out) {      // (uniform branch) the PPR lanes of a tile row are adjacent: one atomic per tile row
-          static_assert(PPR <= 64 && (PPR & (PPR - 1)) == 0, "pieces per row: power of two within a wave");
-          if (g.ssq_nt > 0) {   // one partial per 64-column group (8 adjacent lanes), plain store: exactly one writer
-            static_assert(PPR >= 8 || BN < 64, "a 64-column group is 8 pieces");
-#pragma unroll
-            for (int m = (PPR < 8 ? PPR : 8) / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-            if ((pc & 7) == 0 && row < g.M && col < g.N) g.ssq_out[(size_t)row * g.ssq_nt + (col >> 6)] = ss;
-          } else {
-#pragma unroll
-            for (int m = PPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-            if (pc == 0 && row < g.M) atomicAdd(g.ssq_out + row, ss);
-          }
-        }
-      }
+      };
+      if (eepi == P5_EPI_RELU_DROP) { if (do_drop) pieces(P5EpiTag<2>{}); else pieces(P5EpiTag<1>{}); }
+      else if (eepi == P5_EPI_RESID_DROP) { if (do_drop) pieces(P5EpiTag<4>{}); else pieces(P5EpiTag<3>{}); }
+      else if (eepi == P5_EPI_MASK_POS) pieces(P5EpiTag<5>{});
+      else pieces(P5EpiTag<0>{});
       return;
     }
   }

@@ -1,0 +1,498 @@
+// p5_gemm5.h -- wave-specialised persistent GEMM: four LOADER waves feed a ring of K-steps in LDS, four COMPUTE waves multiply.
+//
+// Same contract and work-unit scheduling as p5_gemm4.h (bias-free nn.Linear forward / dgrad / wgrad of the T5 layers, HF
+// modeling_t5.py:83-94,205-208,304,325-326,367 and their autograd transposes).  Why another kernel: the ablated builds of
+// p5_gemm4_kernel (tools/lab, round 3) show that what limits every kernel here whose waves both copy and multiply is the ISSUE
+// cost of the direct-to-LDS copy -- one `global_load_lds_dwordx4` wave instruction moves 1 KiB and occupies its wave's (in-order)
+// issue for 60-185 cycles (MI355X_MICROARCH.md, per-instruction constants), the time of 4-11 MFMAs; with the copies in the MFMA
+// stream the chip never moves more than ~14 TB/s from L2 into LDS, whatever the ring depth.  The two instruction kinds issue in the
+// same cycle only from DIFFERENT waves of a SIMD.  Hence:
+//   * waves 4-7 (one per SIMD) only copy: each issues its 12 pieces of a 256x128 K-step (48 KiB) and waits for its share of the
+//     previous one; waves 0-3 (one per SIMD) only read fragments and issue MFMAs on 128x64 wave tiles -- 128 accumulator registers,
+//     0.375 fragment reads per MFMA instead of 0.5, which also takes the compute waves off the LDS-bandwidth bound of the 64x64
+//     wave tile;
+//   * one LDS-only barrier per K-step joins the two groups (copies of K-step s+1 landed / slot of K-step s-1 free);
+//   * the loaders run ahead of the compute waves by the depth of the ring, across work-unit boundaries: while the compute waves
+//     write a finished tile out (straight from the accumulators, as in p5_gemm4.h) the next unit's first K-steps are landing,
+//     and the epilogue's stores / residual loads share no vmcnt with any copy.
+#pragma once
+#include "p5_gemm4.h"
+
+template <bool KS, int ABL = 0>
+__global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
+  using T = bf16;
+  constexpr int BM = 256, BN = 128, NST = 3;
+  constexpr int NWC = 4, NWL = 4;                          // compute waves (2 x 2), loader waves
+  constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
+  constexpr int ASZ = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int NDA = BM / (8 * NWL), NDB = BN / (8 * NWL), NDMA = NDA + NDB;   // copy instructions per loader wave per K-step
+  constexpr int PFD = NST - 1;
+  constexpr int NMM = TM * TN;
+  static_assert(NST * STAGE <= 160 * 1024 && PFD * NDMA <= 56, "ring geometry");
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef P5_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+
+  // ---- this workgroup's units (as p5_gemm4.h): XCD x = blockIdx % 8 owns units [x*UPX, (x+1)*UPX), its workgroups take them round-robin ----
+  const int nwg = (int)gridDim.x;
+  const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3, gx = nwg >> 3;
+  const int upx = (grp.total_units + 7) >> 3;
+  const int ulast = upx < grp.total_units - xcd * upx ? upx : grp.total_units - xcd * upx;
+  const int nmy = ulast > jx ? (ulast - jx + gx - 1) / gx : 0;
+  if (nmy <= 0) return;
+
+  struct Unit { int pi, m0, n0, kb, nk; };
+  auto decode = [&](int it) {
+    Unit u;
+    const int id = xcd * upx + it * gx + jx;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < P5_MAX_GROUP; ++q)
+      if (q < grp.nprob && id >= grp.unit_begin[q]) pi = q;
+    const P5GemmArgs& g = grp.p[pi];
+    const int local = id - grp.unit_begin[pi];
+    const int sp = local % g.splitk, tile = local / g.splitk;
+    u.pi = pi;
+    u.m0 = (tile / g.g4_tiles_n) * BM;
+    u.n0 = (tile % g.g4_tiles_n) * BN;
+    u.nk = g.g4_nk;
+    u.kb = sp * g.g4_nk * 64;
+    return u;
+  };
+
+  if (wave >= NWC) {
+    // =========================================== loader waves ===========================================
+    const int lw = wave - NWC;
+    const T* srcA[NDA];
+    const T* srcB[NDB];
+    size_t incA = 0, incB = 0;
+    int c_it = 0, c_left = 0;
+    auto copy_setup = [&](int it) {
+      const Unit u = decode(it);
+      const P5GemmArgs& g = grp.p[u.pi];
+      c_left = u.nk;
+      if constexpr (KS) {
+        incA = (size_t)64 * g.lda; incB = (size_t)64 * g.ldb;
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) {
+          constexpr int CPR = BM / 8, RPI = 512 / BM;
+          const int krow = (lw * NDA + i) * RPI + lane / CPR;
+          int cg = (lane % CPR) ^ ksd_swz<BM>(krow);
+          const int cmax = (g.lda - u.m0) / 8 - 1;        // (row capacity of the k-row in memory, see stage_dma_ks)
+          cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
+          srcA[i] = (const T*)g.A + ((size_t)u.kb + krow) * g.lda + u.m0 + cg * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+          constexpr int CPR = BN / 8, RPI = 512 / BN;
+          const int krow = (lw * NDB + i) * RPI + lane / CPR;
+          int cg = (lane % CPR) ^ ksd_swz<BN>(krow);
+          const int cmax = (g.ldb - u.n0) / 8 - 1;
+          cg = cg < cmax ? cg : (cmax > 0 ? cmax : 0);
+          srcB[i] = (const T*)g.B + ((size_t)u.kb + krow) * g.ldb + u.n0 + cg * 8;
+        }
+      } else {
+        incA = 64; incB = 64;
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) {
+          const int row = (lw * NDA + i) * 8 + (lane >> 3);
+          int gr = u.m0 + row;
+          gr = gr < g.M ? gr : g.M - 1;
+          srcA[i] = (const T*)g.A + (size_t)gr * g.lda + u.kb + (((lane & 7) ^ g4_sigma_a(row)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+          const int row = (lw * NDB + i) * 8 + (lane >> 3);
+          int gr = u.n0 + row;
+          gr = gr < g.N ? gr : g.N - 1;
+          srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + u.kb + (((lane & 7) ^ g4_sigma_b(row)) * 8);
+        }
+      }
+    };
+    auto copy_stage = [&](int buf) {
+      char* b = lds + buf * STAGE;
+      if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) glds16_raw(srcA[i], b + (lw * NDA + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) glds16_raw(srcB[i], b + ASZ + (lw * NDB + i) * 1024);
+      }
+      if (--c_left > 0) {
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) srcA[i] += incA;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) srcB[i] += incB;
+      } else if (c_it + 1 < nmy) {
+        copy_setup(++c_it);
+      } else {
+        c_left = 1;                 // past the last unit: keep re-fetching its last K-step into free slots (constant vmcnt bookkeeping)
+      }
+    };
+    int total = 0;
+    for (int it = 0; it < nmy; ++it) total += decode(it).nk;
+    copy_setup(0);
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) copy_stage(q);
+    P5_WAIT_VM((PFD - 1) * NDMA);           // K-step 0 has landed
+    P5_BARRIER_LDS();
+    int buf = 0;
+    for (int g = 0; g < total; ++g) {
+      const int nb2 = buf == 0 ? NST - 1 : buf - 1;
+      copy_stage(nb2);                      // K-step g+PFD -> the slot of K-step g-1 (read out before the barrier every wave has passed)
+      P5_WAIT_VM((PFD - 1) * NDMA);         // this wave's share of K-step g+1 has landed
+      P5_BARRIER_LDS();
+      buf = buf == NST - 1 ? 0 : buf + 1;
+    }
+    P5_WAIT_VM(0);
+    return;
+  }
+
+  // =========================================== compute waves ===========================================
+  const int wm = wave >> 1, wn = wave & 1;
+  int offA[KS ? TM : 1], offB[KS ? TN : 1];
+  if constexpr (KS) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = ksd_lane_off<BM>(wm * WTM + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = ksd_lane_off<BN>(wn * WTN + j * 16, lane) + ASZ;
+  } else {
+    const int rowa = wm * WTM + (lane & 15);
+    offA[0] = rowa * 128 + (((lane >> 4) ^ g4_sigma_a(rowa)) << 4);
+    const int rowb = wn * WTN + ((lane & 15) >> 2) * 8 + (lane & 3);
+    offB[0] = ASZ + rowb * 128 + (((lane >> 4) ^ g4_sigma_b(rowb)) << 4);
+  }
+  auto frag = [&](int buf, bool is_b, int t, int c) -> u32x4 {
+    const char* p = lds + buf * STAGE;
+    if constexpr ((ABL & 4) != 0) { u32x4 z = {(unsigned)(buf + t), 1u, 2u, 3u}; return z; }
+    if constexpr (KS) {
+      const int off = is_b ? offB[is_b ? t : 0] : offA[is_b ? 0 : t], rbytes = is_b ? BN * 2 : BM * 2;
+      const u32x2 lo = lds_tr16_b64(p + off + c * 32 * rbytes), hi = lds_tr16_b64(p + off + c * 32 * rbytes + 4 * rbytes);
+      u32x4 r;
+      r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+      return r;
+    } else {
+      const int delta = is_b ? ((t >> 1) * 32 + (t & 1) * 4) * 128 : t * 16 * 128;
+      return ld16(p + ((is_b ? offB[0] : offA[0]) ^ (c << 6)) + delta);     // K-chunk 1 = slot index ^ 4
+    }
+  };
+
+  f32x4 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto mm = [&](f32x4& a, const u32x4& fa, const u32x4& fb) {
+    if constexpr ((ABL & 1) != 0) { a[0] += __builtin_bit_cast(float, fa[0] ^ fb[0]); }
+    else mma16<T>(a, fb, fa);     // operands swapped: lane <- C[m = 16 i + (lane & 15)][4 columns]  (p5_gemm4.h)
+  };
+
+  // one 16-row block of the 128x64 wave tile, constant row-block index (p5_gemm4.h epi_rows)
+  auto epi_rows = [&](const f32x4(&a)[TN], int i, const Unit& u, const P5GemmArgs& g, uint32_t seed, bool do_drop, bool vec_ok, int le) {
+    const int gl = le >> 4;
+    const int row = u.m0 + wm * WTM + i * 16 + (le & 15);
+    if constexpr (KS) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = u.n0 + wn * WTN + j * 16 + gl * 4;
+        if (row >= g.M || col >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = a[j][r] * g.alpha;
+        const size_t ci = (size_t)row * g.ldc + col;
+        if (g.c_f32 && col + 4 <= g.N && (g.ldc & 3) == 0) {
+          float* cp = (float*)g.C + ci;
+          if (g.epi == P5_EPI_ATOMIC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+          } else if (g.epi == P5_EPI_ACCUM) {
+            f32x4 c = *(const f32x4*)cp;
+            *(f32x4*)cp = (f32x4){c[0] + v[0], c[1] + v[1], c[2] + v[2], c[3] + v[3]};
+          } else {
+            *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (col + r >= g.N) continue;
+            if (g.epi == P5_EPI_ATOMIC) atomicAdd((float*)g.C + ci + r, v[r]);
+            else if (g.epi == P5_EPI_ACCUM) ((float*)g.C)[ci + r] += v[r];
+            else if (g.c_f32) ((float*)g.C)[ci + r] = v[r];
+            else ((T*)g.C)[ci + r] = from_f<T>(v[r]);
+          }
+        }
+      }
+    } else {
+      const bool row_ok = row < g.M;
+      float sc = g.alpha;
+      if (g.rowss) sc *= gemm_row_rstd(g, row_ok ? row : g.M - 1);
+      float ss = 0.f;
+#pragma unroll
+      for (int h = 0; h < TN / 2; ++h) {
+        const int col = u.n0 + wn * WTN + h * 32 + gl * 8;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = a[2 * h][r] * sc; v[4 + r] = a[2 * h + 1][r] * sc; }
+        if (row_ok && col < g.N) {
+          const size_t ci = (size_t)row * g.ldc + col;
+          const bool full = vec_ok && col + 8 <= g.N;
+          if (g.epi != P5_EPI_STORE && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = 0.f;
+            if (g.aux) {
+              const T* ap = (const T*)g.aux + (size_t)row * g.ldaux + col;
+              if (full) unpack16<T>(ld16(ap), av);
+              else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (col + e < g.N) av[e] = to_f<T>(ap[e]);
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gemm_epi_apply(g, v[e], av[e], seed, do_drop, row, col + e);
+          }
+          if (g.c_f32) {
+            float* cp = (float*)g.C + ci;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (col + e >= g.N) continue;
+              if (g.epi == P5_EPI_ATOMIC) atomicAdd(cp + e, v[e]);
+              else if (g.epi == P5_EPI_ACCUM) cp[e] += v[e];
+              else if (!full) cp[e] = v[e];
+            }
+            if (full && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
+              *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+            if (g.ssq_out) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (col + e < g.N) ss += v[e] * v[e];
+            }
+          } else {
+            const u32x4 packed = pack16<T>(v);
+            if (full) st16((T*)g.C + ci, packed);
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (col + e < g.N) ((T*)g.C)[ci + e] = from_f<T>(v[e]);
+            }
+            if (g.ssq_out) {
+              float w[8];
+              unpack16<T>(packed, w);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (col + e < g.N) ss += w[e] * w[e];
+            }
+          }
+        }
+      }
+      if (g.ssq_out) {          // (uniform) this wave is the only writer of the row's partial for its 64-column group
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (g.ssq_nt > 0) {
+          const int cg = (u.n0 + wn * WTN) >> 6;
+          if (gl == 0 && row_ok && cg < g.ssq_nt) g.ssq_out[(size_t)row * g.ssq_nt + cg] = ss;
+        } else if (gl == 0 && row_ok) {
+          atomicAdd(g.ssq_out + row, ss);
+        }
+      }
+    }
+  };
+  auto epilogue = [&](const Unit& u) {
+    if constexpr ((ABL & 8) != 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (s == 12345.678f) ((float*)grp.p[0].C)[0] = s;
+      return;
+    }
+    const P5GemmArgs& g = grp.p[u.pi];
+    const uint32_t seed = p5_seed(g.drop);
+    const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
+    const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
+    int le = lane;
+#ifndef P5_EMU
+    asm volatile("" : "+v"(le));      // (keeps hipcc from hoisting every lane-dependent output offset out of the unit loop)
+#endif
+    // Fast path: a whole tile inside the output, 16-byte stores.  Everything the eight row blocks need from the problem descriptor
+    // is read ONCE into scalars here: the general code below reads descriptor fields where it uses them, and with the accumulators
+    // holding the scalar registers' spill space hipcc re-issues those kernarg loads (s_load + lgkmcnt(0), ~100 ns each) in every
+    // row block -- measured 7-9 us per 256x128 tile, more than the tile's MFMAs (tools/lab lab4, round 3).
+    if constexpr (!KS) {
+      const int epi = g.epi, N = g.N, ldc = g.ldc, ldaux = g.ldaux;
+      float* const ssq = g.ssq_out;
+      const int ssq_nt = g.ssq_nt;
+      if (vec_ok && !g.c_f32 && u.m0 + BM <= g.M && u.n0 + BN <= N && epi != P5_EPI_ATOMIC && epi != P5_EPI_ACCUM && (ssq == nullptr || ssq_nt > 0)) {
+        const uint32_t skey = g.drop.site_key, thr = g.drop.thr;
+        const float dscale = g.drop.scale, alpha = g.alpha;
+        const float* const rowss = g.rowss;
+        const int rowss_nt = g.rowss_nt;
+        const float invd = g.rowss_invd, eps = g.rowss_eps;
+        const int gl = le >> 4;
+        int row = u.m0 + wm * WTM + (le & 15);
+        const int col0 = u.n0 + wn * WTN + gl * 8;
+        T* cp = (T*)g.C + (size_t)row * ldc + col0;
+        const T* ap = g.aux ? (const T*)g.aux + (size_t)row * ldaux + col0 : nullptr;
+        const uint32_t hseed = p5_mix32(seed + skey);
+        // EK: the epilogue kind as a compile-time constant (0 store, 1 ReLU, 2 ReLU + dropout, 3 + residual, 4 dropout + residual,
+        // 5 ReLU' mask) -- chosen ONCE per tile below: a per-element `if (epi == ...)` chain compiles to scalar branches (the
+        // dropout hash keeps hipcc from if-converting it), ~5 per element, 640 per tile.
+        auto rows = [&](auto ek, const f32x4(&a)[TN]) {
+          constexpr int EK = decltype(ek)::value;
+          float sc = alpha;
+          if (rowss) {
+            float ss;
+            if (rowss_nt > 0) {
+              const float* p = rowss + (size_t)row * rowss_nt;
+              ss = 0.f;
+              if ((rowss_nt & 3) == 0) {
+                for (int t = 0; t < rowss_nt; t += 4) {
+                  const f32x4 v = *(const f32x4*)(p + t);
+                  ss = (((ss + v[0]) + v[1]) + v[2]) + v[3];
+                }
+              } else {
+                for (int t = 0; t < rowss_nt; ++t) ss += p[t];
+              }
+            } else {
+              ss = rowss[row];
+            }
+            sc *= rsqrtf(ss * invd + eps);
+          }
+          u32x4 auxv[TN / 2];
+          if constexpr (EK >= 3) {
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h) auxv[h] = ap ? ld16(ap + h * 32) : (u32x4){0u, 0u, 0u, 0u};
+          }
+          float sq = 0.f;
+#pragma unroll
+          for (int h = 0; h < TN / 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = a[2 * h][r] * sc; v[4 + r] = a[2 * h + 1][r] * sc; }
+            if constexpr (EK != 0) {
+              float av[8];
+              if constexpr (EK >= 3) unpack16<T>(auxv[h], av);
+              const uint32_t idx0 = (uint32_t)(row * N + col0 + h * 32);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                if constexpr (EK == 1 || EK == 2) x = x > 0.f ? x : 0.f;
+                if constexpr (EK == 2 || EK == 4) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? x * dscale : 0.f;
+                if constexpr (EK == 3 || EK == 4) x += av[e];
+                if constexpr (EK == 5) x = av[e] > 0.f ? x : 0.f;
+                v[e] = x;
+              }
+            }
+            const u32x4 packed = pack16<T>(v);
+            st16(cp + h * 32, packed);
+            if (ssq) {
+              float w[8];
+              unpack16<T>(packed, w);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sq += w[e] * w[e];
+            }
+          }
+          if (ssq) {
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            const int cg = (u.n0 + wn * WTN) >> 6;
+            if (gl == 0 && cg < ssq_nt) ssq[(size_t)row * ssq_nt + cg] = sq;
+          }
+          cp += (size_t)16 * ldc;
+          if (ap) ap += (size_t)16 * ldaux;
+          row += 16;
+        };
+        auto all_rows = [&](auto ek) {
+          rows(ek, acc[0]); rows(ek, acc[1]); rows(ek, acc[2]); rows(ek, acc[3]); rows(ek, acc[4]); rows(ek, acc[5]); rows(ek, acc[6]); rows(ek, acc[7]);
+        };
+        if (epi == P5_EPI_RELU_DROP) { if (do_drop) all_rows(P5EpiTag<2>{}); else all_rows(P5EpiTag<1>{}); }
+        else if (epi == P5_EPI_RESID_DROP) { if (do_drop) all_rows(P5EpiTag<4>{}); else all_rows(P5EpiTag<3>{}); }
+        else if (epi == P5_EPI_MASK_POS) all_rows(P5EpiTag<5>{});
+        else all_rows(P5EpiTag<0>{});
+        return;
+      }
+    } else {
+      const int epi = g.epi, ldc = g.ldc;
+      if (g.c_f32 && (ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && u.m0 + BM <= g.M && u.n0 + BN <= g.N && (epi == P5_EPI_ACCUM || epi == P5_EPI_STORE)) {
+        const float alpha = g.alpha;
+        float* cp = (float*)g.C + (size_t)(u.m0 + wm * WTM + (le & 15)) * ldc + (u.n0 + wn * WTN + (le >> 4) * 4);
+        auto rows = [&](const f32x4(&a)[TN]) {
+          f32x4 c[TN];
+          if (epi == P5_EPI_ACCUM) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) c[j] = *(const f32x4*)(cp + j * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              *(f32x4*)(cp + j * 16) = (f32x4){c[j][0] + a[j][0] * alpha, c[j][1] + a[j][1] * alpha, c[j][2] + a[j][2] * alpha, c[j][3] + a[j][3] * alpha};
+          } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *(f32x4*)(cp + j * 16) = (f32x4){a[j][0] * alpha, a[j][1] * alpha, a[j][2] * alpha, a[j][3] * alpha};
+          }
+          cp += (size_t)16 * ldc;
+        };
+        rows(acc[0]); rows(acc[1]); rows(acc[2]); rows(acc[3]); rows(acc[4]); rows(acc[5]); rows(acc[6]); rows(acc[7]);
+        return;
+      }
+    }
+    epi_rows(acc[0], 0, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[1], 1, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[2], 2, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[3], 3, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[4], 4, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[5], 5, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[6], 6, u, g, seed, do_drop, vec_ok, le);
+    epi_rows(acc[7], 7, u, g, seed, do_drop, vec_ok, le);
+  };
+
+  // Both operands' fragments double-buffered (96 registers): the 12 reads of the next K-chunk go out under the first 24 of a
+  // chunk's 32 MFMAs, so the `lgkmcnt(0)` in front of the mid-step barrier (slot `buf` must be read out before a loader may
+  // overwrite it) finds nothing outstanding.
+  u32x4 fa0[TM], fa1[TM], fb0[TN], fb1[TN];
+  auto half = [&](u32x4(&fa)[TM], u32x4(&fb)[TN], u32x4(&na)[TM], u32x4(&nb)[TN], int nbuf, int nc) {
+    P5_SCHED_FENCE();
+#pragma unroll
+    for (int t = 0; t < NMM; ++t) {
+      const int i = t / TN, j = t % TN;
+      mm(acc[i][j], fa[i], fb[j]);
+      P5_SCHED_FENCE();
+      if ((t & 1) == 0 && t / 2 < TM + TN) {
+        const int r = t / 2;          // read order: B0 A0 B1 B2 B3 A1 .. A7 (what the next chunk's first MFMAs need first)
+        if (r == 0) nb[0] = frag(nbuf, true, 0, nc);
+        else if (r == 1) na[0] = frag(nbuf, false, 0, nc);
+        else if (r < 1 + TN) nb[r - 1] = frag(nbuf, true, r - 1, nc);
+        else na[r - TN] = frag(nbuf, false, r - TN, nc);
+        P5_SCHED_FENCE();
+      }
+    }
+  };
+  auto step = [&](int buf, int nb1) {
+    half(fa0, fb0, fa1, fb1, buf, 1);
+    P5_BARRIER_LDS();                     // K-step s+1 has landed (the loaders waited for their copies); slot `buf` is fully read
+    half(fa1, fb1, fa0, fb0, nb1, 0);
+  };
+
+  P5_BARRIER_LDS();                       // K-step 0 has landed
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb0[j] = frag(0, true, j, 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa0[i] = frag(0, false, i, 0);
+  zero_acc();
+  int buf = 0;
+  for (int it = 0; it < nmy; ++it) {
+    const Unit u = decode(it);
+    int k = 0;
+    do {
+      const int nb1 = buf == NST - 1 ? 0 : buf + 1;
+      step(buf, nb1);
+      buf = nb1;
+    } while (++k < u.nk);
+    epilogue(u);
+    zero_acc();
+  }
+}

@@ -16,6 +16,7 @@
 #include "p5_rng.h"
 #include "p5_gemm.h"
 #include "p5_gemm4.h"
+#include "p5_gemm5.h"
 #include "p5_attn.h"
 #include "p5_elem.h"
 #include "p5_decode.h"
@@ -129,7 +130,8 @@ static int g_opt_gemm_wide_min_tiles = getenv("P5_GEMM_WIDE_MIN_TILES") ? atoi(g
 static int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RING_N512")) : 1;   // ring kernel for N = d_model, K >= 1024
 static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
 static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
-enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2 };
+static int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
+enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2, P5_G5_256x128 = 3 };
 template <int BM, int BN, int WMW, int WNW, int NST, bool KS, int OCC = 1>
 static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   int units = 0;
@@ -153,8 +155,31 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
   return P5_KCHECK();
 }
+template <bool KS>
+static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit bookkeeping as launch_gemm4_cfg<256, 128, ...>, 4 loader + 4 compute waves
+  int units = 0;
+  for (int i = 0; i < grp.nprob; ++i) {
+    P5GemmArgs& g = grp.p[i];
+    if (g.splitk < 1) g.splitk = 1;
+    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm5: K must be a multiple of 64 x split-K");
+    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm5: operand alignment");
+    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm5: split-K needs the atomic epilogue");
+    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm5: accumulate epilogues need fp32 C");
+    g.g4_tiles_n = (g.N + 127) / 128;
+    g.g4_nk = g.K / 64 / g.splitk;
+    grp.unit_begin[i] = units;
+    units += ((g.M + 255) / 256) * g.g4_tiles_n * g.splitk;
+  }
+  grp.unit_begin[grp.nprob] = units;
+  grp.total_units = units;
+  int nwg = ((units + 7) / 8) * 8;
+  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
+  P5_LAUNCH((p5_gemm5_kernel<KS>), dim3(nwg), dim3(512), 0, s, grp);
+  return P5_KCHECK();
+}
 static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
   P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
+  if (cfg == P5_G5_256x128 || (cfg == P5_G4_256x128 && (g_opt_gemm_ws & (ks ? 2 : 1)))) return ks ? launch_gemm5<true>(grp, s) : launch_gemm5<false>(grp, s);
   if (ks) {
     if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, true>(grp, s);
     P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 or 256x128 tiles");
@@ -1732,6 +1757,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "wgrad_layers")) g_opt_wgrad_layers = value;
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
+  else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
   else if (!strcmp(name, "g4_wgs")) g_opt_g4_wgs = value;
   else return fail("p5_set_option: unknown option");

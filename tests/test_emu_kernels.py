@@ -67,6 +67,24 @@ def test_gemm_persistent_ring_wgrad_256x128(emu):
     cases.gemm_group_case(emu, 1, 1, probs, wgs=8)
 
 
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_wave_specialised(emu, wgs):
+    """p5_gemm5.h (four loader waves + four compute waves on 128x64 wave tiles), K-contiguous: grouped problems, units crossing
+    workgroup rounds, ragged M / N, one to ten K-steps, every epilogue incl. dropout."""
+    probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1), (40, 72, 192, 3, 0, 1), (264, 72, 640, 4, 1, 2),
+             (72, 100, 128, 0, 1, 1), (136, 64, 256, 6, 1, 1)]
+    cases.gemm_group_case(emu, 3, 0, probs, wgs=wgs, drop_p=0.1)
+    whole_tiles = [(512, 256, 128, 1, 0, 1), (256, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (512, 128, 128, 0, 0, 1), (300, 256, 64, 2, 0, 1)]
+    cases.gemm_group_case(emu, 3, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=1)      # (the descriptor-hoisted epilogue of whole tiles)
+
+
+def test_gemm_wave_specialised_wgrad(emu):
+    """p5_gemm5.h on two K-strided operands (grouped weight gradients): C +=, split-K atomics, plain store; ragged outputs."""
+    probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1), (8, 8, 64, 4, 1, 1)]
+    cases.gemm_group_case(emu, 3, 1, probs, wgs=8)
+    cases.gemm_group_case(emu, 3, 1, [(256, 128, 128, 6, 1, 1), (512, 256, 192, 0, 1, 1), (296, 256, 64, 6, 1, 1)], wgs=8, seed=1)
+
+
 @pytest.mark.parametrize("nst,wgs", [(5, 256), (3, 8), (2, 8)])
 def test_gemm_persistent_ring_wgrad(emu, nst, wgs):
     """p5_gemm4.h, both operands K-strided (weight gradients): grouped, no split-K with C += (epi 6), split-K with atomics (epi 4),

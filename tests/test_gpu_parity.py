@@ -323,6 +323,30 @@ def test_gemm_persistent_ring_wgrad_256x128(hip):
     cases.gemm_group_case(hip, 1, 1, two_layers)
 
 
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_wave_specialised(hip, wgs):
+    """p5_gemm5.h on the hardware: loader waves running the direct-to-LDS ring ahead of the compute waves (one barrier per K-step,
+    across unit boundaries), 128x64 wave tiles; grouped ragged problems with every epilogue, then the benchmark step's shapes."""
+    probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1), (40, 72, 192, 3, 0, 1), (264, 72, 640, 4, 1, 2),
+             (72, 100, 128, 0, 1, 1), (136, 64, 256, 6, 1, 1)]
+    whole_tiles = [(512, 256, 128, 1, 0, 1), (256, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (512, 128, 128, 0, 0, 1), (300, 256, 64, 2, 0, 1)]
+    for rep in range(3):
+        cases.gemm_group_case(hip, 3, 0, probs, wgs=wgs, drop_p=0.1, seed=rep)
+        cases.gemm_group_case(hip, 3, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=rep)
+    for rep in range(2):
+        cases.gemm_group_case(hip, 3, 0, [(8192, 2048, 512, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
+        cases.gemm_group_case(hip, 3, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
+
+
+def test_gemm_wave_specialised_wgrad(hip):
+    probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1), (8, 8, 64, 4, 1, 1)]
+    for rep in range(3):
+        cases.gemm_group_case(hip, 3, 1, probs, wgs=8, seed=rep)
+        cases.gemm_group_case(hip, 3, 1, [(256, 128, 128, 6, 1, 1), (512, 256, 192, 0, 1, 1), (296, 256, 64, 6, 1, 1)], wgs=8, seed=rep)
+    two_layers = [(512, 2048, 8192, 6, 1, 1), (2048, 512, 8192, 6, 1, 1), (512, 512, 8192, 6, 1, 1), (1536, 512, 8192, 6, 1, 1)] * 2
+    cases.gemm_group_case(hip, 3, 1, two_layers)
+
+
 def test_gemm_persistent_ring_wgrad_layer_group(hip):
     """the four weight gradients of one T5-small encoder layer over 8192 tokens as ONE launch, no split-K, C += acc."""
     probs = [(512, 2048, 8192, 6, 1, 1), (2048, 512, 8192, 6, 1, 1), (512, 512, 8192, 6, 1, 1), (1536, 512, 8192, 6, 1, 1)]

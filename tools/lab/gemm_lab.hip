@@ -12,6 +12,7 @@
 #include <functional>
 #include <algorithm>
 #include "p5_gemm4.h"
+#include "p5_gemm5.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -129,6 +130,27 @@ static void launch_g4(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > max_wg) nwg = max_wg;
   hipLaunchKernelGGL((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, ABL, OCC, FLAGS>), dim3(nwg), dim3(WMW * WNW * 64), 0, 0, grp);
+}
+template <bool KS, int ABL = 0>
+static void launch_g5(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
+  P5GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.nprob = (int)gs.size();
+  int units = 0;
+  for (int i = 0; i < grp.nprob; ++i) {
+    P5GemmArgs g = gs[i];
+    const int tm = (g.M + 255) / 256, tn = (g.N + 127) / 128;
+    g.g4_tiles_n = tn;
+    g.g4_nk = g.K / 64 / g.splitk;
+    grp.unit_begin[i] = units;
+    units += tm * tn * g.splitk;
+    grp.p[i] = g;
+  }
+  grp.unit_begin[grp.nprob] = units;
+  grp.total_units = units;
+  int nwg = ((units + 7) / 8) * 8;
+  if (nwg > max_wg) nwg = max_wg;
+  hipLaunchKernelGGL((p5_gemm5_kernel<KS, ABL>), dim3(nwg), dim3(512), 0, 0, grp);
 }
 template <int BM, int BN>
 static void set_rect(P5GemmArgs& g) {     // the launcher's XCD rectangle choice (p5_lib.hip::launch_gemm_tile)
@@ -332,6 +354,55 @@ int main(int argc, char** argv) {
     bench("128x256 8w NST=3, two layers (192 units)", ps2, [&] { launch_g4<128, 256, 2, 4, 3, true>(g8); }, true);
     bench("  abl 256x128 two layers: copies only", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 5>(g8); }, true);
     bench("  abl 256x128 two layers: MFMA + reads", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 10>(g8); }, true);
+  }
+  if (!strcmp(which, "lab4")) {
+    const int fshapes[][3] = {{8192, 2048, 512}, {8192, 1536, 512}, {8192, 512, 2048}, {8192, 512, 512}, {8192, 3072, 768}, {8192, 768, 3072}, {8192, 4096, 1024},
+                              {8192, 8192, 2048}, {8000, 2000, 512}};
+    for (auto& s : fshapes) {
+      Prob p = make_prob(s[0], s[1], s[2], 0, 0, P5_EPI_STORE, 11);
+      printf("FWD4 M=%d N=%d K=%d (bf16 C)\n", s[0], s[1], s[2]);
+      P5GemmArgs g = args_of(p);
+      bench("g4 256x128 8w NST=3", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({g}); }, false);
+      bench("g5 256x128 4 compute + 4 loader waves", {p}, [&] { launch_g5<false>({g}); }, false);
+      {
+        static uint32_t* d_state = nullptr;
+        if (!d_state) { CK(hipMalloc(&d_state, 8)); uint32_t h[2] = {77, 3}; CK(hipMemcpy(d_state, h, 8, hipMemcpyHostToDevice)); }
+        P5GemmArgs gd = g;
+        gd.epi = P5_EPI_RELU_DROP; gd.drop.state = d_state; gd.drop.site_key = p5_site_key(5); gd.drop.thr = p5_drop_thr(0.1f); gd.drop.scale = 1.f / 0.9f;
+        bench("g4 256x128, ReLU + dropout epilogue (timing only)", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({gd}); }, false);
+        bench("g5 256x128, ReLU + dropout epilogue (timing only)", {p}, [&] { launch_g5<false>({gd}); }, false);
+        P5GemmArgs gr = g;
+        gr.epi = P5_EPI_RESID_DROP; gr.drop = gd.drop; gr.aux = p.C; gr.ldaux = p.N;
+        bench("g4 256x128, dropout + residual epilogue (timing only)", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({gr}); }, false);
+        bench("g5 256x128, dropout + residual epilogue (timing only)", {p}, [&] { launch_g5<false>({gr}); }, false);
+      }
+      if (s[1] == 2048 || s[1] == 8192) {
+        bench("  g5 abl: no MFMA", {p}, [&] { launch_g5<false, 1>({g}); }, false);
+        bench("  g5 abl: no copies", {p}, [&] { launch_g5<false, 2>({g}); }, false);
+        bench("  g5 abl: no frag reads", {p}, [&] { launch_g5<false, 4>({g}); }, false);
+        bench("  g5 abl: no epilogue", {p}, [&] { launch_g5<false, 8>({g}); }, false);
+        bench("  g5 abl: copies only", {p}, [&] { launch_g5<false, 5>({g}); }, false);
+        bench("  g5 abl: MFMA + reads", {p}, [&] { launch_g5<false, 10>({g}); }, false);
+        bench("  g5 abl: MFMA only", {p}, [&] { launch_g5<false, 14>({g}); }, false);
+      }
+      CK(hipFree(p.A)); CK(hipFree(p.B)); CK(hipFree(p.C)); CK(hipFree(p.ref));
+    }
+    const int shapes[][2] = {{2048, 512}, {512, 2048}, {1536, 512}, {512, 512}};
+    std::vector<Prob> ps;
+    for (auto& s : shapes) ps.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 23 + s[0]));
+    std::vector<Prob> ps2 = ps;
+    for (auto& s : shapes) ps2.push_back(make_prob(s[0], s[1], 8192, 1, 1, P5_EPI_ATOMIC, 77 + s[0]));
+    std::vector<P5GemmArgs> g4, g8;
+    for (Prob& p : ps) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; g4.push_back(g); }
+    for (Prob& p : ps2) { P5GemmArgs g = args_of(p, 1); g.epi = P5_EPI_ACCUM; g8.push_back(g); }
+    printf("WGRAD4: one layer (4 problems) / two layers (8 problems) per launch\n");
+    bench("g4 256x128 8w NST=3, one layer (96 units)", ps, [&] { launch_g4<256, 128, 4, 2, 3, true>(g4); }, true);
+    bench("g5 256x128, one layer (96 units)", ps, [&] { launch_g5<true>(g4); }, true);
+    bench("g4 256x128 8w NST=3, two layers (192 units)", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true>(g8); }, true);
+    bench("g5 256x128, two layers (192 units)", ps2, [&] { launch_g5<true>(g8); }, true);
+    bench("  g5 abl two layers: copies only", ps2, [&] { launch_g5<true, 5>(g8); }, true);
+    bench("  g5 abl two layers: MFMA + reads", ps2, [&] { launch_g5<true, 10>(g8); }, true);
+    bench("  g5 abl two layers: MFMA only", ps2, [&] { launch_g5<true, 14>(g8); }, true);
   }
   printf("done\n");
   return 0;
