@@ -407,6 +407,39 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
   }
 
   // ---- direct epilogue: lane owns C[row = (lane>>4)*4 + r][col = lane & 15] of every 16x16 tile ----
+  // fp32 outputs without auxiliary operand (weight gradients: store / atomic add / accumulate): the kind is a compile-time
+  // constant of the loop nest and the descriptor is read once -- the general nest below decides everything per element, about
+  // ten scalar branches each.
+  if (g.c_f32 && g.aux == nullptr && g.ssq_out == nullptr && g.rowss == nullptr &&
+      (g.epi == P5_EPI_STORE || g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM)) {
+    const int eM = g.M, eN = g.N, eldc = g.ldc;
+    const float ealpha = g.alpha;
+    float* const eC = (float*)g.C;
+    auto nest = [&](auto ek) {
+      constexpr int EK = decltype(ek)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * (BM / WMW) + i * 16 + (lane >> 4) * 4 + r;
+          float* const crow = eC + (size_t)row * eldc;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WNW) + j * 16 + (lane & 15);
+            if (row < eM && col < eN) {
+              const float v = acc[i][j][r] * ealpha;
+              if constexpr (EK == P5_EPI_ATOMIC) atomicAdd(crow + col, v);
+              else if constexpr (EK == P5_EPI_ACCUM) crow[col] += v;
+              else crow[col] = v;
+            }
+          }
+        }
+    };
+    if (g.epi == P5_EPI_ATOMIC) nest(P5EpiTag<P5_EPI_ATOMIC>{});
+    else if (g.epi == P5_EPI_ACCUM) nest(P5EpiTag<P5_EPI_ACCUM>{});
+    else nest(P5EpiTag<P5_EPI_STORE>{});
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -302,7 +302,32 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       }
     }
   };
-  auto epilogue = [&](const Unit& u) {
+  // what the whole-tile epilogue needs from the problem descriptor, as scalars
+  struct EpiCtx {
+    void* C; const void* aux; float* ssq; const float* rowss;
+    int epi, N, ldc, ldaux, ssq_nt, rowss_nt;
+    uint32_t thr, hseed;
+    float dscale, alpha, invd, eps;
+    bool fast, do_drop;
+  };
+  auto load_ctx = [&](const Unit& u) {
+    const P5GemmArgs& g = grp.p[u.pi];
+    EpiCtx c;
+    c.C = g.C; c.aux = g.aux; c.ssq = g.ssq_out; c.rowss = g.rowss;
+    c.epi = g.epi; c.N = g.N; c.ldc = g.ldc; c.ldaux = g.ldaux; c.ssq_nt = g.ssq_nt; c.rowss_nt = g.rowss_nt;
+    c.thr = g.drop.thr; c.dscale = g.drop.scale; c.alpha = g.alpha; c.invd = g.rowss_invd; c.eps = g.rowss_eps;
+    c.do_drop = g.drop.state != nullptr && g.drop.thr != 0;
+    c.hseed = p5_mix32(p5_seed(g.drop) + g.drop.site_key);
+    const bool inside = u.m0 + BM <= g.M && u.n0 + BN <= g.N;
+    if constexpr (KS) {
+      c.fast = inside && g.c_f32 && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.epi == P5_EPI_ACCUM || g.epi == P5_EPI_STORE);
+    } else {
+      const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
+      c.fast = inside && vec_ok && !g.c_f32 && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM && (g.ssq_out == nullptr || g.ssq_nt > 0);
+    }
+    return c;
+  };
+  auto epilogue = [&](const Unit& u, const EpiCtx& cx) {
     if constexpr ((ABL & 8) != 0) {
       float s = 0.f;
 #pragma unroll
@@ -312,34 +337,30 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       if (s == 12345.678f) ((float*)grp.p[0].C)[0] = s;
       return;
     }
-    const P5GemmArgs& g = grp.p[u.pi];
-    const uint32_t seed = p5_seed(g.drop);
-    const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
-    const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
     int le = lane;
 #ifndef P5_EMU
     asm volatile("" : "+v"(le));      // (keeps hipcc from hoisting every lane-dependent output offset out of the unit loop)
 #endif
     // Fast path: a whole tile inside the output, 16-byte stores.  Everything the eight row blocks need from the problem descriptor
-    // is read ONCE into scalars here: the general code below reads descriptor fields where it uses them, and with the accumulators
-    // holding the scalar registers' spill space hipcc re-issues those kernarg loads (s_load + lgkmcnt(0), ~100 ns each) in every
-    // row block -- measured 7-9 us per 256x128 tile, more than the tile's MFMAs (tools/lab lab4, round 3).
-    if constexpr (!KS) {
-      const int epi = g.epi, N = g.N, ldc = g.ldc, ldaux = g.ldaux;
-      float* const ssq = g.ssq_out;
-      const int ssq_nt = g.ssq_nt;
-      if (vec_ok && !g.c_f32 && u.m0 + BM <= g.M && u.n0 + BN <= N && epi != P5_EPI_ATOMIC && epi != P5_EPI_ACCUM && (ssq == nullptr || ssq_nt > 0)) {
-        const uint32_t skey = g.drop.site_key, thr = g.drop.thr;
-        const float dscale = g.drop.scale, alpha = g.alpha;
-        const float* const rowss = g.rowss;
-        const int rowss_nt = g.rowss_nt;
-        const float invd = g.rowss_invd, eps = g.rowss_eps;
+    // was read ONCE into scalars (EpiCtx): the general code below reads descriptor
+    // fields where it uses them, and with the accumulators holding the scalar registers' spill space hipcc re-issues those kernarg
+    // loads (s_load + lgkmcnt(0), ~100 ns each) in every row block -- measured 7-9 us per 256x128 tile, more than the tile's
+    // MFMAs (tools/lab lab4, round 3).
+    if (cx.fast) {
+      if constexpr (!KS) {
+        const int epi = cx.epi, N = cx.N, ldc = cx.ldc, ldaux = cx.ldaux;
+        float* const ssq = cx.ssq;
+        const int ssq_nt = cx.ssq_nt;
+        const uint32_t thr = cx.thr, hseed = cx.hseed;
+        const float dscale = cx.dscale, alpha = cx.alpha;
+        const float* const rowss = cx.rowss;
+        const int rowss_nt = cx.rowss_nt;
+        const float invd = cx.invd, eps = cx.eps;
         const int gl = le >> 4;
         int row = u.m0 + wm * WTM + (le & 15);
         const int col0 = u.n0 + wn * WTN + gl * 8;
-        T* cp = (T*)g.C + (size_t)row * ldc + col0;
-        const T* ap = g.aux ? (const T*)g.aux + (size_t)row * ldaux + col0 : nullptr;
-        const uint32_t hseed = p5_mix32(seed + skey);
+        T* cp = (T*)cx.C + (size_t)row * ldc + col0;
+        const T* ap = cx.aux ? (const T*)cx.aux + (size_t)row * ldaux + col0 : nullptr;
         // EK: the epilogue kind as a compile-time constant (0 store, 1 ReLU, 2 ReLU + dropout, 3 + residual, 4 dropout + residual,
         // 5 ReLU' mask) -- chosen ONCE per tile below: a per-element `if (epi == ...)` chain compiles to scalar branches (the
         // dropout hash keeps hipcc from if-converting it), ~5 per element, 640 per tile.
@@ -390,7 +411,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
               }
             }
             const u32x4 packed = pack16<T>(v);
-            st16(cp + h * 32, packed);
+            if constexpr ((ABL & 16) != 0) { if (packed[0] == 0x12345678u) st16(cp + h * 32, packed); }      // (lab: epilogue math without the stores)
+            else st16(cp + h * 32, packed);
             if (ssq) {
               float w[8];
               unpack16<T>(packed, w);
@@ -411,17 +433,14 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         auto all_rows = [&](auto ek) {
           rows(ek, acc[0]); rows(ek, acc[1]); rows(ek, acc[2]); rows(ek, acc[3]); rows(ek, acc[4]); rows(ek, acc[5]); rows(ek, acc[6]); rows(ek, acc[7]);
         };
-        if (epi == P5_EPI_RELU_DROP) { if (do_drop) all_rows(P5EpiTag<2>{}); else all_rows(P5EpiTag<1>{}); }
-        else if (epi == P5_EPI_RESID_DROP) { if (do_drop) all_rows(P5EpiTag<4>{}); else all_rows(P5EpiTag<3>{}); }
+        if (epi == P5_EPI_RELU_DROP) { if (cx.do_drop) all_rows(P5EpiTag<2>{}); else all_rows(P5EpiTag<1>{}); }
+        else if (epi == P5_EPI_RESID_DROP) { if (cx.do_drop) all_rows(P5EpiTag<4>{}); else all_rows(P5EpiTag<3>{}); }
         else if (epi == P5_EPI_MASK_POS) all_rows(P5EpiTag<5>{});
         else all_rows(P5EpiTag<0>{});
-        return;
-      }
-    } else {
-      const int epi = g.epi, ldc = g.ldc;
-      if (g.c_f32 && (ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && u.m0 + BM <= g.M && u.n0 + BN <= g.N && (epi == P5_EPI_ACCUM || epi == P5_EPI_STORE)) {
-        const float alpha = g.alpha;
-        float* cp = (float*)g.C + (size_t)(u.m0 + wm * WTM + (le & 15)) * ldc + (u.n0 + wn * WTN + (le >> 4) * 4);
+      } else {
+        const int epi = cx.epi, ldc = cx.ldc;
+        const float alpha = cx.alpha;
+        float* cp = (float*)cx.C + (size_t)(u.m0 + wm * WTM + (le & 15)) * ldc + (u.n0 + wn * WTN + (le >> 4) * 4);
         auto rows = [&](const f32x4(&a)[TN]) {
           f32x4 c[TN];
           if (epi == P5_EPI_ACCUM) {
@@ -437,9 +456,13 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           cp += (size_t)16 * ldc;
         };
         rows(acc[0]); rows(acc[1]); rows(acc[2]); rows(acc[3]); rows(acc[4]); rows(acc[5]); rows(acc[6]); rows(acc[7]);
-        return;
       }
+      return;
     }
+    const P5GemmArgs& g = grp.p[u.pi];
+    const uint32_t seed = p5_seed(g.drop);
+    const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
+    const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
     epi_rows(acc[0], 0, u, g, seed, do_drop, vec_ok, le);
     epi_rows(acc[1], 1, u, g, seed, do_drop, vec_ok, le);
     epi_rows(acc[2], 2, u, g, seed, do_drop, vec_ok, le);
@@ -492,7 +515,9 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       step(buf, nb1);
       buf = nb1;
     } while (++k < u.nk);
-    epilogue(u);
+    // (forcing the descriptor scalars into registers before the K loop -- an asm pin after the first K-step -- was measured:
+    //  the 24 live scalars spill through a vector register's lanes and the main loop slows from 14.8 to 20 us on 8192x2048x512)
+    epilogue(u, load_ctx(u));
     zero_acc();
   }
 }

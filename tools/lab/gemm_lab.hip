@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "p5_gemm4.h"
 #include "p5_gemm5.h"
+#include "p5_gemm6_experimental.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -151,6 +152,46 @@ static void launch_g5(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > max_wg) nwg = max_wg;
   hipLaunchKernelGGL((p5_gemm5_kernel<KS, ABL>), dim3(nwg), dim3(512), 0, 0, grp);
+}
+// write probe: `nwg` workgroups of 256 threads write `bytes` of bf16 output.  mode 0: every wave instruction one contiguous 1 KiB;
+// mode 1: the register epilogue's pattern (a wave instruction = 16 rows x 64 bytes, row pitch `pitch` bytes); mode 2: 4 rows x 256 bytes
+__global__ __launch_bounds__(256) void write_probe(char* out, size_t bytes, int mode, int pitch) {
+  const size_t nchunk = bytes / 1024;                 // 1 KiB per wave instruction
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
+  const u32x4 v = {(unsigned)lane, 2u, 3u, 4u};
+  for (size_t c = wave; c < nchunk; c += nwave) {
+    size_t off;
+    if (mode == 0) off = c * 1024 + lane * 16;
+    else if (mode == 1) {          // chunk c: rows (c / (pitch/64)) * 16 .. +15, 64-byte column segment c % (pitch/64)
+      const size_t segs = pitch / 64, rb = c / segs, sg = c % segs;
+      off = (rb * 16 + (lane & 15)) * (size_t)pitch + sg * 64 + (lane >> 4) * 16;
+    } else {
+      const size_t segs = pitch / 256, rb = c / segs, sg = c % segs;
+      off = (rb * 4 + (lane >> 4)) * (size_t)pitch + sg * 256 + (lane & 15) * 16;
+    }
+    *(u32x4*)(out + off) = v;
+  }
+}
+template <int ABL = 0>
+static void launch_g6(const std::vector<P5GemmArgs>& gs, int max_wg = 256) {
+  P5GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.nprob = (int)gs.size();
+  int units = 0;
+  for (int i = 0; i < grp.nprob; ++i) {
+    P5GemmArgs g = gs[i];
+    g.g4_tiles_n = g.N / 128;
+    g.g4_nk = g.K / 32;
+    grp.unit_begin[i] = units;
+    units += (g.M / 256) * g.g4_tiles_n;
+    grp.p[i] = g;
+  }
+  grp.unit_begin[grp.nprob] = units;
+  grp.total_units = units;
+  int nwg = ((units + 7) / 8) * 8;
+  if (nwg > max_wg) nwg = max_wg;
+  hipLaunchKernelGGL((p5_gemm6_kernel<ABL>), dim3(nwg), dim3(512), 0, 0, grp);
 }
 template <int BM, int BN>
 static void set_rect(P5GemmArgs& g) {     // the launcher's XCD rectangle choice (p5_lib.hip::launch_gemm_tile)
@@ -355,6 +396,28 @@ int main(int argc, char** argv) {
     bench("  abl 256x128 two layers: copies only", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 5>(g8); }, true);
     bench("  abl 256x128 two layers: MFMA + reads", ps2, [&] { launch_g4<256, 128, 4, 2, 3, true, 10>(g8); }, true);
   }
+  if (!strcmp(which, "lab4") || !strcmp(which, "wprobe")) {
+    char* buf;
+    const size_t bytes = (size_t)8192 * 2048 * 2;
+    CK(hipMalloc(&buf, bytes * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("WRITE PROBE: %.1f MB of output per launch (8192 x 2048 bf16), 30 launches back to back\n", bytes / 1e6);
+    for (int rot = 0; rot < 2; ++rot)
+      for (int mode = 0; mode < 3; ++mode)
+        for (int nwg : {256, 1024, 4096}) {
+          for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(write_probe, dim3(nwg), dim3(256), 0, 0, buf, bytes, mode, 4096);
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(write_probe, dim3(nwg), dim3(256), 0, 0, buf + (rot ? (size_t)(i % 8) * bytes : 0), bytes, mode, 4096);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          printf("  mode %d (%s) wgs %4d %s: %6.1f us  %.2f TB/s\n", mode, mode == 0 ? "1 KiB contiguous" : mode == 1 ? "16 rows x 64 B" : "4 rows x 256 B", nwg,
+                 rot ? "rotating over 8 buffers" : "same buffer", ms * 1e3 / 30, bytes / (ms * 1e-3 / 30) / 1e12);
+        }
+    CK(hipFree(buf));
+  }
   if (!strcmp(which, "lab4")) {
     const int fshapes[][3] = {{8192, 2048, 512}, {8192, 1536, 512}, {8192, 512, 2048}, {8192, 512, 512}, {8192, 3072, 768}, {8192, 768, 3072}, {8192, 4096, 1024},
                               {8192, 8192, 2048}, {8000, 2000, 512}};
@@ -364,6 +427,8 @@ int main(int argc, char** argv) {
       P5GemmArgs g = args_of(p);
       bench("g4 256x128 8w NST=3", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({g}); }, false);
       bench("g5 256x128 4 compute + 4 loader waves", {p}, [&] { launch_g5<false>({g}); }, false);
+      const bool g6ok = s[0] % 256 == 0 && s[1] % 128 == 0;
+      if (g6ok) bench("g6 256x128 loaders drain the tiles", {p}, [&] { launch_g6<0>({g}); }, false);
       {
         static uint32_t* d_state = nullptr;
         if (!d_state) { CK(hipMalloc(&d_state, 8)); uint32_t h[2] = {77, 3}; CK(hipMemcpy(d_state, h, 8, hipMemcpyHostToDevice)); }
@@ -371,16 +436,25 @@ int main(int argc, char** argv) {
         gd.epi = P5_EPI_RELU_DROP; gd.drop.state = d_state; gd.drop.site_key = p5_site_key(5); gd.drop.thr = p5_drop_thr(0.1f); gd.drop.scale = 1.f / 0.9f;
         bench("g4 256x128, ReLU + dropout epilogue (timing only)", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({gd}); }, false);
         bench("g5 256x128, ReLU + dropout epilogue (timing only)", {p}, [&] { launch_g5<false>({gd}); }, false);
+        if (g6ok) bench("g6 256x128, ReLU + dropout epilogue (timing only)", {p}, [&] { launch_g6<0>({gd}); }, false);
         P5GemmArgs gr = g;
         gr.epi = P5_EPI_RESID_DROP; gr.drop = gd.drop; gr.aux = p.C; gr.ldaux = p.N;
         bench("g4 256x128, dropout + residual epilogue (timing only)", {p}, [&] { launch_g4<256, 128, 4, 2, 3, false>({gr}); }, false);
         bench("g5 256x128, dropout + residual epilogue (timing only)", {p}, [&] { launch_g5<false>({gr}); }, false);
+        if (g6ok) bench("g6 256x128, dropout + residual epilogue (timing only)", {p}, [&] { launch_g6<0>({gr}); }, false);
       }
       if (s[1] == 2048 || s[1] == 8192) {
+        bench("  g6 abl: no MFMA", {p}, [&] { launch_g6<1>({g}); }, false);
+        bench("  g6 abl: no copies", {p}, [&] { launch_g6<2>({g}); }, false);
+        bench("  g6 abl: no frag reads", {p}, [&] { launch_g6<4>({g}); }, false);
+        bench("  g6 abl: no staging / drain of real data (compute side)", {p}, [&] { launch_g6<8>({g}); }, false);
+        bench("  g6 abl: drain without stores", {p}, [&] { launch_g6<16>({g}); }, false);
+        bench("  g6 abl: MFMA + reads", {p}, [&] { launch_g6<10>({g}); }, false);
         bench("  g5 abl: no MFMA", {p}, [&] { launch_g5<false, 1>({g}); }, false);
         bench("  g5 abl: no copies", {p}, [&] { launch_g5<false, 2>({g}); }, false);
         bench("  g5 abl: no frag reads", {p}, [&] { launch_g5<false, 4>({g}); }, false);
         bench("  g5 abl: no epilogue", {p}, [&] { launch_g5<false, 8>({g}); }, false);
+        bench("  g5 abl: epilogue math, no stores", {p}, [&] { launch_g5<false, 16>({g}); }, false);
         bench("  g5 abl: copies only", {p}, [&] { launch_g5<false, 5>({g}); }, false);
         bench("  g5 abl: MFMA + reads", {p}, [&] { launch_g5<false, 10>({g}); }, false);
         bench("  g5 abl: MFMA only", {p}, [&] { launch_g5<false, 14>({g}); }, false);
