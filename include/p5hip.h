@@ -75,6 +75,9 @@ int p5_engine_grads_zeroed(P5Engine* e);
  * ordered after everything `stream` holds so far (the optimizer step that read the gradients), so that it overlaps the next
  * forward; the next backward waits for it.  Nothing else may read the gradient arena before that backward. */
 int p5_engine_clear_grads(P5Engine* e, void* stream);
+/* optimizer.zero_grad(set_to_none=True) (DistributedRunner.py:93): the gradients are dead until the next backward; no device work.
+   (p5_engine_clear_grads is the eager, set_to_none=False form.) */
+int p5_engine_discard_grads(P5Engine* e);
 /* optional second stream: weight-gradient GEMMs run on it, one sub-layer behind the dgrad chain (NULL = single stream) */
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream);
 

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "p5_refresh_decode_fold": (i32, [vp, vp]),
     "p5_engine_grads_zeroed": (i32, [vp]),
     "p5_engine_clear_grads": (i32, [vp, vp]),
+    "p5_engine_discard_grads": (i32, [vp]),
     "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
     "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
     "p5_generate_timing": (i32, [vp, i32, C.POINTER(f32), C.POINTER(f32)]),

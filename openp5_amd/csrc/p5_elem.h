@@ -289,6 +289,23 @@ __global__ __launch_bounds__(256) void p5_cast_mask_kernel(T* __restrict__ out, 
   }
 }
 
+// out[i] = T(sum_{z < nsplit} part[z * stride + i]), summed in index order: the second half of a deterministic split-K GEMM
+// (P5GemmArgs::c_split_stride) fused with the cast to the compute dtype
+template <class T>
+__global__ __launch_bounds__(256) void p5_reduce_splits_kernel(T* __restrict__ out, const float* __restrict__ part, int nsplit, size_t stride, size_t n) {
+  constexpr int EPF = TT<T>::EPF;      // n is a multiple of d_model, hence of EPF
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPF; i < n; i += (size_t)gridDim.x * 256 * EPF) {
+    float acc[8], v[8];
+    ldf<EPF>(part + i, acc);
+    for (int z = 1; z < nsplit; ++z) {
+      ldf<EPF>(part + (size_t)z * stride + i, v);
+#pragma unroll
+      for (int e = 0; e < EPF; ++e) acc[e] += v[e];
+    }
+    st16(out + i, pack16<T>(acc));
+  }
+}
+
 // dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials); grid = (d/64, row slices)
 __global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d) {
   const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;

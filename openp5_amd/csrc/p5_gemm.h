@@ -55,6 +55,9 @@ struct P5GemmArgs {
   // per 64-column group of the residual stream, each written by exactly one wave with a plain store (no atomics, no clearing, same
   // bits every run) and summed in a fixed order by the consumer.  0 = the decode step's scalar-per-row form (atomic accumulate).
   int rowss_nt, ssq_nt;
+  // Deterministic split-K (fp32 C, epilogue kind P5_EPI_ATOMIC): when > 0, split z STORES its partial product at C + z * stride
+  // (elements) instead of adding to C with atomics; the caller sums the active splits in index order (p5_reduce_splits_kernel).
+  long long c_split_stride;
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets
@@ -414,7 +417,7 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
       (g.epi == P5_EPI_STORE || g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM)) {
     const int eM = g.M, eN = g.N, eldc = g.ldc;
     const float ealpha = g.alpha;
-    float* const eC = (float*)g.C;
+    float* const eC = (float*)g.C + (g.c_split_stride > 0 ? (size_t)blockIdx.z * (size_t)g.c_split_stride : (size_t)0);
     auto nest = [&](auto ek) {
       constexpr int EK = decltype(ek)::value;
 #pragma unroll
@@ -435,7 +438,8 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
           }
         }
     };
-    if (g.epi == P5_EPI_ATOMIC) nest(P5EpiTag<P5_EPI_ATOMIC>{});
+    if (g.epi == P5_EPI_ATOMIC && g.c_split_stride > 0) nest(P5EpiTag<P5_EPI_STORE>{});
+    else if (g.epi == P5_EPI_ATOMIC) nest(P5EpiTag<P5_EPI_ATOMIC>{});
     else if (g.epi == P5_EPI_ACCUM) nest(P5EpiTag<P5_EPI_ACCUM>{});
     else nest(P5EpiTag<P5_EPI_STORE>{});
     return;

@@ -263,6 +263,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
     }
   }
   if (g.splitk > 1) P5_REQUIRE(g.epi == P5_EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
+  if (g.c_split_stride > 0) return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);    // (blockIdx.z = split index)
   if constexpr (sizeof(T) == 2) {
     // 256x256 tiles halve the L2->LDS bytes per MAC; they pay off once every CU gets a tile and the K loop is long enough to
     // amortise the un-overlapped prologue/epilogue of the single resident workgroup (tools/gemm_v2_bench.py: 8192x2048x2048
@@ -429,7 +430,9 @@ struct P5Engine {
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
-  bool grads_zeroed = false;      // p5_engine_grads_zeroed(): the next backward need not clear the gradient arena again
+  bool grads_zeroed = false;      // the gradient arena holds zeros (p5_engine_clear_grads): the next backward need not clear it
+  bool grads_keep = false;        // p5_engine_grads_zeroed(): the next backward ADDS to the arena (2nd.. micro-batch of an accumulation group)
+  int wg_epi = P5_EPI_ACCUM;      // how this backward's grouped weight-gradient GEMMs write: P5_EPI_STORE on a first micro-batch
   // decode-step weights with the following RMSNorm weight folded in (W[out,in] * ln[in]): per decoder layer qkv / cross-q / wi,
   // and the tied head E * final_ln; caller-owned buffer in the compute dtype (p5_engine_bind_decode_fold)
   void* fold = nullptr;
@@ -647,7 +650,7 @@ static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, 
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
   g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = rowss_eps; g.ssq_out = ssq_out;
-  g.rowss_nt = 0; g.ssq_nt = 0; g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0;
+  g.rowss_nt = 0; g.ssq_nt = 0; g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0; g.c_split_stride = 0;
   return launch_gemm<T>(g, s);
 }
 // TRAINING forward with T5LayerNorm folded in (bf16 engine): y = rstd(x) * (x Wf^T), Wf = W diag(ln) from the folded
@@ -752,11 +755,13 @@ static int linear_wgrad(P5Engine* e, hipStream_t main, const void* dy, int lddy,
     P5GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dy; g.B = x; g.C = dW; g.M = N_out; g.N = K_in; g.K = M; g.lda = lddy; g.ldb = ldx; g.ldc = K_in;
-    g.a_ks = 1; g.b_ks = 1; g.epi = P5_EPI_ACCUM; g.c_f32 = 1; g.splitk = 1; g.alpha = alpha; g.drop = no_drop();
+    g.a_ks = 1; g.b_ks = 1; g.epi = e->wg_epi; g.c_f32 = 1; g.splitk = 1; g.alpha = alpha; g.drop = no_drop();
     e->wg_pending.push_back(g);
     if (e->sub >= 0) e->wg_sets |= 1u << (e->sub % P5_NSETS);
     return 0;
   }
+  // (split-K atomics: on a storing backward the target has not been cleared)
+  if (e->wg_epi == P5_EPI_STORE) hipMemsetAsync(dW, 0, (size_t)N_out * K_in * 4, wgrad_stream(e, main));
   return linear_wgrad_on<T>(wgrad_stream(e, main), dy, lddy, x, ldx, dW, M, N_out, K_in, alpha);
 }
 
@@ -785,6 +790,51 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
 }
 
 static constexpr int REL_COPIES = 16;
+static constexpr int P5_HEAD_SPLITS = 32;      // most K-splits of the tied head's input-gradient GEMM (slices of its partial-product buffer)
+
+// A backward that starts a new accumulation group does not clear the 4 B x n_params gradient arena and then add into it: every
+// Linear weight's gradient is written by exactly one GEMM tile pass, which STORES on that first micro-batch (and `+=` on later ones);
+// the head's gradient of the tied embedding is stored before the embedding scatter-adds land on it.  Only the parameters whose
+// gradients are sums of atomics / partial reductions (whole-word embedding, relative-bias tables, T5LayerNorm weights: ~1 MB of
+// T5-small's 242 MB) are cleared, by one table-driven launch.  Saves the fill and the read of the arena per step.
+static int g_opt_grad_store_first = getenv("P5_GRAD_STORE_FIRST") ? atoi(getenv("P5_GRAD_STORE_FIRST")) : 1;
+struct P5ZeroTab {
+  int n;
+  struct D { long long off; int count, blk0; } e[200];
+};
+__global__ __launch_bounds__(256) void p5_zero_segments_kernel(float* __restrict__ G, P5ZeroTab tab) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = tab.n - 1;             // last segment with blk0 <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.e[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const int i0 = (b - tab.e[lo].blk0) * 8192, n = tab.e[lo].count;
+  float* __restrict__ dst = G + tab.e[lo].off;
+  for (int i = i0 + threadIdx.x; i < i0 + 8192 && i < n; i += 256) dst[i] = 0.f;
+}
+static int zero_small_grads(P5Engine* e, hipStream_t s) {
+  const P5Config& c = e->c;
+  P5ZeroTab tab;
+  tab.n = 0;
+  int blocks = 0;
+  auto add = [&](int64_t off, int64_t count) {
+    if (count <= 0 || tab.n >= 200) return;
+    P5ZeroTab::D& q = tab.e[tab.n++];
+    q.off = off; q.count = (int)count; q.blk0 = blocks;
+    blocks += (int)((count + 8191) / 8192);
+  };
+  add(e->off_WW, (int64_t)c.whole_word_size * c.d_model);
+  add(e->off_enc_rel, (int64_t)c.rel_buckets * c.n_heads);
+  add(e->off_dec_rel, (int64_t)c.rel_buckets * c.n_heads);
+  for (const LayerOff& l : e->enc) { add(l.sa.ln, c.d_model); add(l.ff_ln, c.d_model); }
+  for (const LayerOff& l : e->dec) { add(l.sa.ln, c.d_model); add(l.ca.ln, c.d_model); add(l.ff_ln, c.d_model); }
+  add(e->off_enc_fln, c.d_model);
+  add(e->off_dec_fln, c.d_model);
+  P5_REQUIRE(tab.n < 200, "zero_small_grads: too many segments");
+  P5_LAUNCH(p5_zero_segments_kernel, dim3(blocks), dim3(256), 0, s, e->G, tab);
+  return P5_KCHECK();
+}
 
 static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with_bwd) {
   const P5Config& c = e->c;
@@ -843,7 +893,10 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
   if (with_bwd) {
     const size_t Mx = M > Md ? M : Md;
     e->dres_a = (float*)b.take(Mx * d * 4);
-    e->dres_b = (float*)b.take(Mx * d * 4);
+    {   // (also the partial products of the tied head's deterministic split-K input gradient: up to P5_HEAD_SPLITS slices of [Md, d])
+      const size_t need = Md * d * 4 * P5_HEAD_SPLITS;
+      e->dres_b = (float*)b.take(need > Mx * d * 4 ? need : Mx * d * 4);
+    }
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
     e->rel_partial = (float*)b.take((size_t)2 * REL_COPIES * c.rel_buckets * H * 4);
@@ -1104,8 +1157,17 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
   const int nd = c.n_dec_layers, ne = c.n_enc_layers;
   if (stage == 0) {
-    if (!e->grads_zeroed) hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);     // (the caller may just have done it: zero_grad())
+    if (e->grads_keep) {
+      e->wg_epi = P5_EPI_ACCUM;                 // a later micro-batch of an accumulation group: everything adds
+    } else if (sizeof(T) == 2 && g_opt_grad_store_first && g_opt_wgrad_group) {
+      if (!e->grads_zeroed) P5_TRY(zero_small_grads(e, s));
+      e->wg_epi = P5_EPI_STORE;
+    } else {
+      if (!e->grads_zeroed) hipMemsetAsync(e->G, 0, (size_t)e->n_params * 4, s);     // (the caller may just have done it: zero_grad())
+      e->wg_epi = P5_EPI_ACCUM;
+    }
     e->grads_zeroed = false;
+    e->grads_keep = false;
     hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     e->sub = -1;
@@ -1133,15 +1195,32 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_TRY(linear_wgrad<T>(e, s, e->dlogits, e->Vp, e->dec_hn, d, e->G + e->off_E, Md, c.vocab_size, d, alpha));
     P5_TRY(wgrad_flush(e, s, true, (g_opt_wgrad_side & 1) != 0));
     {
-      // K = vocab is long and M*N small: split-K with fp32 atomics into a scratch, then one cast pass
-      hipMemsetAsync(e->dres_b, 0, (size_t)Md * d * 4, s);
+      // K = vocab is long and M*N small: split-K.  The splits STORE their partial products side by side and one pass sums them in index
+      // order and casts -- not fp32 atomics into a cleared buffer: the order atomics land in changes from run to run, the bf16 rounding
+      // of dhn then flips in a few elements, and that is the root of the whole backward (measured: two runs of the same step
+      // differed by 1e-3 relative in every gradient tensor; with this, only the tensors that are themselves sums of atomics differ,
+      // in their last bits).
       // (bf16: reduce over the padded vocabulary Vp = multiple of 64 so that both operands qualify for direct-to-LDS copies;
       //  dlogits columns V..Vp are exact zeros and the rows "E[V..Vp)" are the finite first rows of the next tensor in the arena)
       const int Kv = sizeof(T) == 2 ? e->Vp : c.vocab_size;
-      P5_TRY(gemm<T>(s, e->dlogits, e->Vp, 0, Wc<T>(e, e->off_E), d, 1, e->dres_b, d, Md, d, Kv, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop()));
+      const bool big = Kv >= 16384 || (long)((Md + 127) / 128) * ((d + 127) / 128) >= 512;      // (launch_gemm's tile choice for this problem)
+      const long tiles = big ? (long)((Md + 127) / 128) * ((d + 127) / 128) : (long)((Md + 63) / 64) * ((d + 63) / 64);
+      const int nst = (Kv + 2 * TT<T>::KCH - 1) / (2 * TT<T>::KCH);         // K-steps of the 128x128 / 64x64 kernels (two K-chunks each)
+      int want = (int)(((Kv >= 16384 ? 384 : 768) + tiles - 1) / tiles);
+      want = want > P5_HEAD_SPLITS ? P5_HEAD_SPLITS : want;
+      want = want > nst / 4 ? (nst / 4 > 0 ? nst / 4 : 1) : want;
+      const int per = (nst + want - 1) / want, active = (nst + per - 1) / per;       // splits that have K-steps (the kernel's own arithmetic)
+      {
+        P5GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = e->dlogits; g.B = Wc<T>(e, e->off_E); g.C = e->dres_b; g.M = Md; g.N = d; g.K = Kv; g.lda = e->Vp; g.ldb = d; g.ldc = d;
+        g.a_ks = 0; g.b_ks = 1; g.epi = P5_EPI_ATOMIC; g.c_f32 = 1; g.splitk = want; g.alpha = alpha; g.drop = no_drop();
+        g.rowss_invd = 1.0f / (float)Kv; g.c_split_stride = (long long)Md * d;
+        P5_TRY(launch_gemm<T>(g, s));
+      }
       const size_t n = (size_t)Md * d;
-      P5_LAUNCH((p5_cast_mask_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
-                (const float*)e->dres_b, n, no_drop());
+      P5_LAUNCH((p5_reduce_splits_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->dn,
+                (const float*)e->dres_b, active, n, n);
       P5_TRY(P5_KCHECK());
     }
     e->dres_cur = e->dres_a;
@@ -1758,6 +1837,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
+  else if (!strcmp(name, "grad_store_first")) g_opt_grad_store_first = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
   else if (!strcmp(name, "g4_wgs")) g_opt_g4_wgs = value;
   else return fail("p5_set_option: unknown option");
@@ -1927,7 +2007,10 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   if (stage == p5_backward_num_stages(e) - 1) join_side(e, (hipStream_t)stream);
   return 0;
 }
-int p5_engine_grads_zeroed(P5Engine* e) { e->grads_zeroed = true; return 0; }
+int p5_engine_grads_zeroed(P5Engine* e) { e->grads_keep = true; return 0; }
+// zero_grad(set_to_none=True) of the reference loop: the gradients are dead until the next backward rewrites them -- nothing to do
+// on the device (the next backward stores / clears what it needs); p5_engine_clear_grads is the eager form (set_to_none=False)
+int p5_engine_discard_grads(P5Engine* e) { e->grads_zeroed = false; e->grads_keep = false; return 0; }
 
 // zero_grad() of the reference loop (DistributedRunner.py:93): the 4 B x n_params fill is HBM-bound and nothing before the next
 // backward needs its result, so it goes to the side stream (ordered after everything `stream` has been given so far, i.e. after
@@ -2099,7 +2182,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
-  g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr; g.rowss_nt = 0; g.ssq_nt = 0;
+  g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr; g.rowss_nt = 0; g.ssq_nt = 0; g.c_split_stride = 0;
   g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0;
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
 }

@@ -406,10 +406,15 @@ class P5T5Native(nn.Module):
         return self
 
     def zero_grad(self, set_to_none: bool = True):
-        # the views stay attached.  The engine clears the arena itself -- on its side stream, after the optimizer step already
-        # queued on this stream, so that the 243 MB fill overlaps the next forward; the next backward waits for it (nothing
-        # reads gradients in between in the reference loop, DistributedRunner.py:84-93)
-        self._be.check(self._lib.p5_engine_clear_grads(self._engine, self._be.stream_ptr()), "clear_grads")
+        """set_to_none=True (torch's default, what the reference loop's optimizer.zero_grad() does, DistributedRunner.py:93): the
+        gradients are DEAD until the next backward, which overwrites them -- a first micro-batch STORES every Linear gradient and
+        clears only the ~1 MB of atomically accumulated ones -- so there is no 242 MB fill and no read-modify-write of zeros.  The
+        `.grad` views stay attached (re-attaching ~130 of them every step is host time); their contents are undefined until that
+        backward, where torch would show None.  set_to_none=False: the arena is cleared now."""
+        if set_to_none:
+            self._be.check(self._lib.p5_engine_discard_grads(self._engine), "discard_grads")
+        else:
+            self._be.check(self._lib.p5_engine_clear_grads(self._engine, self._be.stream_ptr()), "clear_grads")
 
     def tie_weights(self):
         return None
@@ -433,6 +438,8 @@ class P5T5Native(nn.Module):
         cur = getattr(self, which)
         if cur is None or cur.numel() < nbytes:
             raw = torch.empty(int(nbytes * 1.05) + 512, dtype=torch.uint8, device=self._be.device)
+            if os.environ.get("P5_POISON_WS"):      # debugging aid: NaN patterns in every byte the engine has not written yet
+                raw.fill_(0xFF)
             skew = (-raw.data_ptr()) % 256          # the engine wants a 256-byte aligned base
             cur = raw[skew:skew + int(nbytes * 1.05) + 255]
             setattr(self, which, cur)

@@ -858,6 +858,67 @@ def bf16_gradient_case(be, ocfg, B, L, T, dropout=0.0, seed=3):
                 worst_rel=max(rows), worst_cos=min((r[1], r[2]) for r in rows), whole_rel=whole[0], whole_cos=whole[1])
 
 
+def backward_reproducible_case(be, ocfg, B, L, T, runs=4):
+    """Two runs of the same step on fresh models: every gradient that is not itself a sum of fp32 atomics (the embeddings' scatter-adds,
+    the relative-bias tables, the T5LayerNorm weights) must come out bit-identical -- the activations' gradients are deterministic."""
+    params = O.init_params(ocfg, 7)
+    a = synth_batch(ocfg, B, L, T, 3)
+    outs = []
+    for r in range(runs):
+        m = build_model(be, ocfg, params, "bf16", 0.0)
+        m.eval()
+        loss = m.loss_and_backward(*a)
+        sync(be)
+        outs.append((float(loss), m._grads.detach().cpu().clone()))
+        views = dict(m._views)
+    atomic = lambda n: n == "shared.weight" or "whole_word" in n or "relative_attention_bias" in n or "layer_norm" in n
+    for r in range(1, runs):
+        assert outs[r][0] == outs[0][0], (r, outs[r][0], outs[0][0])
+        for n, (o, k, _) in views.items():
+            d = float((outs[r][1][o:o + k] - outs[0][1][o:o + k]).abs().max())
+            if atomic(n):
+                assert d <= 1e-5 * max(float(outs[0][1][o:o + k].abs().max()), 1e-6), (r, n, d)
+            else:
+                assert d == 0.0, (r, n, d)
+
+
+def grad_store_first_case(be, ocfg, B, L, T, exact=True):
+    """A backward that starts a new accumulation group STORES the Linear gradients over whatever the arena holds (no clear): its
+    result must equal the clear-then-accumulate path's on the same batch, after an unrelated backward has left its gradients
+    behind; and a second micro-batch (begin_micro_batch(first=False)) must add to it."""
+    params = O.init_params(ocfg, 7)
+    a = synth_batch(ocfg, B, L, T, 3)
+    b = synth_batch(ocfg, B, L, T, 4)
+    got = {}
+    try:
+        for mode in (1, 0):
+            be.check(be.lib.p5_set_option(b"grad_store_first", mode), "opt")
+            m = build_model(be, ocfg, params, "bf16", 0.0)
+            m.eval()
+            m.loss_and_backward(*a)                 # leaves gradients behind
+            m.zero_grad()                           # (dead, not cleared)
+            m.begin_micro_batch(first=True, sync=False)
+            m.loss_and_backward(*b)
+            sync(be)
+            g1 = m._grads.detach().cpu().clone()
+            m.begin_micro_batch(first=False, sync=False)
+            m.loss_and_backward(*a)
+            sync(be)
+            got[mode] = (g1, m._grads.detach().cpu().clone())
+            views = dict(m._views)
+    finally:
+        be.lib.p5_set_option(b"grad_store_first", 1)
+    for i in (0, 1):
+        if exact:
+            assert torch.equal(got[1][i], got[0][i]), (i, float((got[1][i] - got[0][i]).abs().max()))
+        else:       # (the embedding scatter's fp32 atomics land in a different order every run)
+            scale = float(got[0][i].abs().max())
+            bad = [(n, float((got[1][i][o:o + k] - got[0][i][o:o + k]).abs().max()), float(got[0][i][o:o + k].abs().max()))
+                   for n, (o, k, _) in views.items() if float((got[1][i][o:o + k] - got[0][i][o:o + k]).abs().max()) > 1e-5 * scale]
+            assert not bad, (i, scale, bad[:8])
+    assert float((got[1][1] - got[1][0]).abs().max()) > 0
+
+
 def bf16_c2_gradient_case(be, B=64, L=128, T=8):
     """The benchmarked mode at the benchmarked shape (BASELINE.json configs[1]: T5-small, B=64, L=128, T=8, bf16 engine)."""
     return bf16_gradient_case(be, O.T5Cfg.named("t5-small", dropout=0.0), B, L, T)

@@ -258,6 +258,10 @@ def test_model_bf16_norm_folded_into_gemms(emu, dropout):
     assert abs(res[1]["whole_rel"] - res[0]["whole_rel"]) <= 0.02, res
 
 
+def test_gradients_stored_not_accumulated_on_a_first_micro_batch(emu):
+    cases.grad_store_first_case(emu, O.T5Cfg.named("tiny"), 4, 16, 16)
+
+
 @pytest.mark.parametrize("dtype,d_model,heads", [("fp32", 64, 1), ("fp32", 64, 2), ("fp32", 192, 2), ("bf16", 64, 1)])
 def test_generate_odd_widths(emu, dtype, d_model, heads):
     """d_model that the streaming head's K units do not divide (toy models of the runner tests): the engine must take the

@@ -338,6 +338,21 @@ def test_gemm_wave_specialised(hip, wgs):
         cases.gemm_group_case(hip, 3, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
 
 
+def test_backward_is_reproducible(hip):
+    """the tied head's input gradient (K = vocabulary) used to be a split-K GEMM with fp32 atomics: their order, and with it the bf16
+    rounding of the root of the whole backward, changed from run to run (every gradient tensor differed by ~1e-3 relative between two
+    runs of the same step).  Now the splits store partial products and are summed in index order."""
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 16, 64, 8)
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("tiny"), 4, 16, 16)
+
+
+def test_gradients_stored_not_accumulated_on_a_first_micro_batch(hip):
+    """T5-small shapes of the benchmark step (grouped 256x128 weight-gradient launches, tied-head store before the embedding
+    scatter-adds): storing backward == clear-then-accumulate backward, to fp32 atomic-order noise."""
+    cases.grad_store_first_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 16, 64, 8, exact=False)
+    cases.grad_store_first_case(hip, O.T5Cfg.named("tiny"), 4, 16, 16, exact=False)
+
+
 def test_gemm_wave_specialised_wgrad(hip):
     probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1), (8, 8, 64, 4, 1, 1)]
     for rep in range(3):

@@ -199,7 +199,15 @@ def test_gradient_accumulation_equals_big_batch(emu):
     training_step(mb, ob, big)
     assert oa.t == 1 and ob.t == 1
     assert torch.allclose(ma._flat, mb._flat, atol=2e-6, rtol=1e-5), float((ma._flat - mb._flat).abs().max())
-    assert float(ma._grads.abs().sum()) == 0.0                      # zero_grad after the group
+    # zero_grad after the group leaves the gradients DEAD (set_to_none semantics: the next backward overwrites them, nothing is
+    # cleared in between) -- a second group must therefore land on the same parameters as a second big-batch step
+    training_step(ma, oa, b1, micro=0, accum=2)
+    training_step(ma, oa, b0, micro=1, accum=2)
+    training_step(mb, ob, tuple(torch.cat([y, x]) for x, y in zip(b0, b1)))
+    assert oa.t == 2 and ob.t == 2
+    assert torch.allclose(ma._flat, mb._flat, atol=4e-6, rtol=2e-5), float((ma._flat - mb._flat).abs().max())
+    ma.zero_grad(set_to_none=False)
+    assert float(ma._grads.abs().sum()) == 0.0                      # the eager form clears the arena
 
 
 def _ddp_accum_worker(rank, world, port, tmp):
