@@ -197,13 +197,14 @@ def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def time_wgrad_group(be, M, d, F, inner, iters=30):
-    """average duration of the dominant kernel of the step: the four weight gradients of one encoder layer (dW_o[d,F], dW_i[F,d],
-    dW_attn_o[d,inner], dW_qkv[3 inner,d], each reduced over all M tokens) as ONE launch of the persistent ring kernel
-    (p5_gemm4_kernel<128,128,KS>, 192 tiles, no split-K, C += acc), HIP events on the launch stream.  Returns (seconds, flops, bytes)."""
+def time_wgrad_group(be, M, d, F, inner, iters=30, layers=2):
+    """average duration of the dominant kernel of the step, as the step launches it: the weight gradients of TWO encoder layers
+    (per layer dW_o[d,F], dW_i[F,d], dW_attn_o[d,inner], dW_qkv[3 inner,d], each reduced over all M tokens) as ONE launch of the
+    wave-specialised persistent kernel (p5_gemm5_kernel<KS>, 192 tiles of 256x128, no split-K; the epilogue stores, as on the first
+    micro-batch of a step), HIP events on the launch stream.  Returns (seconds, flops, bytes)."""
     import ctypes
     from openp5_amd._abi import P5GemmProblem
-    shapes = [(d, F), (F, d), (d, inner), (3 * inner, d)]
+    shapes = [(d, F), (F, d), (d, inner), (3 * inner, d)] * layers
     arr = (P5GemmProblem * len(shapes))()
     keep = []
     flops = byts = 0.0
@@ -215,12 +216,12 @@ def time_wgrad_group(be, M, d, F, inner, iters=30):
         q = arr[i]
         q.A, q.B, q.C, q.aux = A.data_ptr(), Bm.data_ptr(), C.data_ptr(), None
         q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux = n_out, k_in, M, n_out, k_in, k_in, 0
-        q.epi, q.c_f32, q.splitk, q.alpha = 6, 1, 1, 1.0
+        q.epi, q.c_f32, q.splitk, q.alpha = 0, 1, 1, 1.0
         q.rowss, q.rowss_eps, q.ssq_out = None, 0.0, None
         flops += 2.0 * M * n_out * k_in
-        byts += 2.0 * M * (n_out + k_in) + 2 * 4.0 * n_out * k_in      # both operands once (bf16) + read-modify-write of the fp32 gradient
+        byts += 2.0 * M * (n_out + k_in) + 4.0 * n_out * k_in      # both operands once (bf16) + the fp32 gradient written once
     s = torch.cuda.current_stream()
-    call = lambda: be.lib.p5_op_gemm_group(0, 1, len(shapes), arr, None, 0, 0.0, be.stream_ptr())  # noqa: E731
+    call = lambda: be.lib.p5_op_gemm_group(1, 1, len(shapes), arr, None, 0, 0.0, be.stream_ptr())  # noqa: E731  (tile config 1 = 256x128, as wgrad_flush picks)
     for _ in range(5):
         be.check(call(), "gemm_group")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -506,8 +507,8 @@ def main():
         ach = 2.0 * Mg * Ng * Kg / t_k / 1e12
         t_w, fl_w, by_w = time_wgrad_group(be, Mg, c.d_model, c.d_ff, inner)
         ach_w = fl_w / t_w / 1e12
-        k_fwd = "p5_gemm4_kernel<256,128,8 waves,ring3,KC>"
-        k_wg = "p5_gemm4_kernel<128,128,4 waves,ring3,KS> x4 weight gradients of an encoder layer"
+        k_fwd = "p5_gemm5_kernel<KC> (256x128 tiles, 4 loader + 4 compute waves, ring of 3 K-steps)"
+        k_wg = "p5_gemm5_kernel<KS> (256x128 tiles, 4 loader + 4 compute waves): the 8 weight gradients of two encoder layers in one launch"
         ddp = None
         if world > 1:
             half = str(getattr(model, "ddp_bucket_dtype", "fp32")).replace("torch.", "") in ("bf16", "bfloat16")
@@ -527,14 +528,14 @@ def main():
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
             "distributed": ddp,
-            # dominant kernel of the step by time (profiles/README.md): ONE launch = the four weight gradients of an encoder layer on
-            # the persistent ring kernel (6 of them per step, ~12 % of the kernel time); `roofline_fwd` is the FFN up-projection.  Both
-            # are timed live with HIP events on the launch stream (`avg_launch_us`: the kernel alone); `in_step_us` is the same
-            # kernel's average duration inside the step, where it shares the GPU with the other stream (from the rocprofv3 trace).
-            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]],
+            # dominant kernel of the step by time (profiles/README.md): ONE launch = the eight weight gradients of two encoder layers on
+            # the wave-specialised persistent kernel (3 of them per step); `roofline_fwd` is the FFN up-projection on the same kernel's
+            # K-contiguous build.  Both are timed live with HIP events on the launch stream (`avg_launch_us`: the kernel alone, operands
+            # warm); `in_step_us` is the same kernel's average duration inside the step (from the rocprofv3 trace of bench.py).
+            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]] * 2,
                          "achieved": ach_w, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("wgrad_group", (Mg, c.d_model, c.d_ff)), "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes)",
-                         "algorithmic_bytes": by_w, "avg_launch_us": t_w * 1e6, "in_step_us": in_step_us("wgrad_group"),
+                         "traffic": pmc_traffic("wgrad_group2", (Mg, c.d_model, c.d_ff)), "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes)",
+                         "algorithmic_bytes": by_w, "avg_launch_us": t_w * 1e6, "in_step_us": in_step_us("wgrad_group2"),
                          "flops_per_launch": fl_w},
             "roofline_fwd": {"bound": "mfma", "kernel": k_fwd, "shape": [Mg, Ng, Kg], "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / BF16_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "traffic_source": "profiles/pmc_traffic.json",

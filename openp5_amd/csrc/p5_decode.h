@@ -259,6 +259,11 @@ struct P5BeamState {
 
 // ---- shared tail of the beam step: HF steps d-g (utils.py:3131-3204, 3008-3075) from the item's top-2K candidate list in
 // `sh`, materialisation of the new finished / running sets, step counter + stop flag.  `st` is already parity-swapped. ----
+// longest hypothesis the decode kernels hold (beam bookkeeping below in LDS, ancestry gather of p5_dec_self_attn2_kernel unrolled over
+// max_len / 8 passes); p5_generate / p5_decode_begin refuse anything longer (p5_lib.hip) -- one constant for both sides
+#ifndef P5_MAX_LEN
+#define P5_MAX_LEN 64
+#endif
 struct P5BeamSh {
   float top_lp[P5_MAX_K2], run_lp[P5_MAX_K2], msc[P5_MAX_K + P5_MAX_K2];
   int top_beam[P5_MAX_K2], top_tok[P5_MAX_K2], top_node[P5_MAX_K2], hit[P5_MAX_K2];
@@ -270,7 +275,7 @@ struct P5BeamSh {
   int old_unsat, old_node[P5_MAX_K], old_coff[P5_MAX_K];
   float old_fin_score[P5_MAX_K];
   int old_fin_flag[P5_MAX_K], old_fin_len[P5_MAX_K];
-  int old_run_seq[P5_MAX_K * 64], old_fin_seq[P5_MAX_K * 64], old_anc[P5_MAX_K * 64];     // [Kb][max_len], [Kb][max_len], [pos+1][Kb]
+  int old_run_seq[P5_MAX_K * P5_MAX_LEN], old_fin_seq[P5_MAX_K * P5_MAX_LEN], old_anc[P5_MAX_K * P5_MAX_LEN];   // [Kb][max_len], [Kb][max_len], [pos+1][Kb]
 };
 
 // issue every load of the item's old state (see P5BeamSh); the caller's next __syncthreads() publishes it

@@ -2097,7 +2097,7 @@ int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_
                     const uint32_t* excluded_nodes, int excluded_words, int max_children, void* ws, int64_t ws_bytes, void* stream) {
   P5_REQUIRE(e->P, "engine not bound");
   P5_REQUIRE(K >= 1 && K <= 64, "1 <= num_beams <= 64");
-  P5_REQUIRE(max_len >= 2 && max_len <= 64, "2 <= max_length <= 64");
+  P5_REQUIRE(max_len >= 2 && max_len <= P5_MAX_LEN, "2 <= max_length <= 64 (P5_MAX_LEN)");
   P5_REQUIRE(L >= 1 && L <= 512, "1 <= L <= 512");
   P5_REQUIRE(max_children >= 1, "max_children");
   P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");

@@ -11,16 +11,16 @@ export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out/pmc"
 rm -rf "$OUT"; mkdir -p "$OUT"
 : > "$ROOT/gpurun_out/pmc_raw.txt"
-# name | kernel-name pattern | gemm_one.py arguments (M N K [a_ks b_ks])
+# key (bench.py: pmc_traffic(name, shape)) | shape | kernel-name pattern | command
 CASES=(
-  "p5_gemm_kernel<bf16,128,128,KC,KC,direct-to-LDS>|8192x2048x512|p5_gemm_kernelI4bf16Li128ELi128ELb0ELb0E|8192 2048 512"
-  "p5_gemm2_kernel<128,128,ring4,KS,KS>|2048x512x8192|p5_gemm2_kernelILi128ELi128ELi4ELb1ELb1E|2048 512 8192 1 1"
+  "fwd_wide|8192x2048x512|p5_gemm5_kernelILb0E|python tools/gemm_one.py 8192 2048 512"
+  "wgrad_group2|8192x512x2048|p5_gemm5_kernelILb1E|python tools/gemm_group_one.py"
 )
 for c in "${CASES[@]}"; do
-  IFS='|' read -r NAME SHAPE PAT ARGS <<< "$c"
+  IFS='|' read -r NAME SHAPE PAT CMD <<< "$c"
   for CTR in FETCH_SIZE WRITE_SIZE; do
     D="$OUT/${CTR}_$(echo "$SHAPE" | tr 'x' '_')"
-    rocprofv3 --pmc $CTR --kernel-trace -d "$D" -o g -- python tools/gemm_one.py $ARGS > "$D.log" 2>&1 || { tail -5 "$D.log"; exit 1; }
+    rocprofv3 --pmc $CTR --kernel-trace -d "$D" -o g -- $CMD > "$D.log" 2>&1 || { tail -5 "$D.log"; exit 1; }
     DB=$(find "$D" -name "*_results.db" | head -1)
     echo "## $NAME $SHAPE $CTR" >> "$ROOT/gpurun_out/pmc_raw.txt"
     python profiles/pmc_dump.py "$DB" "$PAT" >> "$ROOT/gpurun_out/pmc_raw.txt"
@@ -44,7 +44,7 @@ for k, e in tab.items():
         e["read_bytes"] = e["FETCH_SIZE_raw_kb"] * 1024.0 * 2.0      # gfx950 correction (MI355X_MICROARCH.md, HBM section)
         e["write_bytes"] = e["WRITE_SIZE_raw_kb"] * 1024.0
         e["traffic_bytes"] = e["read_bytes"] + e["write_bytes"]
-        e["note"] = "per launch; FETCH_SIZE x2 (gfx950), separate --pmc passes, averaged over the launches of tools/gemm_one.py"
+        e["note"] = "per launch; FETCH_SIZE x2 (gfx950), separate --pmc passes, averaged over the launches of tools/gemm_one.py / tools/gemm_group_one.py"
 json.dump(tab, open(f"{root}/profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 json.dump(tab, open(f"{root}/gpurun_out/pmc_traffic.json", "w"), indent=1, sort_keys=True)   # gpurun merges gpurun_out/ back
 print(json.dumps(tab, indent=1, sort_keys=True))

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ( cd "$ROOT" && rocprofv3 --kernel-trace --stats -d "$OUT" -o t -- "$@" ) > "$OUT/run.log" 2>&1 || { tail -20 "$OUT/run.log"; exit 1; }
 DB=$(find "$OUT" -name "*_results.db" | head -1)
-python "$ROOT/profiles/summarize_rocpd.py" "$DB" "$ROOT/gpurun_out/${NAME}.md" > /dev/null
+python "$ROOT/profiles/summarize_rocpd.py" "$DB" "$ROOT/gpurun_out/${NAME}.md" --in-step "$ROOT/gpurun_out/${NAME}_in_step.json" > /dev/null
 python "$ROOT/profiles/summarize_rocpd.py" "$DB" "$ROOT/gpurun_out/${NAME}_by_shape.md" --by-grid > /dev/null
 grep -v "^W2026\|^I2026" "$OUT/run.log" | tail -5
 rm -rf "$OUT"/*.db 2>/dev/null || true
