@@ -1323,6 +1323,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s2, e->G + e->off_enc_rel,
               (const float*)e->rel_partial, c.rel_buckets * H, REL_COPIES);
     P5_TRY(P5_KCHECK());
+    // (a gather of the whole-word table's gradient -- one workgroup per (table row, 256-row slice), matching rows summed in
+    //  registers, one atomic per column -- was measured: 4.545 vs 4.493 ms per step; index 0 (every pad) makes a few workgroups long)
     if (s2 != s) {
       P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s2, (float*)nullptr, e->G + e->off_WW, (const float*)e->dres_cur,
                 e->ids, e->ww, M, d, mk_drop(e, 0, 0, 0));
