@@ -858,6 +858,34 @@ def bf16_gradient_case(be, ocfg, B, L, T, dropout=0.0, seed=3):
                 worst_rel=max(rows), worst_cos=min((r[1], r[2]) for r in rows), whole_rel=whole[0], whole_cos=whole[1])
 
 
+def grad_arena_coverage_case(be, ocfg, B, L, T, dtype="bf16"):
+    """zero_grad() leaves the gradient arena DEAD, not cleared: the next backward must write every parameter's gradient itself (store
+    it, or clear it before accumulating into it).  Poison the arena with NaN behind zero_grad(): after the backward no parameter's
+    gradient may contain a NaN, and all of them must equal the gradients of a fresh model's first backward."""
+    params = O.init_params(ocfg, 7)
+    a = synth_batch(ocfg, B, L, T, 3)
+    b = synth_batch(ocfg, B, L, T, 4)
+    ref = build_model(be, ocfg, params, dtype, 0.0)
+    ref.eval()
+    ref.loss_and_backward(*b)
+    sync(be)
+    want = ref._grads.detach().cpu().clone()
+    m = build_model(be, ocfg, params, dtype, 0.0)
+    m.eval()
+    m.loss_and_backward(*a)
+    m.zero_grad()
+    sync(be)
+    m._grads.fill_(float("nan"))
+    m.begin_micro_batch(first=True, sync=False)
+    m.loss_and_backward(*b)
+    sync(be)
+    got = m._grads.detach().cpu()
+    for n, (o, k, _) in m._views.items():
+        g = got[o:o + k]
+        assert not bool(torch.isnan(g).any()), f"{n}: gradient not (fully) written by a backward that follows zero_grad()"
+        assert torch.allclose(g, want[o:o + k], rtol=1e-5, atol=1e-7), (n, float((g - want[o:o + k]).abs().max()))
+
+
 def backward_reproducible_case(be, ocfg, B, L, T, runs=4):
     """Two runs of the same step on fresh models: every gradient that is not itself a sum of fp32 atomics (the embeddings' scatter-adds,
     the relative-bias tables, the T5LayerNorm weights) must come out bit-identical -- the activations' gradients are deterministic."""

@@ -262,6 +262,14 @@ def test_gradients_stored_not_accumulated_on_a_first_micro_batch(emu):
     cases.grad_store_first_case(emu, O.T5Cfg.named("tiny"), 4, 16, 16)
 
 
+@pytest.mark.parametrize("name,shape,dtype", [("tiny", (4, 16, 16), "bf16"), ("tiny_gated", (4, 16, 16), "bf16"), ("tiny", (3, 10, 5), "bf16"),
+                                              ("tiny", (2, 16, 5), "fp32")])
+def test_backward_writes_every_gradient_after_zero_grad(emu, name, shape, dtype):
+    """grouped path (token counts that are multiples of 64), gated FFN, the split-K path of ragged token counts, the fp32 engine."""
+    cfg = O.T5Cfg.named("tiny", ff_act="gated-gelu") if name == "tiny_gated" else O.T5Cfg.named(name)
+    cases.grad_arena_coverage_case(emu, cfg, *shape, dtype=dtype)
+
+
 @pytest.mark.parametrize("dtype,d_model,heads", [("fp32", 64, 1), ("fp32", 64, 2), ("fp32", 192, 2), ("bf16", 64, 1)])
 def test_generate_odd_widths(emu, dtype, d_model, heads):
     """d_model that the streaming head's K units do not divide (toy models of the runner tests): the engine must take the

@@ -338,6 +338,11 @@ def test_gemm_wave_specialised(hip, wgs):
         cases.gemm_group_case(hip, 3, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
 
 
+def test_backward_writes_every_gradient_after_zero_grad(hip):
+    cases.grad_arena_coverage_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 16, 64, 8)
+    cases.grad_arena_coverage_case(hip, O.T5Cfg.named("tiny"), 3, 10, 5)
+
+
 def test_backward_is_reproducible(hip):
     """the tied head's input gradient (K = vocabulary) used to be a split-K GEMM with fp32 atomics: their order, and with it the bf16
     rounding of the root of the whole backward, changed from run to run (every gradient tensor differed by ~1e-3 relative between two
