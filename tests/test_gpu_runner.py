@@ -133,11 +133,13 @@ def test_resume_on_device(hip, tmp_path):
     diff = float((second.model._flat - straight.model._flat).abs().max())
     scale = float(straight.model._flat.abs().max())
     print(f"[resume] max |param diff| resumed vs straight {diff:.3e} (run-to-run noise of the straight run {noise:.3e}, largest parameter {scale:.3f})")
-    # AdamW turns a gradient element that is pure fp32-atomic ordering noise around zero (|g| ~ 1e-9: sums of cancelling atomics in
-    # the embedding / relative-bias / norm-weight gradients) into an update of +-lr, so two runs of the SAME steps occasionally differ
-    # by 2 x lr (5.7e-3 at this schedule) in a handful of parameters while everything else agrees to the atomic noise floor -- seen
-    # between resumed and straight runs and, equally, between two straight runs.  The gate: all but a handful of the parameters within
-    # the noise tolerance, the handful within a few learning rates.
+    # Observed in 2 of 7 full GPU-suite runs of round 3: max |diff| = 5.67e-3 (about 2 x lr at this schedule) while the two straight runs
+    # agree to 2.4e-7; the host-emulation version of this test is bit-exact, so the state that must survive does.  Working
+    # explanation (not yet confirmed on the device -- the GPU budget of the round ran out): AdamW turns a gradient element that is
+    # pure fp32-atomic ordering noise around zero (|g| ~ 1e-9: the embedding / relative-bias / norm-weight gradients are sums of
+    # atomics) into an update of +-lr, and the first step after a resume runs with a cold cache, i.e. a different atomic order than the
+    # steady state of the straight run.  The gate therefore counts: all but a handful of the parameters within the noise tolerance,
+    # the handful within a few learning rates -- a systematic loss of state would move thousands of parameters and still fail.
     d_el = (second.model._flat - straight.model._flat).abs()
     tol = max(10 * noise, 1e-5 * scale)
     outliers = int((d_el > tol).sum())
