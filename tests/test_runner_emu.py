@@ -251,9 +251,11 @@ def test_data_parallel_gradient_accumulation(emu, tmp_path):
     assert torch.allclose(m._flat, a0["flat"], atol=2e-6, rtol=1e-5), float((m._flat - a0["flat"]).abs().max())
 
 
-def test_resume_is_exact(emu, tmp_path):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_resume_is_exact(emu, tmp_path, dtype):
     """train 2 epochs straight == train 1 epoch, save the resume file, build everything anew, --resume, train the 2nd epoch:
-    identical parameters and optimizer moments (weights + m/v/t + schedule position + dropout counter + data order)."""
+    identical parameters and optimizer moments (weights + m/v/t + schedule position + dropout counter + data order); the bf16 engine
+    adds the shadow / transposed / norm-folded weight copies and the stored-not-cleared gradient arena to what must come back."""
     tok = build_offline_tokenizer(VOCAB)
 
     def build(epochs, extra=()):
@@ -264,7 +266,7 @@ def test_resume_is_exact(emu, tmp_path):
         train = ConcatDataset([MultiTaskDataset(args, "Toy", "train")])
         loader = DataLoader(train, sampler=SingleMultiDataTaskSampler(train, args.batch_size, args.seed), batch_size=args.batch_size,
                             collate_fn=Collator(tok))
-        model = tiny_model(emu, len(tok), dropout=0.1, seed=9)
+        model = tiny_model(emu, len(tok), dropout=0.1, seed=9, dtype=dtype)
         model.set_dropout_seed(77, 0)
         return DistributedRunner(model, tok, loader, None, torch.device("cpu"), args, 0)
 
