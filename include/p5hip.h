@@ -68,8 +68,10 @@ int p5_refresh_shadow(P5Engine* e, void* stream);
 int64_t p5_transposed_bytes(const P5Engine* e);
 int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream);
 int p5_refresh_transposed(P5Engine* e, void* stream);
-/* The caller has just zero-filled the gradient arena on the stream the next backward will use (optimizer.zero_grad()):
- * that backward then skips its own clearing pass (243 MB for T5-small).  One-shot. */
+/* The next backward ADDS to what the gradient arena holds instead of starting a new sum: the 2nd.. micro-batch of a gradient-
+ * accumulation group, or an arena the caller has just zero-filled itself on the stream that backward will use.  One-shot.
+ * Without it a backward starts a new sum: it stores every Linear gradient and clears the atomically accumulated ones itself
+ * (p5_engine_discard_grads), or clears the whole arena first where the storing path does not apply (fp32 engine). */
 int p5_engine_grads_zeroed(P5Engine* e);
 /* optimizer.zero_grad() (DistributedRunner.py:93) done by the engine: the fill is issued on the side stream when one is bound,
  * ordered after everything `stream` holds so far (the optimizer step that read the gradients), so that it overlaps the next
