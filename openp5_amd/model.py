@@ -583,9 +583,11 @@ class P5T5Native(nn.Module):
         if trie is None:
             raise ValueError("generate() needs a trie / prefix_allowed_tokens_fn (OpenP5 always decodes under the item trie)")
         if isinstance(trie, Trie) or (hasattr(trie, "trie_dict") and not isinstance(trie, CompiledTrie)):
+            app = getattr(trie, "append_trie", None)
+            key = (getattr(trie, "len", None), id(app), getattr(app, "len", None), getattr(trie, "bos_token_id", None))
             cache = getattr(trie, "_p5_compiled", None)
-            if cache is None or cache[0] != getattr(trie, "len", None):
-                cache = (getattr(trie, "len", None), CompiledTrie.from_dict(trie.trie_dict))
+            if cache is None or cache[0] != key:
+                cache = (key, CompiledTrie.from_trie(trie))        # (grafts an appended trie, trie.py)
                 try:
                     trie._p5_compiled = cache
                 except Exception:

@@ -1,7 +1,7 @@
 """Item-ID prefix trie (host side) and its CSR compilation for the device beam search.
 
 `Trie` mirrors /root/reference/src/src_t5/utils/generation_trie.py:7-88 (same constructor, `add`, `get`,
-`__len__`, `__iter__`, `trie_dict`; the `append_trie` hook of the reference is kept).  `prefix_allowed_tokens_fn`
+`__len__`, `__iter__`, `trie_dict`; the `append_trie` hook of the reference is kept and compiled for the device too).  `prefix_allowed_tokens_fn`
 mirrors generation_trie.py:91-97 and additionally exposes `.candidate_trie`, which `P5T5Native.generate` uses to
 run the constraint on the device instead of calling back into Python per (batch x beam) row per step.
 """
@@ -98,6 +98,7 @@ class CompiledTrie:
         self.max_children = int(np.max(np.diff(self.child_off))) if self.n_nodes > 0 else 0
         self._dev = {}
         self._max_depth = None
+        self.grafted = False            # compiled from a trie with an appended trie: a DAG, item bookkeeping does not apply
 
     @property
     def max_depth(self) -> int:
@@ -139,10 +140,45 @@ class CompiledTrie:
         return CompiledTrie(np.asarray(off), np.asarray(tok), np.asarray(nxt))
 
     @staticmethod
-    def from_trie(trie: Trie) -> "CompiledTrie":
-        if getattr(trie, "append_trie", None) is not None:
-            raise NotImplementedError("append_trie tries are not supported by the device path")
-        return CompiledTrie.from_dict(trie.trie_dict)
+    def from_trie(trie) -> "CompiledTrie":
+        """Compile a `Trie` (ours or the reference's: anything with `.trie_dict`, optionally `.append_trie` / `.bos_token_id`).
+        An appended trie (generation_trie.py:19-21, 47-70) is GRAFTED at compile time, so the device search needs nothing new:
+        wherever a node of the main trie has a `bos_token_id` child, the allowed tokens are its other children plus the appended
+        trie's root tokens (`output.remove(bos); output += append_trie.trie_dict.keys()`, :54-57), and a token the main node does
+        not have leads into the appended trie (`append_trie.get(prefix_sequence)`, :66-68) -- the main trie wins when both have
+        the token (`elif prefix_sequence[0] in trie_dict`, :59).  The result is a DAG in the same CSR form (the appended trie's
+        nodes are shared by every graft point), children sorted by token as everywhere else."""
+        app = getattr(trie, "append_trie", None)
+        main = CompiledTrie.from_dict(trie.trie_dict)
+        if app is None:
+            return main
+        bos = trie.bos_token_id
+        sub = CompiledTrie.from_trie(app)               # (the appended trie may itself carry one)
+        base = main.n_nodes
+        rt, rn = sub.children(0)
+        off, tok, nxt = [0], [], []
+        for n in range(main.n_nodes):
+            t, c = main.children(n)
+            edges = [(int(a), int(b)) for a, b in zip(t, c)]
+            have = {a for a, _ in edges}
+            if bos in have:
+                edges = [(a, b) for a, b in edges if a != bos]
+                edges += [(int(a), base + int(b)) for a, b in zip(rt, rn) if int(a) not in have]
+                if bos in {int(a) for a in rt}:         # bos itself stays allowed then, and the main trie's edge is the one taken
+                    edges.append((int(bos), int(c[list(t).index(bos)])))
+            for a, b in sorted(edges):
+                tok.append(a)
+                nxt.append(b)
+            off.append(len(tok))
+        for n in range(sub.n_nodes):
+            t, c = sub.children(n)
+            for a, b in zip(t, c):
+                tok.append(int(a))
+                nxt.append(base + int(b))
+            off.append(len(tok))
+        out = CompiledTrie(np.asarray(off), np.asarray(tok), np.asarray(nxt))
+        out.grafted = True
+        return out
 
     @staticmethod
     def from_sequences(seqs: Iterable[Sequence[int]]) -> "CompiledTrie":
@@ -153,6 +189,8 @@ class CompiledTrie:
     # excluded", which is a bitmap over node ids) ----
     def index_items(self, seqs: Sequence[Sequence[int]]) -> None:
         """Record, for each item sequence (in the caller's order), the node ids along its path."""
+        if self.grafted:
+            raise NotImplementedError("per-item bookkeeping (history exclusion) on a trie with an appended trie")
         edge = {}
         off, tok, nxt = self.child_off, self.child_tok, self.child_node
         for n in range(self.n_nodes):

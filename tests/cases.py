@@ -530,7 +530,13 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
     ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
     items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
     trie = Trie(items)
-    if via == "ours":
+    if via == "append":             # generation_trie.py:19-21: a second trie takes over where the first one reaches `bos_token_id`
+        bos = min(61, ocfg.vocab_size - 2)
+        heads = sorted({tuple(it[:4]) for it in items})                      # the first four tokens of the item ids: several graft points ...
+        trie = Trie([list(h) + [bos] for h in heads])
+        trie.append(Trie([list(it[4:]) for it in items]), bos)               # ... sharing ONE appended trie of their tails (ending in </s>)
+        fn = prefix_allowed_tokens_fn(trie)
+    elif via == "ours":
         fn = prefix_allowed_tokens_fn(trie)
     elif via == "closure":          # the reference's closure style (generation_trie.py:91-97)
         def make(candidate_trie):

@@ -170,7 +170,7 @@ def test_golden(emu, name):
     cases.golden_case(emu, name)
 
 
-@pytest.mark.parametrize("via", ["ours", "closure", "opaque"])
+@pytest.mark.parametrize("via", ["ours", "closure", "opaque", "append"])
 def test_generate(emu, via):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
 

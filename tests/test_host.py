@@ -333,3 +333,49 @@ def test_filtered_id_metrics_match_string_metrics():
     a = evaluate.rel_results_filtered_ids(seqs, scores, gold_ids, positive_idx, seq2idx, k)
     ref = evaluate.rel_results_filtered(positive_txt, id2user, user_idx, width, gen_txt, gold_txt, scores.reshape(-1).tolist(), k)
     assert a == ref and any(sum(r) for r in a)
+
+
+def test_compiled_trie_grafts_an_appended_trie():
+    """generation_trie.py:19-21, 47-70: `Trie.append(trie, bos_token_id)`.  The CSR compilation grafts the appended trie wherever
+    the main trie has a `bos` child; walking the compiled automaton must allow exactly what `Trie.get` allows after every
+    prefix that `Trie.get` itself can generate."""
+    import random
+    from openp5_amd.trie import Trie, CompiledTrie
+    rnd = random.Random(3)
+    BOS = 7
+    for trial in range(20):
+        main_seqs, app_seqs = [], []
+        for _ in range(rnd.randint(2, 8)):
+            q = [0] + [rnd.randint(2, 12) for _ in range(rnd.randint(1, 4))]
+            if rnd.random() < 0.7:
+                q.append(BOS)                       # hand-over point
+                if rnd.random() < 0.3:
+                    q += [rnd.randint(2, 12), 1]    # (the main trie may also continue behind its own bos: never reachable)
+            else:
+                q.append(1)
+            main_seqs.append(q)
+        for _ in range(rnd.randint(1, 6)):
+            app_seqs.append([rnd.randint(2, 12) for _ in range(rnd.randint(1, 3))] + [1])
+        if trial % 4 == 0:
+            app_seqs.append([BOS, 3, 1])            # the appended trie's root may have the bos token too
+        t, a = Trie(main_seqs), Trie(app_seqs)
+        t.append(a, BOS)
+        ct = CompiledTrie.from_trie(t)
+        assert ct.grafted and ct.max_children >= 1
+        # breadth-first over every prefix the host trie can produce
+        frontier, seen = [([], 0)], 0
+        while frontier:
+            nxt = []
+            for prefix, node in frontier:
+                toks, kids = ct.children(node)
+                want = t.get(prefix)
+                assert sorted(set(int(x) for x in toks)) == sorted(set(want)), (trial, prefix, list(toks), want)
+                assert list(toks) == sorted(toks)
+                for tok, kid in zip(toks, kids):
+                    nxt.append((prefix + [int(tok)], int(kid)))
+                seen += 1
+            frontier = nxt
+            assert seen < 20000
+        assert ct.max_depth >= max(len(q) for q in main_seqs)
+    with pytest.raises(NotImplementedError):
+        ct.index_items(main_seqs)
