@@ -132,7 +132,7 @@ def test_golden_t5_small_dims(hip):
     cases.golden_case(hip, "t5small_relu", nll_tol=1e-4, grad_tol=1e-3, score_tol=1e-4)
 
 
-@pytest.mark.parametrize("via", ["ours", "closure", "opaque"])
+@pytest.mark.parametrize("via", ["ours", "closure", "opaque", "append"])
 def test_generate(hip, via):
     cases.generate_case(hip, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
 
