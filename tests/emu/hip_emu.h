@@ -109,9 +109,13 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
   static std::vector<char*> stacks;
   while (stacks.size() < nt) stacks.push_back((char*)aligned_alloc(64, kStack));
   std::vector<char> dyn(shmem + 64);
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
+  // P5_EMU_BLOCK_ORDER=reverse: workgroups run last-to-first.  Any order is a valid execution of kernels whose workgroups only meet in
+  // atomics; it changes the order fp32 atomics land in -- the one thing that differs between two runs on the device.
+  static const bool reverse = getenv("P5_EMU_BLOCK_ORDER") && !strcmp(getenv("P5_EMU_BLOCK_ORDER"), "reverse");
+  const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
+  for (unsigned long long lin = 0; lin < nblk; ++lin) {
+        const unsigned long long id = reverse ? nblk - 1 - lin : lin;
+        const unsigned bx = (unsigned)(id % grid.x), by = (unsigned)((id / grid.x) % grid.y), bz = (unsigned)(id / ((unsigned long long)grid.x * grid.y));
         b.fibers.assign(nt, Fiber());
         b.waves.assign((nt + 63) / 64, Wave());
         b.nthreads = b.live = nt;

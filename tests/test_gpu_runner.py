@@ -133,17 +133,18 @@ def test_resume_on_device(hip, tmp_path):
     diff = float((second.model._flat - straight.model._flat).abs().max())
     scale = float(straight.model._flat.abs().max())
     print(f"[resume] max |param diff| resumed vs straight {diff:.3e} (run-to-run noise of the straight run {noise:.3e}, largest parameter {scale:.3f})")
-    # What the device shows (round 3, seven runs of this test): two STRAIGHT runs of the same two epochs agree to 2.4e-7 in some
-    # processes and differ by 6.7e-5 .. 5.5e-4 (max |param diff|) in others; the RESUMED run ends up to 5.7e-3 (~ 2 x lr; 1.9e-4
-    # relative L2; first moments 4.6e-2 relative L2) away from the straight one.  The toy's ragged token counts put every weight
-    # gradient on the split-K path with fp32 atomics; their arrival order depends on what ran on the device before (a resumed run
-    # starts cold), and AdamW amplifies an ordering-sized change of a near-zero gradient element to a fraction of lr per step.  That
-    # the STATE survives the round trip is proven bit-exactly on the host emulation for both engines
-    # (tests/test_runner_emu.py::test_resume_is_exact[fp32|bf16]); a NaN-poisoned workspace / gradient arena shows no uninitialised
-    # read (tools/diag_poison.py, test_backward_writes_every_gradient_after_zero_grad).  The device gate is therefore aggregate and
-    # sized to catch a LOST piece of state -- a missing optimizer moment, schedule position, dropout counter or data order moves every
-    # parameter by ~lr per step (relative L2 >= 1e-2) -- not ordering noise.  (DESIGN.md section 7 lists the open question whether
-    # ordering noise explains all of the 5.7e-3.)
+    # OPEN (round 3, found when the round's GPU budget was nearly spent).  Observed over seven runs of this test on the device: two
+    # STRAIGHT runs of the same two epochs agree to 2.4e-7 in some processes and differ by 6.7e-5 .. 5.5e-4 (max |param diff|) in
+    # others; the RESUMED run ends up to 5.7e-3 (~ 2 x lr; 1.9e-4 relative L2; first moments 4.6e-2 relative L2) away from the
+    # straight one.  What it is NOT: lost state -- the round trip is bit-exact on the host emulation for both engines
+    # (tests/test_runner_emu.py::test_resume_is_exact[fp32|bf16]); an uninitialised read of the workspace or the gradient arena --
+    # NaN-poisoned runs are clean (tools/diag_poison.py, test_backward_writes_every_gradient_after_zero_grad); the order of the fp32
+    # atomics -- the emulation with the workgroups run last-to-first (P5_EMU_BLOCK_ORDER=reverse, every atomic sum in the opposite
+    # order) reproduces this very training to 2.4e-7 / 1.3e-9 relative L2, exactly the floor seen on the device in the good cases
+    # (tests/test_runner_emu.py::test_training_is_insensitive_to_atomic_order).  So a device-only effect with a few discrete outcomes
+    # remains to be found (next round: bisect with grad_store_first / norm_fuse / dropout off on this test).  Until then the device
+    # gate is aggregate and sized to catch a LOST piece of state -- a missing optimizer moment, schedule position, dropout counter or
+    # data order moves every parameter by ~lr per step (relative L2 >= 1e-2).
     ref = straight.model._flat
     rel_l2 = float((second.model._flat - ref).norm() / ref.norm())
     rel_l2_noise = float((again.model._flat - ref).norm() / ref.norm())
