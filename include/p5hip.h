@@ -125,7 +125,9 @@ int64_t p5_generate_workspace_bytes(const P5Engine* e, int B, int L, int K, int 
  * without building one trie per user).  NULL / 0 = nothing excluded.
  * Replaces P5_T5.generate(...) = HF beam search + PrefixConstrainedLogitsProcessor (DistributedRunner.py:361-371).
  * Enqueues the whole search and returns WITHOUT synchronising: HF's stop test is taken on the device, so no step reads
- * anything back.  max_len bounds the number of decode steps enqueued (max_len - 1): pass min(max_length, depth of the trie). */
+ * anything back.  max_len bounds the number of decode steps enqueued (max_len - 1): pass min(max_length, depth of the trie).
+ * Limits: 1 <= K <= 64 beams, 2 <= max_len <= 128; the trie may be any DAG in this CSR form (an appended trie, generation_trie.py:19-21,
+ * is grafted by the caller -- openp5_amd/trie.py::CompiledTrie.from_trie). */
 int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                 const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,

@@ -259,10 +259,11 @@ struct P5BeamState {
 
 // ---- shared tail of the beam step: HF steps d-g (utils.py:3131-3204, 3008-3075) from the item's top-2K candidate list in
 // `sh`, materialisation of the new finished / running sets, step counter + stop flag.  `st` is already parity-swapped. ----
-// longest hypothesis the decode kernels hold (beam bookkeeping below in LDS, ancestry gather of p5_dec_self_attn2_kernel unrolled over
-// max_len / 8 passes); p5_generate / p5_decode_begin refuse anything longer (p5_lib.hip) -- one constant for both sides
+// longest hypothesis the decode kernels hold (beam bookkeeping below in LDS: 3 x P5_MAX_K x P5_MAX_LEN ints = 96 KiB; ancestry gather of
+// p5_dec_self_attn2_kernel unrolled over P5_MAX_LEN / 8 passes); p5_generate / p5_decode_begin refuse anything longer (p5_lib.hip) -- one
+// constant for both sides.  OpenP5 decodes item ids of <= 30 tokens (DistributedRunner.py:361-371, max_length=30)
 #ifndef P5_MAX_LEN
-#define P5_MAX_LEN 64
+#define P5_MAX_LEN 128
 #endif
 struct P5BeamSh {
   float top_lp[P5_MAX_K2], run_lp[P5_MAX_K2], msc[P5_MAX_K + P5_MAX_K2];

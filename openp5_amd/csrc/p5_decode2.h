@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256) void p5_rmsnorm_f32in_kernel(T* __restrict__ y
 
 // ---- single-token self-attention over the ancestry-indexed cache, one wave per (row, head) ----
 // lane = (key slot ts = lane / 8, dim chunk dc = lane % 8 -> 8 dims): 8 cached positions are scored per pass with 16-byte
-// loads, all passes' loads are independent (max_len <= 64 -> at most 8 passes, unrolled), so a wave has one ancestry gather
-// and one K/V gather in flight instead of a dependent chain of `pos` of each.
-template <class T>
+// loads, all passes' loads are independent (NP passes, unrolled: 8 for max_len <= 64, 16 up to P5_MAX_LEN = 128), so a wave has one
+// ancestry gather and one K/V gather in flight instead of a dependent chain of `pos` of each.
+template <class T, int NP = 8>
 __global__ __launch_bounds__(256) void p5_dec_self_attn2_kernel(T* __restrict__ out, const T* __restrict__ qkv, T* __restrict__ cache,
                                                                const int* __restrict__ anc_odd, const int* __restrict__ anc_even,
                                                                const float* __restrict__ rel_table, const int* __restrict__ lut, int lut_half, int R,
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(256) void p5_dec_self_attn2_kernel(T* __restrict__ 
     st8(cache + ((size_t)pos * R + r) * 2 * inner + h * 64 + dc * 8, kc);
     st8(cache + ((size_t)pos * R + r) * 2 * inner + inner + h * 64 + dc * 8, vc);
   }
-  float s[8], vv[8][8];
+  float s[NP], vv[NP][8];
   float m = P5_NEG_INF;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NP; ++it) {
     const int t = it * 8 + ts;
     s[it] = P5_NEG_INF;
 #pragma unroll
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void p5_dec_self_attn2_kernel(T* __restrict__ 
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NP; ++it) {
     const float p = (s[it] == P5_NEG_INF) ? 0.f : expf(s[it] - m);
     l += p;
 #pragma unroll

@@ -1545,8 +1545,12 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
     const LayerOff& lo = e->dec[i];
     // ---- self-attention: qkv = norm(x) Wqkv^T ; attention over the ancestry-indexed cache ; x += o Wo^T ----
     P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.sa.ln, Wc<T>(e, lo.sa.q), d, w.qkv, 3 * in, R, 3 * in, d, P5_SK_STORE, 1.f, c.eps, done));
-    P5_LAUNCH((p5_dec_self_attn2_kernel<T>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
-              (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
+    if (max_len <= 64)
+      P5_LAUNCH((p5_dec_self_attn2_kernel<T, 8>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
+                (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
+    else
+      P5_LAUNCH((p5_dec_self_attn2_kernel<T, P5_MAX_LEN / 8>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
+                (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
     P5_TRY(P5_KCHECK());
     P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.sa.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
     // ---- cross-attention ----
@@ -2099,7 +2103,8 @@ int p5_decode_begin(P5Engine* e, const int64_t* input_ids, const int64_t* whole_
                     const uint32_t* excluded_nodes, int excluded_words, int max_children, void* ws, int64_t ws_bytes, void* stream) {
   P5_REQUIRE(e->P, "engine not bound");
   P5_REQUIRE(K >= 1 && K <= 64, "1 <= num_beams <= 64");
-  P5_REQUIRE(max_len >= 2 && max_len <= P5_MAX_LEN, "2 <= max_length <= 64 (P5_MAX_LEN)");
+  P5_REQUIRE(max_len >= 2 && max_len <= P5_MAX_LEN, "2 <= max_length <= 128 (P5_MAX_LEN)");
+  P5_REQUIRE(max_len <= 64 || g_opt_decode_v2, "max_length > 64 needs the decode_v2 step (the first-generation self-attention kernel keeps one score per lane)");
   P5_REQUIRE(L >= 1 && L <= 512, "1 <= L <= 512");
   P5_REQUIRE(max_children >= 1, "max_children");
   P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");

@@ -523,12 +523,12 @@ def make_items(n_items, seed, lo=7, hi=40, prefix=(0, 5, 6), minlen=2, maxlen=4)
     return sorted(list(x) for x in items)
 
 
-def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours"):
+def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours", id_len=(2, 4)):
     params = O.init_params(ocfg, 7)
     m = build_model(be, ocfg, params, dtype)
     m.eval()
     ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
-    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
+    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1), minlen=id_len[0], maxlen=id_len[1])
     trie = Trie(items)
     if via == "append":             # generation_trie.py:19-21: a second trie takes over where the first one reaches `bos_token_id`
         bos = min(61, ocfg.vocab_size - 2)

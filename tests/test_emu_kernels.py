@@ -175,6 +175,12 @@ def test_generate(emu, via):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, via=via)
 
 
+def test_generate_ids_longer_than_64_tokens(emu):
+    """max_length up to P5_MAX_LEN = 128: the decode step's self-attention takes the 16-pass build, the beam bookkeeping holds 128
+    positions per hypothesis (OpenP5 itself never exceeds 30, DistributedRunner.py:361-371)."""
+    cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 12, 3, 100, 12, id_len=(66, 80), seed=3)
+
+
 def test_generate_unfused_decode_norms(emu):
     """the decode step with separate RMSNorm kernels (p5_set_option decode_fused 0) -- the default folds them into the GEMMs."""
     try:
