@@ -6,6 +6,12 @@
 // kernel sources against this header lets the not-gpu test-suite exercise every kernel's index
 // arithmetic, masking, softmax/backward algebra and the engine's orchestration on the host CPU.
 //
+// Adversarial modes (environment, read once per process; tests/test_emu_kernels.py::test_kernels_under_adversarial_emulation):
+//   P5_EMU_POISON_LDS=1        every __shared__ array holds 0xFF bytes (NaN / -1) at the start of a launch
+//   P5_EMU_FIBER_ORDER=reverse the threads of a workgroup are resumed last-to-first between barriers
+//   P5_EMU_BLOCK_ORDER=reverse the workgroups of a launch run last-to-first (order of global atomics)
+// What the emulation cannot show: timing of asynchronous direct-to-LDS copies (vmcnt bookkeeping), real wave interleavings.
+//
 // It is NOT a product path: the shipped library (libp5hip.so) is compiled by hipcc for gfx950 only
 // and the Python package refuses to run without it.  Nothing under openp5_amd/ loads the emulator;
 // only tests/ build and inject it.
@@ -30,7 +36,13 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+// LDS: function-local statics, all collected in one section so that the emulator can POISON them between workgroups
+// (P5_EMU_POISON_LDS=1): on the device a workgroup finds whatever the previous workgroup on that CU left in LDS; here every array
+// would otherwise keep its own previous contents (deterministic, plausible values).  0xFF bytes are NaN in bf16 / fp32 and -1 as
+// integers, so a kernel that reads LDS it has not written shows up as NaN in its output.
+#define __shared__ static __attribute__((section("p5_lds")))
+extern "C" char __start_p5_lds[] __attribute__((weak));
+extern "C" char __stop_p5_lds[] __attribute__((weak));
 #define __restrict__ __restrict
 
 struct dim3 {
@@ -113,6 +125,10 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
   // atomics; it changes the order fp32 atomics land in -- the one thing that differs between two runs on the device.
   static const bool reverse = getenv("P5_EMU_BLOCK_ORDER") && !strcmp(getenv("P5_EMU_BLOCK_ORDER"), "reverse");
   const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
+  // (once per launch, not per workgroup -- the section holds the LDS of every kernel instantiation, ~12 MB: the launch's first
+  //  workgroup then runs on poisoned LDS, the later ones on what their predecessor left, like on the device)
+  static const bool poison_lds = getenv("P5_EMU_POISON_LDS") && atoi(getenv("P5_EMU_POISON_LDS")) != 0;
+  if (poison_lds && __start_p5_lds) memset(__start_p5_lds, 0xFF, (size_t)(__stop_p5_lds - __start_p5_lds));
   for (unsigned long long lin = 0; lin < nblk; ++lin) {
         const unsigned long long id = reverse ? nblk - 1 - lin : lin;
         const unsigned bx = (unsigned)(id % grid.x), by = (unsigned)((id / grid.x) % grid.y), bz = (unsigned)(id / ((unsigned long long)grid.x * grid.y));
@@ -141,10 +157,15 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
           for (int r = 0; r < 6; ++r) *(--sp) = nullptr;
           f.sp = sp;
         }
+        // P5_EMU_FIBER_ORDER=reverse: the threads of a workgroup are resumed last-to-first.  Between two barriers any order is a valid
+        // execution; a write that a LATER thread's read depends on without a barrier in between (a missing __syncthreads, hidden by
+        // the first-to-last order) then shows up as a wrong result.
+        static const bool frev = getenv("P5_EMU_FIBER_ORDER") && !strcmp(getenv("P5_EMU_FIBER_ORDER"), "reverse");
         unsigned remaining = nt;
         while (remaining) {
           remaining = 0;
-          for (unsigned t = 0; t < nt; ++t) {
+          for (unsigned tt = 0; tt < nt; ++tt) {
+            const unsigned t = frev ? nt - 1 - tt : tt;
             Fiber& f = b.fibers[t];
             if (f.done) continue;
             b.cur = &f;

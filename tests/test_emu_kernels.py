@@ -1,6 +1,7 @@
 """not-gpu: every HIP kernel + the engine, compiled for the host against tests/emu/hip_emu.h, checked against torch /
 the oracle.  This validates index arithmetic, masking, softmax / backward algebra and orchestration; the -m gpu suite
 re-runs the same cases on the real gfx950 build (which is what validates the hardware layout assumptions)."""
+import os
 import pytest
 
 from oracle import t5_oracle as O
@@ -295,3 +296,18 @@ def test_generate_wide_fanout(emu, n_wide, K):
     """trie levels with 300 / 1100 siblings (ML-1M-like number pieces, collaborative <CIk> tokens): the streaming head's
     per-row radix select, including the ties of the dead beams, reproduces HF's top-2K order."""
     cases.generate_wide_fanout_case(emu, O.T5Cfg.named("tiny", vocab_size=1200), 2, 16, K, n_wide)
+
+
+@pytest.mark.parametrize("env", [{"P5_EMU_POISON_LDS": "1"}, {"P5_EMU_FIBER_ORDER": "reverse"}, {"P5_EMU_BLOCK_ORDER": "reverse"}])
+def test_kernels_under_adversarial_emulation(env):
+    """The emulator's three adversarial modes (tests/emu/hip_emu.h) on a cross-section of the kernel tests, in a fresh process each
+    (the modes are read once per process): LDS poisoned with NaN bytes before every launch (a kernel that reads LDS it has not written),
+    the threads of a workgroup resumed last-to-first (a missing barrier hidden by the first-to-last order), the workgroups run
+    last-to-first (order of the fp32 atomics).  The full kernel suite passes under each of them (round 3); this keeps a slice of
+    it in the default run."""
+    import subprocess
+    import sys
+    sel = "test_model_bf16 or test_golden or gemm_persistent_ring or wave_specialised or test_generate_excluded_history or attn_bwd_fused"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
+                       env={**os.environ, **env}, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
