@@ -1159,7 +1159,9 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   if (stage == 0) {
     if (e->grads_keep) {
       e->wg_epi = P5_EPI_ACCUM;                 // a later micro-batch of an accumulation group: everything adds
-    } else if (sizeof(T) == 2 && g_opt_grad_store_first && g_opt_wgrad_group) {
+    } else if (sizeof(T) == 2 && g_opt_grad_store_first && g_opt_wgrad_group && (M % 64) == 0 && (Md % 64) == 0) {
+      // (token counts that are multiples of 64 -- every batch of 64 sequences -- put ALL weight gradients on the grouped, storing
+      //  path; ragged counts keep the clear-then-add form below: their split-K atomics need a cleared target anyway)
       if (!e->grads_zeroed) P5_TRY(zero_small_grads(e, s));
       e->wg_epi = P5_EPI_STORE;
     } else {
