@@ -183,10 +183,13 @@ int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, cons
 int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table,
                    const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
                    int ldv, int ldo, int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
+/* d_rel_table [rel_buckets, H] (+=, may be NULL): the gradient of the relative-bias table is reduced WITHOUT fp32 atomics -- every
+ * workgroup adds into its own slot of d_rel_scratch (caller-provided float[B * ceil(Lq / 64)][rel_buckets * H], cleared here) and the
+ * slots are summed in index order, so the result is bit-reproducible. */
 int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                   float* Dvec, void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, const int* lut,
-                   int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-                   int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
+                   float* Dvec, void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch,
+                   int rel_buckets, const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
+                   int ldv, int ldo, int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
                    void* stream);
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream);
 /* decode-step projection over a few hundred rows (p5_decode2.h): C = A W^T, W = T [N, ldw].  amode 0: A = T [M, lda];

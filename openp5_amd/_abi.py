@@ -64,7 +64,7 @@ PROTOTYPES = {
     "p5_op_rmsnorm_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, vp]),
     "p5_op_rmsnorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "p5_op_attn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u32, f32, vp]),
-    "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+    "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                             i32, i32, i32, i32, vp, u32, f32, vp]),
     "p5_op_ce_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "p5_op_dec_cross_attn": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -145,6 +145,41 @@ __device__ static __forceinline__ void stage_bias_mask(const P5AttnArgs& a, int 
     skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
 }
 
+
+// d(relative-bias table), deterministic: `sv[i]` holds this workgroup's sum of dS over relative position i - (Lq - 1) (already in a
+// fixed association).  Positions -> buckets: thread t < 64 owns bucket t and adds the positions that map to it in increasing order
+// (it scans only [first, last] position of its bucket -- T5's bucket function is monotone on either side of 0, so that interval holds
+// nothing else; integer LDS min/max give the same interval on every run), then adds its sum to THIS workgroup's slot of the partial
+// table with a plain read-modify-write: slot `slot` is touched by exactly one workgroup per launch, and the launches of a backward
+// (one per layer) are ordered by the stream.  p5_reduce_copies_kernel sums the slots in index order.  No fp32 atomics anywhere:
+// rounds 1-3 used LDS and global float atomics here, whose arrival order changed the last bits of the table's gradient from run to run.
+// `scratch`: >= 128 ints + nrel bytes of LDS that are dead by now.  Called by the NT threads of a workgroup (NT > 64: contains
+// workgroup barriers) or by ONE wave (NT == 64: wave-level ordering only, the other waves of the workgroup carry on).
+template <int NT>
+__device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, int h, int slot, const float* sv, void* scratch, int tid) {
+#define P5_RB_SYNC() do { if constexpr (NT == 64) { P5_WAVE_SYNC(); } else { __syncthreads(); } } while (0)
+  const int nrel = a.Lq + a.Lk - 1;
+  int* slo = (int*)scratch;
+  int* shi = slo + 64;
+  unsigned char* sid = (unsigned char*)(shi + 64);
+  if (tid < 64) { slo[tid] = 0x7fffffff; shi[tid] = -1; }
+  P5_RB_SYNC();
+  for (int i = tid; i < nrel; i += NT) {
+    const int bk = a.bucket_lut[i - (a.Lq - 1) + a.lut_half] & 63;
+    sid[i] = (unsigned char)bk;
+    atomicMin(&slo[bk], i);
+    atomicMax(&shi[bk], i);
+  }
+  P5_RB_SYNC();
+#undef P5_RB_SYNC
+  if (tid < 64 && shi[tid] >= 0) {
+    float acc = 0.f;
+    for (int i = slo[tid]; i <= shi[tid]; ++i) acc += (sid[i] == tid) ? sv[i] : 0.f;
+    float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
+    *dst += acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------
@@ -421,8 +456,8 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char tileK[64 * C::TS];
   __shared__ __attribute__((aligned(16))) char tileV[64 * C::TS];
   __shared__ __attribute__((aligned(16))) char pbuf[4 * 16 * C::TS];
-  __shared__ float sbias[1024];
-  __shared__ float sdb[1024];
+  __shared__ __attribute__((aligned(16))) float sbias[1024];
+  __shared__ float sdb[4][1024];          // per-wave sums of dS along the diagonals (relative positions)
   __shared__ __attribute__((aligned(16))) float skneg[512];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -435,7 +470,7 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
 
   stage_bias_mask(a, b, h, sbias, skneg, nch * 64, tid);
   if (a.d_rel_table)
-    for (int i = tid; i < nrel; i += 256) sdb[i] = 0.f;
+    for (int i = tid; i < 4 * 1024; i += 256) (&sdb[0][0])[i] = 0.f;
 
   u32x4 qf[C::NCK], dof[C::NCK];
   float Drow = 0.f;
@@ -515,8 +550,9 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
     }
     __syncthreads();
     if (a.d_rel_table) {
-      // d(rel-bias): sum dS along the diagonals (constant key - query) of this wave's [16 q][64 keys] tile held in
-      // LDS -- one LDS atomic per diagonal per wave instead of one per score element
+      // d(rel-bias): sum dS along the diagonals (constant key - query) of this wave's [16 q][64 keys] tile held in LDS, into
+      // the wave's OWN row of sums (plain read-modify-write: the lanes of a wave hold different diagonals, its key chunks come
+      // one after the other) -- no LDS atomics, same association every run
       for (int dd = lane; dd < 79; dd += 64) {
         float sum = 0.f;
 #pragma unroll
@@ -525,7 +561,7 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
           if (kcol >= 0 && kcol < 64) sum += to_f<T>(*(const T*)(pw + qr * C::TS + kcol * C::SZ));
         }
         const int idx = ch * 64 + dd - 15 - q0 + a.Lq - 1;
-        if (sum != 0.f && idx >= 0 && idx < nrel) atomicAdd(&sdb[idx], sum);
+        if (idx >= 0 && idx < nrel) sdb[wave][idx] += sum;
       }
     }
 #pragma unroll
@@ -540,21 +576,10 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
     wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, pw, lane);
   }
   if (a.d_rel_table) {
-    // relative positions -> buckets inside the workgroup, then one global atomic per (bucket, head) into one of
-    // `rel_copies` partial tables (same-address atomics from ~B*Lq/64 workgroups serialise at L2 otherwise)
     __syncthreads();
-    float* sbk = sbias;   // sbias is dead from here on
-    if (tid < 64) sbk[tid] = 0.f;
+    for (int i = tid; i < nrel; i += 256) sdb[0][i] = ((sdb[0][i] + sdb[1][i]) + sdb[2][i]) + sdb[3][i];      // (waves in index order)
     __syncthreads();
-    for (int i = tid; i < nrel; i += 256) {
-      const float v = sdb[i];
-      if (v != 0.f) atomicAdd(&sbk[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] & 63], v);
-    }
-    __syncthreads();
-    if (tid < 64 && sbk[tid] != 0.f) {
-      const int copy = a.rel_copies > 1 ? (b % a.rel_copies) : 0;
-      atomicAdd(&a.d_rel_table[(size_t)copy * a.rel_stride + tid * a.H + h], sbk[tid]);
-    }
+    rel_bias_grad_flush<256>(a, h, b * (int)gridDim.x + (int)blockIdx.x, &sdb[0][0], sbias, tid);      // (sbias is dead from here on)
   }
 }
 
@@ -825,14 +850,11 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
   __syncthreads();      // P and dS complete; K and V tiles dead from here on
 
   if (a.d_rel_table && wave == 7) {
-    // relative positions -> buckets -> one global atomic per (bucket, head) into one of `rel_copies` partial tables, by ONE
-    // wave and BEFORE phase B: a workgroup does not retire until its atomics have returned (~4 us when they were the last thing
-    // it did), so they are put in flight here, under the MFMAs and stores of phase B
-    float* sbk = sbias;   // (dead since phase A)
-    sbk[lane] = 0.f;
-    P5_WAVE_SYNC();
+    // by ONE wave and BEFORE phase B, so that the other waves' MFMAs and stores cover it.  Relative positions: the eight waves'
+    // diagonal sums added in wave order (relative position i - (Lq - 1) is diagonal dd = i + 15 + 16 w - (Lq - 1) of wave w's
+    // rows), then positions -> buckets -> this workgroup's slot of the partial table (rel_bias_grad_flush)
+    float* sv = (float*)tV;               // (the V tile is dead; the staging of dQ / dK / dV below uses the K tile only)
     for (int i = lane; i < nrel; i += 64) {
-      // relative position i - (Lq - 1) is diagonal dd = i + 15 + 16 w - (Lq - 1) of wave w's rows
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
@@ -841,13 +863,9 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
         const float x = sdiag[w * 144 + (in ? dd : 0)];
         v += in ? x : 0.f;
       }
-      if (v != 0.f) atomicAdd(&sbk[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] & 63], v);
+      sv[i] = v;
     }
-    P5_WAVE_SYNC();
-    if (sbk[lane] != 0.f) {
-      const int copy = a.rel_copies > 1 ? (b % a.rel_copies) : 0;
-      atomicAdd(&a.d_rel_table[(size_t)copy * a.rel_stride + lane * a.H + h], sbk[lane]);
-    }
+    rel_bias_grad_flush<64>(a, h, b, sv, sbias, lane);       // (sbias: dead since phase A; 256 floats >= 128 ints + 255 bytes)
   }
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   char* scratch = tK + wave * 16 * C::TS;     // (8 waves x 16 rows = exactly the K tile)

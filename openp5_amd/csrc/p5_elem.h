@@ -306,24 +306,39 @@ __global__ __launch_bounds__(256) void p5_reduce_splits_kernel(T* __restrict__ o
   }
 }
 
-// dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials); grid = (d/64, row slices)
-__global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d) {
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  __shared__ float sred[4][64];
-  const int per = (nrows + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = (b0 + per < nrows) ? b0 + per : nrows;
+// dst[j] += sum_b partial[b][j]  (per-workgroup norm-weight gradient partials).  DETERMINISTIC: one workgroup owns 16 columns and
+// sums ALL partial rows in a fixed association -- 16 row classes (b mod 16) summed sequentially in registers, then the classes in index
+// order -- and is the only writer of its columns (plain read-modify-write, no atomics): the same bits on every run.  (Rounds 1-3 split
+// the rows over 16 workgroups that added with fp32 atomics; their arrival order made the last bits of every T5LayerNorm gradient vary
+// from run to run, and AdamW turns a last-bit difference of a near-zero gradient into an O(lr) difference of the parameter.)
+// grid = (d/16); 256 threads = 16 row classes x 16 columns.
+__device__ static __forceinline__ void reduce_rows_16col(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d, int cg) {
+  const int col = cg * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+  __shared__ float sred[16][17];
   float s = 0.f;
-  if (j < d)
-    for (int b = b0 + part; b < b1; b += 4) s += partial[(size_t)b * d + j];
-  sred[part][threadIdx.x & 63] = s;
+  if (col < d) {
+    int b = part;
+    for (; b + 48 < nrows; b += 64) {      // four independent loads in flight, added in row order
+      const float v0 = partial[(size_t)b * d + col], v1 = partial[(size_t)(b + 16) * d + col];
+      const float v2 = partial[(size_t)(b + 32) * d + col], v3 = partial[(size_t)(b + 48) * d + col];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; b < nrows; b += 16) s += partial[(size_t)b * d + col];
+  }
+  sred[part][threadIdx.x & 15] = s;
   __syncthreads();
-  if (part == 0 && j < d) {
-    const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
-    if (v != 0.f) atomicAdd(dst + j, v);
+  if (part == 0 && col < d) {
+    float v = sred[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v += sred[q][threadIdx.x];
+    dst[col] += v;
   }
 }
+__global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__ dst, const float* __restrict__ partial, int nrows, int d) {
+  reduce_rows_16col(dst, partial, nrows, d, blockIdx.x);
+}
 
-// the same for every T5LayerNorm of a backward stage in ONE launch: slot z = blockIdx.z reduces its partial rows into its weight's
+// the same for every T5LayerNorm of a backward stage in ONE launch: slot z = blockIdx.y reduces its partial rows into its weight's
 // gradient (32 launches per T5-small step -> 14)
 struct P5ReduceMulti {
   int n, d;
@@ -331,23 +346,8 @@ struct P5ReduceMulti {
   long long dst_off[4], part_off[4];    // element offsets into the gradient arena / the partial-sum scratch
 };
 __global__ __launch_bounds__(256) void p5_reduce_rows_multi_kernel(P5ReduceMulti a, float* __restrict__ G, const float* __restrict__ scratch) {
-  const int z = blockIdx.z;
-  const int nrows = a.nrows[z], d = a.d;
-  float* __restrict__ dst = G + a.dst_off[z];
-  const float* __restrict__ partial = scratch + a.part_off[z];
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  __shared__ float sred[4][64];
-  const int per = (nrows + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = (b0 + per < nrows) ? b0 + per : nrows;
-  float s = 0.f;
-  if (j < d)
-    for (int b = b0 + part; b < b1; b += 4) s += partial[(size_t)b * d + j];
-  sred[part][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (part == 0 && j < d) {
-    const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
-    if (v != 0.f) atomicAdd(dst + j, v);
-  }
+  const int z = blockIdx.y;
+  reduce_rows_16col(G + a.dst_off[z], scratch + a.part_off[z], a.nrows[z], a.d, blockIdx.x);
 }
 
 // dst[i] += sum_c partial[c][i]   (partial copies of the relative-bias gradient)

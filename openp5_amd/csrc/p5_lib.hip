@@ -19,6 +19,7 @@
 #include "p5_gemm5.h"
 #include "p5_attn.h"
 #include "p5_elem.h"
+#include "p5_embed.h"
 #include "p5_decode.h"
 #include "p5_decode2.h"
 #include "../../include/p5hip.h"
@@ -427,6 +428,11 @@ struct P5Engine {
   void* dy_next = nullptr;
   void *kv_all = nullptr, *dkv_all = nullptr;   // cross-attention K/V (and their gradients) of all decoder layers, [M, n_dec*2*inner]
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
+  // deterministic embedding gradients (p5_embed.h): set 0 = tied table E over the encoder ids followed by the decoder ids, set 1 = whole-word table
+  int* emb_idx[P5_EMB_MAXSETS] = {};     // perm | skey | sstart | slen, n ints each
+  float* emb_part[P5_EMB_MAXSETS] = {};
+  float* dres_dec0 = nullptr;            // [Md, d] gradient of the decoder's embedding rows (kept until the last stage)
+  float* dres_out_override = nullptr;    // the next swap_norm_bwd writes its residual gradient here
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
@@ -695,11 +701,19 @@ static int dgrad_w(P5Engine* e, hipStream_t s, const void* dy, int lddy, int64_t
     return gemm<T>(s, dy, lddy, 0, (const T*)e->St + w_off, N_out, 0, dx, lddx, M, K_in, N_out, epi, aux, ldaux, alpha, c_f32, no_drop());
   return linear_dgrad<T>(s, dy, lddy, Wc<T>(e, w_off), dx, lddx, M, N_out, K_in, epi, aux, ldaux, alpha, c_f32);
 }
-// dW += dy^T x   (fp32 atomics into the grad arena)
+static int g_opt_wgrad_split_atomic = getenv("P5_WGRAD_SPLIT_ATOMIC") ? atoi(getenv("P5_WGRAD_SPLIT_ATOMIC")) : 0;    // 1 = split-K atomics (not reproducible)
+// dW += dy^T x   (into the grad arena)
 template <class T>
 static int linear_wgrad_on(hipStream_t s, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
                         float alpha = 1.f) {
-  return gemm<T>(s, dy, lddy, 1, x, ldx, 1, dW, K_in, N_out, K_in, M, P5_EPI_ATOMIC, nullptr, 0, alpha, 1, no_drop());
+  // ONE split: every element of dW then receives exactly one add per backward -- the same bits on every run.  (Split-K with fp32
+  // atomics -- rounds 1-3 -- made the last bits depend on the order the splits landed in; the grouped bf16 path never splits.)
+  P5GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dy; g.B = x; g.C = dW; g.M = N_out; g.N = K_in; g.K = M; g.lda = lddy; g.ldb = ldx; g.ldc = K_in;
+  g.a_ks = 1; g.b_ks = 1; g.epi = P5_EPI_ATOMIC; g.c_f32 = 1; g.splitk = g_opt_wgrad_split_atomic ? 0 : 1; g.alpha = alpha; g.drop = no_drop();
+  g.rowss_invd = 1.0f / (float)M;
+  return launch_gemm<T>(g, s);
 }
 
 // Weight gradients of the bf16 engine are DEFERRED: the problem is queued and the whole layer's queue goes out as one launch of the
@@ -789,7 +803,9 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
   return P5_KCHECK();
 }
 
-static constexpr int REL_COPIES = 16;
+// relative-bias gradient: one slot of [rel_buckets, H] partial sums per attention-backward workgroup (batch item x 64-query block),
+// written with plain read-modify-writes by that workgroup only and summed in slot order (p5_attn.h rel_bias_grad_flush)
+static int rel_slots(int B, int Lq) { return B * ((Lq + 63) / 64); }
 static constexpr int P5_HEAD_SPLITS = 32;      // most K-splits of the tied head's input-gradient GEMM (slices of its partial-product buffer)
 
 // A backward that starts a new accumulation group does not clear the 4 B x n_params gradient arena and then add into it: every
@@ -798,6 +814,9 @@ static constexpr int P5_HEAD_SPLITS = 32;      // most K-splits of the tied head
 // gradients are sums of atomics / partial reductions (whole-word embedding, relative-bias tables, T5LayerNorm weights: ~1 MB of
 // T5-small's 242 MB) are cleared, by one table-driven launch.  Saves the fill and the read of the arena per step.
 static int g_opt_grad_store_first = getenv("P5_GRAD_STORE_FIRST") ? atoi(getenv("P5_GRAD_STORE_FIRST")) : 1;
+// embedding gradients as fixed-order segmented sums (p5_embed.h) instead of fp32 atomic scatters: bit-reproducible training (0 = the
+// atomic scatter of rounds 1-3, kept for A/B timing)
+static int g_opt_embed_det = getenv("P5_EMBED_DET") ? atoi(getenv("P5_EMBED_DET")) : 1;
 struct P5ZeroTab {
   int n;
   struct D { long long off; int count, blk0; } e[200];
@@ -899,8 +918,15 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     }
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
-    e->rel_partial = (float*)b.take((size_t)2 * REL_COPIES * c.rel_buckets * H * 4);
+    e->rel_partial = (float*)b.take((size_t)(rel_slots(B, L) + rel_slots(B, T > 0 ? T : 1)) * c.rel_buckets * H * 4);
     e->dw_scratch = (float*)b.take((size_t)(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2) * 1024 * d * 4);
+    {
+      const size_t n0 = M + Md, n1 = M;
+      e->emb_idx[0] = (int*)b.take(4 * n0 * 4); e->emb_idx[1] = (int*)b.take(4 * n1 * 4);
+      e->emb_part[0] = (float*)b.take(((n0 + P5_EMB_SEG - 1) / P5_EMB_SEG) * 2 * d * 4);
+      e->emb_part[1] = (float*)b.take(((n1 + P5_EMB_SEG - 1) / P5_EMB_SEG) * 2 * d * 4);
+      e->dres_dec0 = (float*)b.take((Md > 0 ? Md : 1) * d * 4);
+    }
     e->dn = b.take(Mx * d * sz);
     e->dO = b.take(Mx * in * sz);
     for (int p = 0; p < P5_NSETS; ++p) {
@@ -1095,10 +1121,7 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
 static int norm_flush(P5Engine* e, hipStream_t main) {
   P5ReduceMulti& r = e->nr_pending;
   if (r.n == 0) return 0;
-  int mx = 0;
-  for (int i = 0; i < r.n; ++i) mx = r.nrows[i] > mx ? r.nrows[i] : mx;
-  P5_LAUNCH(p5_reduce_rows_multi_kernel, dim3((r.d + 63) / 64, mx >= 64 ? 16 : 1, r.n), dim3(256), 0, wgrad_stream(e, main), r, e->G,
-            (const float*)e->dw_scratch);
+  P5_LAUNCH(p5_reduce_rows_multi_kernel, dim3((r.d + 15) / 16, r.n), dim3(256), 0, wgrad_stream(e, main), r, e->G, (const float*)e->dw_scratch);
   r.n = 0;
   return P5_KCHECK();
 }
@@ -1107,6 +1130,7 @@ template <class T>
 static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_off, const float* rstd, int rows, P5Drop din, P5Drop dnext,
                          bool has_res_in = true, const float* ssq = nullptr, void* n_out = nullptr) {
   float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
+  if (e->dres_out_override) { out = e->dres_out_override; e->dres_out_override = nullptr; }
   end_sublayer_sync(e, s);
   const int d = e->c.d_model;
   float* part = e->dw_scratch + (size_t)(e->norm_slot++) * 1024 * d;
@@ -1139,8 +1163,8 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.dQ = e->dqkv; a.dK = (T*)e->dqkv + in; a.dV = (T*)e->dqkv + 2 * in; a.Dvec = e->Dvec;
   a.rel_table = e->P + (is_dec ? e->off_dec_rel : e->off_enc_rel);
   a.rel_stride = c.rel_buckets * H;
-  a.rel_copies = REL_COPIES;
-  a.d_rel_table = e->rel_partial + (is_dec ? (size_t)REL_COPIES * a.rel_stride : 0);
+  a.rel_copies = 0;
+  a.d_rel_table = e->rel_partial + (is_dec ? (size_t)rel_slots(e->B, e->L) * a.rel_stride : 0);      // encoder slots, then decoder slots
   a.bucket_lut = is_dec ? e->lut_dec : e->lut_enc; a.lut_half = e->lut_half; a.kmask = is_dec ? nullptr : e->mask;
   a.B = e->B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.lddo = in;
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
@@ -1170,7 +1194,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     }
     e->grads_zeroed = false;
     e->grads_keep = false;
-    hipMemsetAsync(e->rel_partial, 0, (size_t)2 * REL_COPIES * c.rel_buckets * H * 4, s);
+    hipMemsetAsync(e->rel_partial, 0, (size_t)(rel_slots(e->B, e->L) + rel_slots(e->B, e->T)) * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     e->sub = -1;
     e->norm_slot = 0;
@@ -1256,6 +1280,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     // self attention
     begin_sublayer(e);
     P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
+    if (i == 0 && g_opt_embed_det) e->dres_out_override = e->dres_dec0;      // gradient of the decoder's embedding rows: consumed by the last stage
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
                             nf ? l.n_sa : nullptr));
     return wgrad_flush(e, s, false, (g_opt_wgrad_side & 1) != 0);     // the six weight gradients of the layer: one launch
@@ -1274,13 +1299,14 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
                              nullptr, 0, 1.f, 1));
     }
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
-              (const float*)(e->rel_partial + (size_t)REL_COPIES * c.rel_buckets * H), c.rel_buckets * H, REL_COPIES);
+              (const float*)(e->rel_partial + (size_t)rel_slots(e->B, e->L) * c.rel_buckets * H), c.rel_buckets * H, rel_slots(e->B, e->T));
     P5_TRY(P5_KCHECK());
 #ifndef P5_EMU
     // shared.weight's gradient: the tied head's weight gradient adds with plain read-modify-writes (side stream, stage 0); the
     // embedding scatters (atomics, from here on) must not run beside it
     if (e->side && e->head_wg_valid) { hipStreamWaitEvent(s, e->head_wg_ev, 0); e->head_wg_valid = false; }
 #endif
+    if (g_opt_embed_det) return 0;      // (the decoder's lookup rows join the encoder's in the last stage: one owner per row of the tied table)
     P5_LAUNCH((p5_embed_bwd_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, e->G + e->off_E, (float*)nullptr, (const float*)e->dres_cur,
               (const int64_t*)e->dec_ids, (const int64_t*)nullptr, Md, d, mk_drop(e, 1, 0, 0));
     return P5_KCHECK();
@@ -1323,8 +1349,30 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     if (e->side) { fork_to_side(e, s); s2 = e->side; }
 #endif
     P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s2, e->G + e->off_enc_rel,
-              (const float*)e->rel_partial, c.rel_buckets * H, REL_COPIES);
+              (const float*)e->rel_partial, c.rel_buckets * H, rel_slots(e->B, e->L));
     P5_TRY(P5_KCHECK());
+    if (g_opt_embed_det) {
+      // embedding gradients without atomics (p5_embed.h): tied table over (encoder ids ++ decoder ids), whole-word table over the encoder's
+      P5EmbArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.nsets = 2; ea.d = d;
+      const int n[2] = {M + Md, M};
+      for (int k = 0; k < 2; ++k) {
+        P5EmbSet& q = ea.s[k];
+        q.key0 = k == 0 ? e->ids : e->ww; q.dres0 = e->dres_cur; q.drop0 = mk_drop(e, 0, 0, 0); q.n0 = M;
+        if (k == 0) { q.key1 = e->dec_ids; q.dres1 = e->dres_dec0; q.drop1 = mk_drop(e, 1, 0, 0); q.n1 = Md; }
+        q.table = e->G + (k == 0 ? e->off_E : e->off_WW);
+        q.perm = e->emb_idx[k]; q.skey = q.perm + n[k]; q.sstart = q.skey + n[k]; q.slen = q.sstart + n[k];
+        q.part = e->emb_part[k];
+      }
+      P5_LAUNCH(p5_embed_rank_kernel, dim3((n[0] + 63) / 64, 2), dim3(256), 0, s, ea);
+      P5_TRY(P5_KCHECK());
+      const int nblk = (n[0] + P5_EMB_SEG - 1) / P5_EMB_SEG;
+      P5_LAUNCH(p5_embed_seg_kernel, dim3(nblk, 2), dim3(256), 0, s, ea);
+      P5_TRY(P5_KCHECK());
+      P5_LAUNCH(p5_embed_fix_kernel, dim3(nblk, 2), dim3(256), 0, s, ea);
+      return P5_KCHECK();
+    }
     // (a gather of the whole-word table's gradient -- one workgroup per (table row, 256-row slice), matching rows summed in
     //  registers, one atomic per column -- was measured: 4.545 vs 4.493 ms per step; index 0 (every pad) makes a few workgroups long)
     if (s2 != s) {
@@ -1846,6 +1894,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
   else if (!strcmp(name, "grad_store_first")) g_opt_grad_store_first = value;
+  else if (!strcmp(name, "embed_det")) g_opt_embed_det = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
   else if (!strcmp(name, "g4_wgs")) g_opt_g4_wgs = value;
   else return fail("p5_set_option: unknown option");
@@ -2221,7 +2270,7 @@ int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, cons
   P5_TRY(dtype == 1 ? rmsnorm_bwd<bf16>(s, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop(), dw_partial, &nblk)
                     : rmsnorm_bwd<float>(s, dres_out, dy_next, dw, dy, x, w, rstd, dres_in, rows, d, no_drop(), no_drop(), dw_partial, &nblk));
   if (dw_partial) {    // the engine's mode: per-workgroup partials + a separate reduction
-    P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 63) / 64, nblk >= 64 ? 16 : 1), dim3(256), 0, s, dw, (const float*)dw_partial, nblk, d);
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((d + 15) / 16), dim3(256), 0, s, dw, (const float*)dw_partial, nblk, d);
     P5_TRY(P5_KCHECK());
   }
   return 0;
@@ -2237,16 +2286,27 @@ int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void*
   return dtype == 1 ? launch_attn_fwd<bf16>(a, (hipStream_t)stream) : launch_attn_fwd<float>(a, (hipStream_t)stream);
 }
 int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, float* Dvec,
-                   void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, const int* lut, int lut_half,
-                   const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                   void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch, int rel_buckets, const int* lut,
+                   int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                    int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream) {
   P5AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.Q = Q; a.K = K; a.V = V; a.O = (void*)O; a.dO = dO; a.lse = (float*)lse; a.Dvec = Dvec; a.dQ = dQ; a.dK = dK; a.dV = dV;
-  a.rel_table = rel_table; a.d_rel_table = d_rel_table; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
+  a.rel_table = rel_table; a.d_rel_table = nullptr; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
-  a.lddv = lddv; a.causal = causal; a.rel_copies = 1; a.rel_stride = 0; a.drop = op_drop(rng_state, site, drop_p);
-  return dtype == 1 ? launch_attn_bwd<bf16>(a, (hipStream_t)stream) : launch_attn_bwd<float>(a, (hipStream_t)stream);
+  a.lddv = lddv; a.causal = causal; a.rel_copies = 0; a.rel_stride = rel_buckets * H; a.drop = op_drop(rng_state, site, drop_p);
+  hipStream_t s = (hipStream_t)stream;
+  if (d_rel_table) {
+    P5_REQUIRE(d_rel_scratch && rel_buckets >= 1 && rel_buckets <= 64, "attn_bwd: d_rel_table needs d_rel_scratch [B * ceil(Lq / 64)][rel_buckets * H] and rel_buckets <= 64");
+    hipMemsetAsync(d_rel_scratch, 0, (size_t)rel_slots(B, Lq) * rel_buckets * H * 4, s);
+    a.d_rel_table = d_rel_scratch;
+  }
+  P5_TRY(dtype == 1 ? launch_attn_bwd<bf16>(a, s) : launch_attn_bwd<float>(a, s));
+  if (d_rel_table) {
+    P5_LAUNCH(p5_reduce_copies_kernel, dim3((rel_buckets * H + 255) / 256), dim3(256), 0, s, d_rel_table, (const float*)d_rel_scratch, rel_buckets * H, rel_slots(B, Lq));
+    P5_TRY(P5_KCHECK());
+  }
+  return 0;
 }
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream) {
   P5_LAUNCH((p5_ce_fwd_kernel<float>), dim3(rows), dim3(256), 0, (hipStream_t)stream, nll, lse, logits, labels, V, ldl);

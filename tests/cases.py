@@ -276,10 +276,11 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
         dQd, dKd, dVd = dq_d, dkv_d, dkv_d[:, inner:]
         lddq, lddk, lddv = inner, 2 * inner, 2 * inner
     dtab = dev(be, torch.zeros(32, H)) if mode != "cross" else None
+    dscr = dev(be, torch.full((B * ((Lq + 63) // 64), 32 * H), float("nan"))) if mode != "cross" else None     # (the op clears its slots itself)
     Dv = dev(be, torch.zeros(B * H * Lq))
     dOd = dev(be, dO)
     be.check(be.lib.p5_op_attn_bwd(dtype, P(Qd), P(Kd), P(Vd), P(Od), P(dOd), P(lse), P(Dv), P(dQd), P(dKd), P(dVd), P(table_d),
-                                   P(dtab), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk, ldv, inner, lddq, lddk, lddv, causal, None,
+                                   P(dtab), P(dscr), 32, P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk, ldv, inner, lddq, lddk, lddv, causal, None,
                                    0, 0.0, be.stream_ptr()), "attn_bwd")
     sync(be)
     tol = 2e-5 if dtype == 0 else 4e-2
@@ -373,9 +374,10 @@ def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
         be.check(be.lib.p5_set_option(b"attn_fused", fused), "set_option")
         dqkv = dev(be, torch.zeros(B * L, 3 * inner, dtype=tt))
         dtab = dev(be, torch.zeros(32, H))
+        dscr = dev(be, torch.zeros(B * ((L + 63) // 64), 32 * H))
         Dv = dev(be, torch.zeros(B * H * L))
         be.check(be.lib.p5_op_attn_bwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(dOd), P(lse), P(Dv), P(dqkv), P(dqkv[:, inner:]), P(dqkv[:, 2 * inner:]),
-                                       P(table_d), P(dtab), P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner, 3 * inner, 3 * inner, inner,
+                                       P(table_d), P(dtab), P(dscr), 32, P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner, 3 * inner, 3 * inner, inner,
                                        3 * inner, 3 * inner, 3 * inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_bwd")
         sync(be)
         res.append((dqkv.cpu().float(), dtab.cpu().clone()))
@@ -892,28 +894,31 @@ def grad_arena_coverage_case(be, ocfg, B, L, T, dtype="bf16"):
         assert torch.allclose(g, want[o:o + k], rtol=1e-5, atol=1e-7), (n, float((g - want[o:o + k]).abs().max()))
 
 
-def backward_reproducible_case(be, ocfg, B, L, T, runs=4):
-    """Two runs of the same step on fresh models: every gradient that is not itself a sum of fp32 atomics (the embeddings' scatter-adds,
-    the relative-bias tables, the T5LayerNorm weights) must come out bit-identical -- the activations' gradients are deterministic."""
+def backward_reproducible_case(be, ocfg, B, L, T, runs=4, dropout=0.0, dtype="bf16"):
+    """The same step on fresh models: the loss and EVERY gradient must come out bit-identical.  Since round 4 no gradient of the engine
+    is a sum of fp32 atomics (embedding lookups: fixed-order segmented sums, p5_embed.h; relative-bias tables: per-workgroup slots;
+    T5LayerNorm weights: fixed-association partial sums; weight gradients: one writer per element), so there is no exception list --
+    AdamW turns a last-bit difference of a near-zero gradient into an O(lr) parameter difference, which is how the run-to-run
+    differences of round 3 arose (profiles/r04_repro_before_fix.txt)."""
     params = O.init_params(ocfg, 7)
     a = synth_batch(ocfg, B, L, T, 3)
     outs = []
     for r in range(runs):
-        m = build_model(be, ocfg, params, "bf16", 0.0)
-        m.eval()
+        m = build_model(be, ocfg, params, dtype, dropout)
+        if dropout > 0:
+            m.train()
+            m.set_dropout_seed(41, 5)
+        else:
+            m.eval()
         loss = m.loss_and_backward(*a)
         sync(be)
         outs.append((float(loss), m._grads.detach().cpu().clone()))
         views = dict(m._views)
-    atomic = lambda n: n == "shared.weight" or "whole_word" in n or "relative_attention_bias" in n or "layer_norm" in n
     for r in range(1, runs):
         assert outs[r][0] == outs[0][0], (r, outs[r][0], outs[0][0])
-        for n, (o, k, _) in views.items():
-            d = float((outs[r][1][o:o + k] - outs[0][1][o:o + k]).abs().max())
-            if atomic(n):
-                assert d <= 1e-5 * max(float(outs[0][1][o:o + k].abs().max()), 1e-6), (r, n, d)
-            else:
-                assert d == 0.0, (r, n, d)
+        bad = [(n, float((outs[r][1][o:o + k] - outs[0][1][o:o + k]).abs().max())) for n, (o, k, _) in views.items()
+               if not torch.equal(outs[r][1][o:o + k], outs[0][1][o:o + k])]
+        assert not bad, (r, bad[:8], len(bad))
 
 
 def grad_store_first_case(be, ocfg, B, L, T, exact=True):

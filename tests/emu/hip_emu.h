@@ -271,6 +271,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 #define __expf expf
 static inline void __threadfence() {}
 #define __logf logf

@@ -344,11 +344,16 @@ def test_backward_writes_every_gradient_after_zero_grad(hip):
 
 
 def test_backward_is_reproducible(hip):
-    """the tied head's input gradient (K = vocabulary) used to be a split-K GEMM with fp32 atomics: their order, and with it the bf16
-    rounding of the root of the whole backward, changed from run to run (every gradient tensor differed by ~1e-3 relative between two
-    runs of the same step).  Now the splits store partial products and are summed in index order."""
+    """Bit-reproducibility of one backward over fresh models, every gradient tensor, no exceptions (cases.backward_reproducible_case):
+    at exactly the benchmarked shape and mode (C2: T5-small, B=64, L=128, T=8, bf16, dropout 0.1 -- wave-specialised forward GEMMs with
+    dropout epilogues, grouped weight gradients, fused attention backward, 8704-row embedding segments), on ragged shapes (token
+    counts that are not multiples of 64: the ungrouped weight-gradient path, blocked attention kernels) and in the fp32 engine."""
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("t5-small", dropout=0.1), 64, 128, 8, dropout=0.1)
     cases.backward_reproducible_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 16, 64, 8)
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("t5-small", dropout=0.1), 7, 37, 6, dropout=0.1, runs=3)
     cases.backward_reproducible_case(hip, O.T5Cfg.named("tiny"), 4, 16, 16)
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("tiny"), 3, 21, 5, dropout=0.1, dtype="fp32", runs=3)
+    cases.backward_reproducible_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 8, 200, 8, runs=3)       # L > 128: blocked attention backward, 4 query blocks per head
 
 
 def test_gradients_stored_not_accumulated_on_a_first_micro_batch(hip):

@@ -13,7 +13,7 @@ qkv = (0.5 * torch.randn(B * L, 3 * inner, device="cuda")).to(bf)
 dqkv = torch.zeros_like(qkv)
 O = torch.zeros(B * L, inner, device="cuda", dtype=bf); dO = torch.randn(B * L, inner, device="cuda").to(bf)
 lse = torch.zeros(B * H * L, device="cuda"); Dv = torch.zeros(B * H * L, device="cuda")
-table = (0.5 * torch.randn(32, H)).cuda(); dtab = torch.zeros(32, H, device="cuda")
+table = (0.5 * torch.randn(32, H)).cuda(); dtab = torch.zeros(32, H, device="cuda"); dscr = torch.zeros(B * ((L + 63) // 64), 32 * H, device="cuda")
 lut = relative_position_bucket_lut(512, True, 32, 128).cuda()
 kmask = torch.ones(B, L, dtype=torch.long, device="cuda"); kmask[:, 120:] = 0
 rng = torch.tensor([1234, 7], dtype=torch.int32, device="cuda")
@@ -22,7 +22,7 @@ f = ctypes.c_float
 fwd = lambda: lib.p5_op_attn_fwd(1, P(qkv), P(qkv[:, inner:]), P(qkv[:, 2 * inner:]), P(O), P(lse), P(table), P(lut), 512, P(kmask), B, H, L, L,
                                  3 * inner, 3 * inner, 3 * inner, inner, 0, P(rng), 11, f(0.1), s)
 bwd = lambda: lib.p5_op_attn_bwd(1, P(qkv), P(qkv[:, inner:]), P(qkv[:, 2 * inner:]), P(O), P(dO), P(lse), P(Dv), P(dqkv), P(dqkv[:, inner:]),
-                                 P(dqkv[:, 2 * inner:]), P(table), P(dtab), P(lut), 512, P(kmask), B, H, L, L, 3 * inner, 3 * inner, 3 * inner,
+                                 P(dqkv[:, 2 * inner:]), P(table), P(dtab), P(dscr), 32, P(lut), 512, P(kmask), B, H, L, L, 3 * inner, 3 * inner, 3 * inner,
                                  inner, 3 * inner, 3 * inner, 3 * inner, 0, P(rng), 11, f(0.1), s)
 def timeit(name, call, iters=40):
     for _ in range(3): assert call() == 0, lib.p5_last_error()
