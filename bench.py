@@ -139,6 +139,41 @@ def time_training(model, opt, batch, steps, warmup, world, device):
     return dt, float(last.detach())
 
 
+def profile_training(be, model, opt, batch, steps=3):
+    """Per-kernel time of `steps` training steps measured IN THIS RUN by the library's own profiler (p5_profile_begin / p5_profile_end:
+    two HIP events around every launch, on the launch stream): a list of {"kernel", "launches", "total_us", "flops"} per (kernel, grid),
+    per step.  Durations include each launch's dispatch gap, so they are upper bounds of the rocprofv3 kernel durations."""
+    import ctypes
+    model.train()
+    train_step(model, opt, batch)
+    torch.cuda.synchronize()
+    be.check(be.lib.p5_profile_begin(), "p5_profile_begin")
+    for _ in range(steps):
+        train_step(model, opt, batch)
+    buf = ctypes.create_string_buffer(1 << 20)
+    be.check(be.lib.p5_profile_end(buf, len(buf)), "p5_profile_end")
+    rows = json.loads(buf.value.decode() or "[]")
+    for r in rows:
+        r["launches_per_step"] = r["launches"] / steps
+        r["us_per_step"] = r["total_us"] / steps
+        r["flops_per_step"] = r["flops"] / steps
+    return rows
+
+
+def kernel_classes(rows):
+    """aggregate the profiler's (kernel, grid) rows by kernel name (+ tag): what a rocprofv3 --stats table shows per kernel."""
+    cls = {}
+    for r in rows:
+        name = r["kernel"].split(" grid=")[0]
+        c = cls.setdefault(name, {"kernel": name, "launches_per_step": 0.0, "us_per_step": 0.0, "flops_per_step": 0.0, "grids": []})
+        c["launches_per_step"] += r["launches_per_step"]
+        c["us_per_step"] += r["us_per_step"]
+        c["flops_per_step"] += r["flops_per_step"]
+        c["grids"].append({"grid": r["kernel"].split(" grid=")[1], "launches_per_step": r["launches_per_step"], "avg_us": r["total_us"] / max(1, r["launches"]),
+                           "tflops": r["flops"] / max(r["total_us"], 1e-9) / 1e6})
+    return sorted(cls.values(), key=lambda c: -c["us_per_step"])
+
+
 def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, seed, vocab=V):
     from openp5_amd.trie import prefix_allowed_tokens_fn
     model.eval()
@@ -489,6 +524,7 @@ def main():
     batch = synth_batch(B, L, T, device, 100 + rank)
     dt, final_loss = time_training(model, opt, batch, args.steps, args.warmup, world, device)
     samples_per_s = world * B * args.steps / dt
+    prof_rows = profile_training(be, model, opt, batch) if (rank == 0 and world == 1) else None      # outside the timed region
 
     # ---- beam-10 constrained generation: items/s (B=20 users/GPU, K=10, ML1M-sized trie of 3416 items) ----
     gen = None
@@ -528,19 +564,46 @@ def main():
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
             "distributed": ddp,
-            # dominant kernel of the step by time (profiles/README.md): ONE launch = the eight weight gradients of two encoder layers on
-            # the wave-specialised persistent kernel (3 of them per step); `roofline_fwd` is the FFN up-projection on the same kernel's
-            # K-contiguous build.  Both are timed live with HIP events on the launch stream (`avg_launch_us`: the kernel alone, operands
-            # warm); `in_step_us` is the same kernel's average duration inside the step (from the rocprofv3 trace of bench.py).
-            "roofline": {"bound": "mfma", "kernel": k_wg, "shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]] * 2,
-                         "achieved": ach_w, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_w / BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("wgrad_group2", (Mg, c.d_model, c.d_ff)), "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh, separate FETCH_SIZE / WRITE_SIZE passes)",
-                         "algorithmic_bytes": by_w, "avg_launch_us": t_w * 1e6, "in_step_us": in_step_us("wgrad_group2"),
-                         "flops_per_launch": fl_w},
-            "roofline_fwd": {"bound": "mfma", "kernel": k_fwd, "shape": [Mg, Ng, Kg], "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / BF16_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "traffic_source": "profiles/pmc_traffic.json",
-                             "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng), "avg_launch_us": t_k * 1e6, "in_step_us": in_step_us("fwd_wide")},
+            # `roofline` = the kernel with the largest share of the step's time IN THIS RUN (library profiler, HIP events around every
+            # launch of 3 extra steps outside the timed region): aggregate algorithmic FLOPs of its launches / their summed in-step
+            # durations.  `alone` = its largest shape timed by itself (operands warm) with the PMC HBM traffic of that launch.
+            # `roofline_wgrad`: the grouped weight-gradient launch (two encoder layers, round 3's `roofline`), `step_kernels`: the
+            # whole per-kernel table of the step.
         }
+        cls = kernel_classes(prof_rows) if prof_rows else []
+        gemm_cls = [c for c in cls if c["flops_per_step"] > 0]
+        fwd_alone = {"shape": [Mg, Ng, Kg], "avg_launch_us": t_k * 1e6, "achieved": ach, "frac": ach / BF16_PEAK_TFLOPS,
+                     "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
+                     "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"}
+        wg_alone = {"shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]] * 2,
+                    "avg_launch_us": t_w * 1e6, "achieved": ach_w, "frac": ach_w / BF16_PEAK_TFLOPS, "flops_per_launch": fl_w,
+                    "traffic": pmc_traffic("wgrad_group2", (Mg, c.d_model, c.d_ff)), "algorithmic_bytes": by_w,
+                    "traffic_source": "profiles/pmc_traffic.json"}
+        if cls:
+            top = cls[0]
+            tf = top["flops_per_step"] / max(top["us_per_step"], 1e-9) / 1e6
+            is_ks = "[KS" in top["kernel"] or " KS]" in top["kernel"]      # (the tag, not the template parameter's name)
+            line["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": tf, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_PEAK_TFLOPS,
+                                "launches_per_step": top["launches_per_step"], "us_per_step": top["us_per_step"], "flops_per_step": top["flops_per_step"],
+                                "share_of_kernel_time": top["us_per_step"] / max(1e-9, sum(c["us_per_step"] for c in cls)),
+                                "by_grid": top["grids"], "alone": wg_alone if is_ks else fwd_alone, "traffic": (wg_alone if is_ks else fwd_alone)["traffic"],
+                                "source": "p5_profile_begin/end in this run: HIP events around every launch of 3 steps (durations include the dispatch gap)"}
+            ks = [c for c in cls if "p5_gemm5_kernel" in c["kernel"] and "[KS" in c["kernel"]]
+            if ks and not is_ks:
+                k0 = ks[0]
+                tfk = k0["flops_per_step"] / max(k0["us_per_step"], 1e-9) / 1e6
+                line["roofline_wgrad"] = {"bound": "mfma", "kernel": k0["kernel"], "achieved": tfk, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfk / BF16_PEAK_TFLOPS,
+                                          "launches_per_step": k0["launches_per_step"], "us_per_step": k0["us_per_step"], "alone": wg_alone, "traffic": wg_alone["traffic"]}
+            line["gemm_family"] = {"tflops": sum(c["flops_per_step"] for c in gemm_cls) / max(1e-9, sum(c["us_per_step"] for c in gemm_cls)) / 1e6,
+                                   "us_per_step": sum(c["us_per_step"] for c in gemm_cls), "launches_per_step": sum(c["launches_per_step"] for c in gemm_cls)}
+            line["step_kernels"] = [{"kernel": c["kernel"], "launches_per_step": c["launches_per_step"], "us_per_step": round(c["us_per_step"], 2),
+                                     "tflops": (round(c["flops_per_step"] / max(c["us_per_step"], 1e-9) / 1e6, 1) if c["flops_per_step"] > 0 else None)} for c in cls]
+            line["step_launches"] = sum(c["launches_per_step"] for c in cls)
+        else:
+            line["roofline"] = dict(bound="mfma", kernel=k_wg, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **wg_alone)
+        line["roofline_fwd"] = dict(bound="mfma", kernel=k_fwd, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **fwd_alone)
+        if True:
+            pass
         if gen:
             S = gen["decoded_len"] - 1
             timed = (timing or {}).get("decode_ms")

@@ -46,6 +46,12 @@ const char* p5_last_error(void);
  * 128x128 tiles), "gemm_ring", "gemm_small_ring", "gemm_ksdma", "gemm_xcd_rect", "decode_fused" = 0|1 */
 int p5_set_option(const char* name, int value);
 int p5_abi_version(void);
+/* In-run kernel profiler (measurement aid, bench.py): between p5_profile_begin() and p5_profile_end() every kernel launch of the library is
+ * bracketed by two HIP events on its stream; p5_profile_end synchronises and writes a JSON array of {"kernel" (name + launch grid), "launches",
+ * "total_us", "flops" (algorithmic FLOPs of the GEMM / attention launches, 0 elsewhere)} into `report` (NUL-terminated, `cap` bytes).
+ * Durations include the dispatch gap of each launch (~1-2 us), i.e. they are upper bounds of the rocprofv3 kernel durations. */
+int p5_profile_begin(void);
+int p5_profile_end(char* report, int cap);
 int p5_is_emulator(void);   /* 1 only for the test-only host emulation build under tests/emu */
 
 /* ---- engine lifetime + parameter arena layout ---- */
@@ -102,6 +108,12 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream);
 int p5_backward(P5Engine* e, const float* dnll, void* stream);
 /* arena range [begin,end) whose gradients are final once `stage` has run (for bucketed all-reduce) */
 int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end);
+/* What a data-parallel caller exchanges after each p5_backward_stage call: the gradient range that became FINAL with that call -- the
+ * union of the stage ranges whose kernels have all been launched (empty while a two-layer weight-gradient group of the encoder is still
+ * filling up: the staged backward issues the same grouped launches as p5_backward; p5_backward_stage_pairs(e, 0) restores one launch per
+ * layer and one range per stage).  Ranges are contiguous and walk the arena from the back. */
+int p5_backward_final_range(const P5Engine* e, int64_t* begin, int64_t* end);
+int p5_backward_stage_pairs(P5Engine* e, int on);
 
 /* out_partials: float[1024], fully overwritten; p5_adamw_step sums them in a fixed order (bit-identical on every rank) */
 int p5_grad_sumsq(const float* grads, int64_t n, float* out_partials, void* stream);

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "p5_backward_stage": (i32, [vp, vp, i32, vp]),
     "p5_backward": (i32, [vp, vp, vp]),
     "p5_backward_stage_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "p5_backward_final_range": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    "p5_backward_stage_pairs": (i32, [vp, i32]),
     "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     "p5_decode_fold_count": (i64, [vp]),
@@ -70,6 +72,8 @@ PROTOTYPES = {
     "p5_op_dec_cross_attn": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p5_op_skinny_gemm": (i32, [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "p5_op_tr_probe": (i32, [vp, vp, vp]),
+    "p5_profile_begin": (i32, []),
+    "p5_profile_end": (i32, [C.c_char_p, i32]),
 }
 
 

@@ -88,8 +88,40 @@ template <> struct TT<bf16> { static constexpr int EPF = 8; static constexpr int
 #define P5_DYN_SMEM(name) char* name = emu::B().dyn_smem
 #define P5_LANE() ((int)emu::lane())
 #else
-#define P5_LAUNCH(kern, grid, block, shmem, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
+// In-run kernel profiler (p5_profile_begin / p5_profile_end, include/p5hip.h): while it is on, every launch of the library is bracketed
+// by two HIP events on the launch stream; the report aggregates per (kernel, grid).  bench.py uses it to name the dominant kernel of
+// the step and its in-step duration in the very run the driver times (measurement aid; off by default, costs nothing then).
+#include <vector>
+#include <string>
+struct P5Prof {
+  struct Rec { const char* name; const char* tag; unsigned gx, gy, gz, bx; double flops; hipEvent_t a, b; };
+  int on = 0;
+  double pending_flops = 0.0;       // set by a launcher right before its P5_LAUNCH (algorithmic FLOPs of that launch)
+  const char* pending_tag = "";     // ... and what the template parameters of the stringified kernel name stand for
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+  }
+  void begin(const char* name, dim3 g, dim3 b, hipStream_t s) {
+    Rec r{name, pending_tag, g.x, g.y, g.z, b.x, pending_flops, get(), get()};
+    pending_flops = 0.0; pending_tag = "";
+    hipEventRecord(r.a, s);
+    recs.push_back(r);
+  }
+  void end(hipStream_t s) { hipEventRecord(recs.back().b, s); }
+};
+static inline P5Prof& p5_prof() { static P5Prof p; return p; }
+#define P5_LAUNCH(kern, grid, block, shmem, stream, ...)                                   \
+  do {                                                                                     \
+    P5Prof& _pf = p5_prof();                                                               \
+    if (_pf.on) _pf.begin(#kern, dim3(grid), dim3(block), (stream));                       \
+    else { _pf.pending_flops = 0.0; _pf.pending_tag = ""; }                                \
+    hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__);             \
+    if (_pf.on) _pf.end((stream));                                                         \
+  } while (0)
 #define P5_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define P5_LANE() ((int)(threadIdx.x & 63))
 #endif

@@ -66,9 +66,19 @@ static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS"
 static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
 static int g_opt_dec_head_nv = getenv("P5_DEC_HEAD_NV") ? atoi(getenv("P5_DEC_HEAD_NV")) : 0;   // streaming head: forced E rows per workgroup (0 = auto)
 
+#ifdef P5_EMU
+#define P5_PROF_FLOPS(x) ((void)0)
+#define P5_PROF_TAG(x) ((void)0)
+#else
+#define P5_PROF_FLOPS(x) (p5_prof().pending_flops = (x))
+#define P5_PROF_TAG(x) (p5_prof().pending_tag = (x))
+#endif
 template <class T, int BM, int BN>
 static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
+  P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
+  P5_PROF_TAG(sizeof(T) == 2 ? (BM == 256 ? "bf16 256x256" : BM == 128 ? (g.a_ks ? "bf16 128x128 KS" : "bf16 128x128 KC") : (g.a_ks ? "bf16 64x64 KS" : (g.b_ks ? "bf16 64x64 KC/KS" : "bf16 64x64 KC")))
+                             : (BM == 128 ? "f32 128x128" : "f32 64x64"));
   g.xcd_bm = g.xcd_bn = 0;
   if (g_opt_gemm_xcd_rect) {
     // exact cover of the gx x gy tile grid by 8 equal rectangles; keep the one with the smallest half-perimeter, and only if
@@ -153,6 +163,12 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   grp.total_units = units;
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > g_opt_g4_wgs * OCC) nwg = g_opt_g4_wgs * OCC;
+  {
+    double fl = 0.0;
+    for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
+    P5_PROF_FLOPS(fl);
+    P5_PROF_TAG(KS ? (BM == 256 ? "256x128 KS" : "128x128 KS") : (BM == 256 ? "256x128 KC" : "128xN KC"));
+  }
   P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
   return P5_KCHECK();
 }
@@ -175,6 +191,12 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   grp.total_units = units;
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
+  {
+    double fl = 0.0;
+    for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
+    P5_PROF_FLOPS(fl);
+    P5_PROF_TAG(KS ? "KS: grouped weight gradients" : "KC: forward / data-gradient GEMMs");
+  }
   P5_LAUNCH((p5_gemm5_kernel<KS>), dim3(nwg), dim3(512), 0, s, grp);
   return P5_KCHECK();
 }
@@ -283,6 +305,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
       dim3 grid((g.N + 63) / 64, (g.M + 31) / 32, 1);
       g.xcd_bm = g.xcd_bn = 0;
       g.splitk = 1;
+      P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
       P5_LAUNCH((p5_gemm2_kernel<32, 64, 8, false, false>), grid, dim3(256), 0, s, g);
       return P5_KCHECK();
     }
@@ -293,6 +316,7 @@ static int launch_gemm(P5GemmArgs g, hipStream_t s) {
 template <class T>
 static int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) {
   P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  P5_PROF_FLOPS(4.0 * a.B * a.H * a.Lq * a.Lk * 64);
   if constexpr (sizeof(T) == 2) {
     // one workgroup per (batch, head): K and V fetched once, every load up front, one barrier (p5_attn.h)
     if (g_opt_attn_fwd_wg && a.Lq <= 128 && a.Lk <= 128) {
@@ -425,6 +449,9 @@ struct P5Engine {
   std::vector<P5GemmArgs> wg_pending;     // deferred weight-gradient problems (bf16, token count a multiple of 64)
   unsigned wg_sets = 0;                   // bit p: a pending problem reads temporaries of set p
   bool whole_backward = false;            // inside p5_backward (as opposed to stage-by-stage calls of a data-parallel caller)
+  bool stage_pairs = true;                // staged backward: the encoder's weight gradients still leave in two-layer groups (the benchmarked launch)
+  int64_t fin_b = 0, fin_e = 0;           // staged backward: gradient range completed by the stages run since the last p5_backward_final_range
+  int64_t rep_b = 0, rep_e = 0;           // ... and the range that call reports
   void* dy_next = nullptr;
   void *kv_all = nullptr, *dkv_all = nullptr;   // cross-attention K/V (and their gradients) of all decoder layers, [M, n_dec*2*inner]
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
@@ -1294,7 +1321,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       // layer's group (one launch).  d(enc_out) is on the critical path of the encoder backward either way.
       P5_TRY(linear_wgrad<T>(e, s, e->dkv_all, ldkv, e->enc_out, d, e->G + e->dec[0].ca.k, M, ldkv, d));
       const bool side2 = e->side && (g_opt_wgrad_side & 2) != 0;
-      if (side2 || !e->whole_backward) P5_TRY(wgrad_flush(e, s, false, side2));
+      if (side2 || !(e->whole_backward || e->stage_pairs)) P5_TRY(wgrad_flush(e, s, false, side2));
       P5_TRY(dgrad_w<T>(e, side2 ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
                              nullptr, 0, 1.f, 1));
     }
@@ -1337,7 +1364,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens (or of 2 layers = 384 tiles when the
     // whole backward runs in one call and nobody waits for per-layer gradient ranges)
     // (the top layer's group also carries the cross-attention K/V block queued in the previous stage: 5 problems; then pairs of layers)
-    const bool pairs = e->whole_backward && g_opt_wgrad_layers > 1;
+    const bool pairs = (e->whole_backward || e->stage_pairs) && g_opt_wgrad_layers > 1;
     if (!pairs || i == 0 || e->wg_pending.size() >= 5) return wgrad_flush(e, s, false, (g_opt_wgrad_side & 2) != 0);
     return 0;
   }
@@ -1901,6 +1928,50 @@ int p5_set_option(const char* name, int value) {
   return 0;
 }
 int p5_abi_version(void) { return 1; }
+// ---- in-run kernel profiler (p5_device.h P5Prof) ----
+int p5_profile_begin(void) {
+#ifndef P5_EMU
+  P5Prof& p = p5_prof();
+  p.recs.clear(); p.used = 0; p.pending_flops = 0.0; p.on = 1;
+#endif
+  return 0;
+}
+int p5_profile_end(char* report, int cap) {
+  if (report && cap > 0) report[0] = 0;
+#ifndef P5_EMU
+  P5Prof& p = p5_prof();
+  p.on = 0;
+  if (p.recs.empty()) return 0;
+  if (hipEventSynchronize(p.recs.back().b) != hipSuccess) return fail("profile: event sync failed");
+  struct Agg { std::string key; int n; double us, flops; };
+  std::vector<Agg> agg;
+  for (const P5Prof::Rec& r : p.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    char k[512];
+    snprintf(k, sizeof(k), "%s%s%s%s grid=(%u,%u,%u) block=%u", r.name, r.tag[0] ? " [" : "", r.tag, r.tag[0] ? "]" : "", r.gx, r.gy, r.gz, r.bx);
+    size_t i = 0;
+    for (; i < agg.size(); ++i) if (agg[i].key == k) break;
+    if (i == agg.size()) agg.push_back({k, 0, 0.0, 0.0});
+    agg[i].n++; agg[i].us += ms * 1e3; agg[i].flops += r.flops;
+  }
+  std::string out = "[";
+  for (size_t i = 0; i < agg.size(); ++i) {
+    std::string key;
+    for (char c : agg[i].key) { if (c == '"' || c == '\\') key += '\\'; key += c; }
+    char b[768];
+    snprintf(b, sizeof(b), "%s{\"kernel\": \"%s\", \"launches\": %d, \"total_us\": %.3f, \"flops\": %.6e}", i ? ", " : "", key.c_str(), agg[i].n, agg[i].us, agg[i].flops);
+    out += b;
+  }
+  out += "]";
+  if (report && cap > 0) {
+    if ((int)out.size() + 1 > cap) return fail("profile: report buffer too small");
+    memcpy(report, out.c_str(), out.size() + 1);
+  }
+  p.recs.clear();
+#endif
+  return 0;
+}
 int p5_is_emulator(void) {
 #ifdef P5_EMU
   return 1;
@@ -2054,9 +2125,24 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   P5_REQUIRE(e->Md > 0, "p5_forward must run first");
   P5_TRY(e->c.dtype == 1 ? backward_stage_impl<bf16>(e, dnll, stage, (hipStream_t)stream)
                          : backward_stage_impl<float>(e, dnll, stage, (hipStream_t)stream));
-  if (!e->whole_backward || stage == p5_backward_num_stages(e) - 1) {
-    P5_TRY(wgrad_flush(e, (hipStream_t)stream, false, (g_opt_wgrad_side & 2) != 0));      // (a stage never leaves weight gradients or norm partials pending:
-    P5_TRY(norm_flush(e, (hipStream_t)stream));               //  its gradient range is final once this call's work has run)
+  const bool last_stage = stage == p5_backward_num_stages(e) - 1;
+  if (!e->whole_backward || last_stage) {
+    // stage-by-stage callers: norm partials never stay pending; weight gradients only while a two-layer encoder group (or the
+    // cross-attention K/V block that leaves with the top group) is still filling up -- p5_backward_final_range reports a range only
+    // once everything inside it has been launched
+    if (!e->stage_pairs || last_stage) P5_TRY(wgrad_flush(e, (hipStream_t)stream, false, (g_opt_wgrad_side & 2) != 0));
+    P5_TRY(norm_flush(e, (hipStream_t)stream));
+  }
+  {
+    int64_t b = 0, en = 0;
+    p5_backward_stage_range(e, stage, &b, &en);
+    if (stage == 0) { e->fin_b = e->fin_e = 0; }
+    if (en > b) {
+      if (e->fin_e <= e->fin_b) { e->fin_b = b; e->fin_e = en; }
+      else { e->fin_b = b < e->fin_b ? b : e->fin_b; e->fin_e = en > e->fin_e ? en : e->fin_e; }
+    }
+    e->rep_b = e->rep_e = 0;
+    if (e->wg_pending.empty() && e->fin_e > e->fin_b) { e->rep_b = e->fin_b; e->rep_e = e->fin_e; e->fin_b = e->fin_e = 0; }
   }
   // the side stream is now ordered after this stage's main-stream work (a bucket all-reduce enqueued behind the side
   // stream sees every gradient of the stage); after the last stage the main stream waits for the side stream
@@ -2064,6 +2150,10 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
   if (stage == p5_backward_num_stages(e) - 1) join_side(e, (hipStream_t)stream);
   return 0;
 }
+// the gradient range that became FINAL with the most recent p5_backward_stage call (empty while a grouped weight-gradient launch is
+// still collecting problems): contiguous, because the stages walk the arena from the back.  What a data-parallel caller all-reduces.
+int p5_backward_final_range(const P5Engine* e, int64_t* begin, int64_t* end) { *begin = e->rep_b; *end = e->rep_e; return 0; }
+int p5_backward_stage_pairs(P5Engine* e, int on) { e->stage_pairs = on != 0; return 0; }
 int p5_engine_grads_zeroed(P5Engine* e) { e->grads_keep = true; return 0; }
 // zero_grad(set_to_none=True) of the reference loop: the gradients are dead until the next backward rewrites them -- nothing to do
 // on the device (the next backward stores / clears what it needs); p5_engine_clear_grads is the eager form (set_to_none=False)

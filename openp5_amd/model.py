@@ -148,6 +148,9 @@ class P5T5Native(nn.Module):
         self.ddp_group = None
         self._ddp_sync = True       # False on all but the last micro-batch of a gradient-accumulation group
         self.ddp_bucket_dtype = "fp32"   # "bf16": gradient buckets travel as bf16 (half the bytes on the xGMI links)
+        self.staged_backward = False     # run the stage-by-stage backward (the data-parallel code path) even at world size 1, without collectives
+        self.ddp_timing = False          # record device time the main stream spends waiting for the gradient exchange (bench.py)
+        self.ddp_wait_ms = []
         self._pending = []
         self._side = None
         self._comm = None
@@ -471,7 +474,8 @@ class P5T5Native(nn.Module):
         if dnll is not None:
             dnll = dnll.to(torch.float32).contiguous()
         lib, eng, sp = self._lib, self._engine, self._be.stream_ptr()
-        if self.ddp_world > 1 and self._ddp_sync:
+        exchange = self.ddp_world > 1 and self._ddp_sync
+        if exchange or self.staged_backward:
             import torch.distributed as dist
             nst = lib.p5_backward_num_stages(eng)
             b, e = ctypes.c_int64(), ctypes.c_int64()
@@ -479,8 +483,10 @@ class P5T5Native(nn.Module):
             half = str(self.ddp_bucket_dtype).replace("torch.", "") in ("bf16", "bfloat16")
             for st in range(nst):
                 self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
-                lib.p5_backward_stage_range(eng, st, ctypes.byref(b), ctypes.byref(e))
-                if e.value > b.value:
+                # the range that became final with this stage (empty while a two-layer weight-gradient group is still filling up: the
+                # staged backward issues the same grouped launches as the single-GPU step)
+                lib.p5_backward_final_range(eng, ctypes.byref(b), ctypes.byref(e))
+                if e.value > b.value and exchange:
                     # the bucket's all-reduce goes to a communication stream ordered after this stage's work (the engine's side
                     # stream when it has one -- it also carries the stage's weight gradients -- else a stream of our own that
                     # waits for the main stream here), so that it overlaps the following stages
@@ -495,6 +501,10 @@ class P5T5Native(nn.Module):
                         seg = self._grads[b.value:e.value]
                         buf = seg.to(torch.bfloat16) if half else seg       # bf16 bucket: cast, reduce, cast back (below)
                         self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True), buf, seg))
+            timing = self.ddp_timing and exchange and self._flat.is_cuda
+            if timing:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for w, buf, seg in self._pending:
                 w.wait()
                 if half:
@@ -503,10 +513,13 @@ class P5T5Native(nn.Module):
                     seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
             self._pending = []
             for cs in (self._side, self._comm):
-                if cs is not None:
+                if cs is not None and exchange:
                     # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
                     # stream they were issued from (gloo on device tensors) need the explicit edge comm -> main
                     torch.cuda.current_stream().wait_stream(cs)
+            if timing:
+                ev1.record()
+                self.ddp_wait_ms.append((ev0, ev1))     # (read by bench.py after a synchronize: main-stream time between the end of the backward and the last bucket)
         else:
             self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
         for name, p in self.named_parameters():

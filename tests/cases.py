@@ -921,6 +921,56 @@ def backward_reproducible_case(be, ocfg, B, L, T, runs=4, dropout=0.0, dtype="bf
         assert not bad, (r, bad[:8], len(bad))
 
 
+def staged_backward_case(be, ocfg, B, L, T, dtype="bf16", dropout=0.0):
+    """The stage-by-stage backward of the data-parallel path (p5_backward_stage + p5_backward_final_range): the ranges it reports are
+    contiguous, walk the arena from the back and tile it exactly; every gradient equals the whole backward's bit for bit -- with and
+    without two-layer weight-gradient groups (p5_backward_stage_pairs)."""
+    import ctypes
+    params = O.init_params(ocfg, 7)
+    a = synth_batch(ocfg, B, L, T, 3)
+
+    def run(staged, pairs):
+        m = build_model(be, ocfg, params, dtype, dropout)
+        if dropout > 0:
+            m.train()
+            m.set_dropout_seed(41, 5)
+        else:
+            m.eval()
+        m.staged_backward = staged
+        be.check(be.lib.p5_backward_stage_pairs(m._engine, 1 if pairs else 0), "pairs")
+        ranges = []
+        if staged:
+            orig = be.lib.p5_backward_final_range
+
+            class Spy:          # record what the model's backward loop is told
+                def __call__(self, eng, b, e):
+                    rc = orig(eng, b, e)
+                    ranges.append((b._obj.value, e._obj.value))
+                    return rc
+            spy = Spy()
+            lib = m._lib
+
+            class LibProxy:
+                def __getattr__(self, k):
+                    return spy if k == "p5_backward_final_range" else getattr(lib, k)
+            m._lib = LibProxy()
+        loss = m.loss_and_backward(*a)
+        sync(be)
+        return float(loss), m._grads.detach().cpu().clone(), ranges, int(m._n)
+
+    l0, g0, _, n = run(False, True)
+    for pairs in (True, False):
+        l1, g1, ranges, _ = run(True, pairs)
+        assert l1 == l0
+        assert torch.equal(g1, g0), (pairs, float((g1 - g0).abs().max()))
+        got = [r for r in ranges if r[1] > r[0]]
+        assert got and got[-1][0] == 0 and got[0][1] == n, got
+        for (b0, e0), (b1, e1) in zip(got, got[1:]):
+            assert e1 == b0, ("ranges must tile the arena from the back", got)
+        if pairs and ocfg.num_layers >= 2 and B * L % 64 == 0 and B * T % 64 == 0 and dtype == "bf16":
+            assert len(got) < len(ranges), "two-layer groups: some stages must report nothing"
+
+
 def grad_store_first_case(be, ocfg, B, L, T, exact=True):
     """A backward that starts a new accumulation group STORES the Linear gradients over whatever the arena holds (no clear): its
     result must equal the clear-then-accumulate path's on the same batch, after an unrelated backward has left its gradients

@@ -311,3 +311,9 @@ def test_kernels_under_adversarial_emulation(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
                        env={**os.environ, **env}, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_staged_backward_ranges_and_gradients(emu):
+    cases.staged_backward_case(emu, O.T5Cfg.named("tiny"), 4, 16, 16)
+    cases.staged_backward_case(emu, O.T5Cfg.named("tiny"), 3, 10, 5, dtype="fp32")
+    cases.staged_backward_case(emu, O.T5Cfg.named("tiny", num_layers=3, num_decoder_layers=2), 8, 16, 8, dropout=0.1)

@@ -117,3 +117,12 @@ def test_two_ranks_rccl(tmp_path):
     mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     n0, n1 = torch.load(tmp_path / "n0.pt"), torch.load(tmp_path / "n1.pt")
     assert torch.equal(n0["flat"], n1["flat"]), "ranks diverged over RCCL"
+
+
+def test_staged_backward_ranges_and_gradients(hip):
+    """the data-parallel code path on one GPU: stage-by-stage backward == whole backward bit for bit, its final ranges tile the arena;
+    T5-small at the benchmark shape (two-layer weight-gradient groups inside the staged backward) and a ragged toy"""
+    from oracle import t5_oracle as O
+    from tests import cases
+    cases.staged_backward_case(hip, O.T5Cfg.named("t5-small", dropout=0.1), 64, 128, 8, dropout=0.1)
+    cases.staged_backward_case(hip, O.T5Cfg.named("tiny"), 3, 10, 5)
