@@ -525,6 +525,25 @@ def main():
     dt, final_loss = time_training(model, opt, batch, args.steps, args.warmup, world, device)
     samples_per_s = world * B * args.steps / dt
     prof_rows = profile_training(be, model, opt, batch) if (rank == 0 and world == 1) else None      # outside the timed region
+    staged = None
+    if world == 1 and args.legs != "none":
+        # the data-parallel code path on ONE GPU: stage-by-stage backward (16 engine calls, gradient ranges reported per stage, the same
+        # two-layer weight-gradient groups), no collective -- what staging itself costs against the single-call backward timed above
+        model.staged_backward = True
+        sdt, _ = time_training(model, opt, batch, args.steps, 2, 1, device)
+        model.staged_backward = False
+        staged = {"ms_per_step": sdt / args.steps * 1e3, "samples_per_s": B * args.steps / sdt, "steps": args.steps,
+                  "note": "p5_backward_stage x 16 + p5_backward_final_range per stage, world size 1, no all-reduce"}
+    comm_wait_ms = None
+    if world > 1:
+        # device time the main stream waits for the gradient exchange after the last backward stage (extra steps outside the timed region)
+        model.ddp_timing, model.ddp_wait_ms = True, []
+        for _ in range(5):
+            train_step(model, opt, batch)
+        torch.cuda.synchronize()
+        w = sorted(a.elapsed_time(b) for a, b in model.ddp_wait_ms)
+        comm_wait_ms = w[len(w) // 2] if w else None
+        model.ddp_timing = False
 
     # ---- beam-10 constrained generation: items/s (B=20 users/GPU, K=10, ML1M-sized trie of 3416 items) ----
     gen = None
@@ -550,7 +569,9 @@ def main():
             half = str(getattr(model, "ddp_bucket_dtype", "fp32")).replace("torch.", "") in ("bf16", "bfloat16")
             ddp = {"world_size": _dist().get_world_size(), "backend": _dist().get_backend(), "collective": "all_reduce(SUM) of contiguous gradient-arena "
                    "buckets, one per backward stage, issued behind the stage on the side stream",
-                   "allreduce_bytes_per_step_per_rank": int(model._n) * (2 if half else 4), "bucket_dtype": "bf16" if half else "fp32"}
+                   "allreduce_bytes_per_step_per_rank": int(model._n) * (2 if half else 4), "bucket_dtype": "bf16" if half else "fp32",
+                   "comm_wait_ms_after_backward": comm_wait_ms,
+                   "note": "comm_wait = device time between the end of the backward and the completion of the last bucket on the main stream (median of 5 extra steps)"}
         line = {
             "metric": "train_samples_per_sec", "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -620,6 +641,8 @@ def main():
             del model, opt
             torch.cuda.empty_cache()
             legs = {}
+            if staged:
+                legs["staged_backward_1gpu"] = staged
             if "task_mix" in legs_on:
                 try:
                     legs["task_mix"] = task_mix_leg(be, device)

@@ -697,6 +697,178 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// backward for SHORT query blocks (Lq <= 16: the decoder's self-attention over T target tokens and its cross-attention, T <= 16 queries
+// against the encoder's L keys) -- dQ, dK, dV and the relative-bias gradient in ONE launch, one workgroup per (batch, head).
+// The two-kernel path above runs these as a dQ kernel in which only one of four waves has queries (the wave = 16 queries split leaves
+// three idle) followed by a dK/dV kernel: 24 latency-bound launches per T5-small step.  Here the four waves split the KEYS of every
+// 64-key chunk (wave w: keys 16 w .. 16 w + 15): each forms its [16 keys x 16 queries] block of P and dS once and uses it three times:
+//   dV += P^T dO, dK += dS^T Q (its own 16 keys: stored per chunk), dQ += dS K (accumulated over all chunks, the four waves' partial
+//   sums added in wave order at the end).  Same element arithmetic as the other kernels (recomputed P from the saved log-sum-exp).
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void p5_attn_bwd_small_kernel(P5AttnArgs a) {
+  using C = AttnC<T>;
+  constexpr int KR = C::KCH;                 // reduction elements of one mma16 (32 bf16 / 16 f32) = rows of a K-strided fragment chunk
+  constexpr int RS = 64 + 16;                // row stride (bytes) of the small A-operand images: KR elements + pad
+  __shared__ __attribute__((aligned(16))) char tileK[64 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tileV[64 * C::TS];
+  __shared__ __attribute__((aligned(16))) char tileQ[32 * C::TS];       // rows >= Lq are zero
+  __shared__ __attribute__((aligned(16))) char tileDO[32 * C::TS];
+  __shared__ __attribute__((aligned(16))) char aP[4][16 * RS];          // per wave: P^T  [key][query]   (A operand of dV)
+  __shared__ __attribute__((aligned(16))) char aS[4][16 * RS];          //           dS^T [key][query]   (A operand of dK)
+  __shared__ __attribute__((aligned(16))) char bS[4][16 * RS];          //           dS   [query][key of the wave's KR-row chunk]  (A operand of dQ)
+  __shared__ __attribute__((aligned(16))) char wscr[4][16 * C::TS];     // wave scratch of the row stores
+  __shared__ __attribute__((aligned(16))) float sdq[4][16][68];
+  __shared__ __attribute__((aligned(16))) float sbias[1024];
+  __shared__ float sdb[4][528];
+  __shared__ __attribute__((aligned(16))) float slse[16];
+  __shared__ __attribute__((aligned(16))) float sD[16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+  const T* dO = (const T*)a.dO + (size_t)b * a.Lq * a.lddo + h * 64;
+  const T* O = (const T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64;
+  const int nrel = a.Lq + a.Lk - 1;
+  const int nch = (a.Lk + 63) / 64;
+
+  // ---- stage Q, dO (zero rows beyond Lq), the per-head bias over relative positions, lse, D = rowsum(dO * O) ----
+  for (int p = tid; p < 32 * C::PPR; p += 256) {
+    const int row = p / C::PPR, pc = p % C::PPR;
+    st16(tileQ + row * C::TS + pc * 16, row < a.Lq ? ld16(Q + (size_t)row * a.ldq + pc * C::EPF) : zero16());
+    st16(tileDO + row * C::TS + pc * 16, row < a.Lq ? ld16(dO + (size_t)row * a.lddo + pc * C::EPF) : zero16());
+  }
+  if (a.rel_table) {
+    for (int i = tid; i < nrel; i += 256) sbias[i] = a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h];
+    if (a.d_rel_table)
+      for (int i = tid; i < 4 * 528; i += 256) (&sdb[0][0])[i] = 0.f;
+  }
+  if (tid < 64) {        // 4 lanes per query, 16 columns each
+    const int q = tid >> 2, part = tid & 3;
+    float d = 0.f;
+    if (q < a.Lq) {
+      for (int c = 0; c < 16; c += C::EPF) {
+        float x[8], y[8];
+        unpack16<T>(ld16(dO + (size_t)q * a.lddo + part * 16 + c), x);
+        unpack16<T>(ld16(O + (size_t)q * a.ldo + part * 16 + c), y);
+#pragma unroll
+        for (int e = 0; e < C::EPF; ++e) d += x[e] * y[e];
+      }
+    }
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    if (part == 0) {
+      sD[q] = d;
+      slse[q] = q < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
+      if (a.Dvec && q < a.Lq) a.Dvec[((size_t)b * a.H + h) * a.Lq + q] = d;
+    }
+  }
+  for (int i = lane; i < 16 * RS / 4; i += 64) {        // zero the wave's A-operand images once (their padding columns stay zero)
+    ((unsigned*)aP[wave])[i] = 0u; ((unsigned*)aS[wave])[i] = 0u; ((unsigned*)bS[wave])[i] = 0u;
+  }
+  __syncthreads();
+
+  u32x4 qf[C::NCK], dof[C::NCK];
+#pragma unroll
+  for (int c = 0; c < C::NCK; ++c) { qf[c] = tile_frag_kc<T>(tileQ, 0, c, lane); dof[c] = tile_frag_kc<T>(tileDO, 0, c, lane); }
+  const bool causal = a.causal != 0;
+  const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const uint32_t seed = p5_seed(a.drop);
+  const int qb = g * 4;                                 // the lane's four queries qb .. qb + 3; its key is li of the wave's 16
+  const f32x4 ls = *(const f32x4*)(slse + qb), dd = *(const f32x4*)(sD + qb);
+  const int kc_w = (wave * 16) / KR, koff = (wave * 16) % KR;      // where the wave's 16 keys sit inside tileK's K-strided fragment chunks
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    stage_tile64<T>(tileK, K + (size_t)ch * 64 * a.ldk, a.ldk, a.Lk - ch * 64, tid);
+    stage_tile64<T>(tileV, V + (size_t)ch * 64 * a.ldv, a.ldv, a.Lk - ch * 64, tid);
+    __syncthreads();
+    const int k0 = ch * 64 + wave * 16, kj = k0 + li;
+    if (k0 < a.Lk) {                                    // (wave-uniform; a wave without keys in this chunk only takes part in the barriers)
+      const bool kok = kj < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + kj] != 0);
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C::NCK; ++c) {
+        // C[row = query g*4 + r][col = key li]
+        mma16<T>(sacc, qf[c], tile_frag_kc<T>(tileK, wave * 16, c, lane));
+        mma16<T>(dpacc, dof[c], tile_frag_kc<T>(tileV, wave * 16, c, lane));
+      }
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qb + r;
+        const int qic = qi < a.Lq ? qi : a.Lq - 1;
+        const float bias = a.rel_table ? sbias[(kj < a.Lk ? kj : a.Lk - 1) - qic + a.Lq - 1] : 0.f;
+        const float mk = do_drop ? (p5_keep(seed, a.drop.site_key, (uint32_t)((((size_t)b * a.H + h) * a.Lq + qic) * a.Lk) + (uint32_t)kj, a.drop.thr) ? a.drop.scale : 0.f) : 1.f;
+        const bool ok = kok & (qi < a.Lq) & !(causal & (kj > qi));
+        const float p = p5_exp<T>((sacc[r] + bias) - ls[r]);
+        pv[r] = ok ? p * mk : 0.f;
+        dsv[r] = ok ? p * (dpacc[r] * mk - dd[r]) : 0.f;
+      }
+      P5_WAVE_SYNC();
+      st4<T>(aP[wave] + li * RS + qb * C::SZ, pv);                 // [key li][queries qb..qb+3]
+      st4<T>(aS[wave] + li * RS + qb * C::SZ, dsv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(T*)(bS[wave] + (qb + r) * RS + (koff + li) * C::SZ) = from_f<T>(dsv[r]);      // [query][key]
+      P5_WAVE_SYNC();
+      if (a.d_rel_table) {
+        // sums of dS along the 31 diagonals (constant key - query) of the wave's [16 q][16 keys] block, into the wave's own row
+        for (int dg = lane; dg < 31; dg += 64) {
+          float sum = 0.f;
+#pragma unroll
+          for (int qr = 0; qr < 16; ++qr) {
+            const int kcol = dg - 15 + qr;
+            if (kcol >= 0 && kcol < 16) sum += to_f<T>(*(const T*)(bS[wave] + qr * RS + (koff + kcol) * C::SZ));
+          }
+          const int idx = k0 + dg - 15 + a.Lq - 1;
+          if (idx >= 0 && idx < nrel) sdb[wave][idx] += sum;
+        }
+      }
+      f32x4 dk[4], dv[4];
+      const u32x4 pa = ld16(aP[wave] + li * RS + g * 16), sa = ld16(aS[wave] + li * RS + g * 16);
+      const u32x4 dsa = ld16(bS[wave] + li * RS + g * 16);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma16<T>(dv[dt], pa, tile_frag_ks<T>(tileDO, dt * 16, 0, lane));
+        mma16<T>(dk[dt], sa, tile_frag_ks<T>(tileQ, dt * 16, 0, lane));
+        mma16<T>(dq[dt], dsa, tile_frag_ks<T>(tileK, dt * 16, kc_w, lane));
+      }
+      const float one[4] = {1.f, 1.f, 1.f, 1.f};
+      wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, wscr[wave], lane);
+      wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, wscr[wave], lane);
+    }
+  }
+  // ---- dQ: the four waves' partial sums (each over its keys of every chunk), added in wave order ----
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdq[wave][g * 4 + r][dt * 16 + li] = dq[dt][r];
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 t[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        t[dt][r] = ((sdq[0][g * 4 + r][dt * 16 + li] + sdq[1][g * 4 + r][dt * 16 + li]) + sdq[2][g * 4 + r][dt * 16 + li]) + sdq[3][g * 4 + r][dt * 16 + li];
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, 0, a.Lq, t, one, wscr[0], lane);
+  }
+  if (a.d_rel_table) {
+    for (int i = tid; i < nrel; i += 256) sdb[0][i] = ((sdb[0][i] + sdb[1][i]) + sdb[2][i]) + sdb[3][i];
+    __syncthreads();
+    rel_bias_grad_flush<256>(a, h, b, &sdb[0][0], sbias, tid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, fused (bf16, Lq and Lk <= 128: the encoder's self-attention at the benchmark shape).  The two-kernel backward
 // above reads Q, K, V, dO twice and recomputes P twice; measured on MI355X both kernels (and the forward) take ~0.4 us per
 // MB they move whatever their arithmetic looks like (rewriting the per-element code branch-free changed nothing), i.e. the

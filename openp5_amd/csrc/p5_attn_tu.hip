@@ -1,0 +1,51 @@
+// p5_attn_tu.hip -- translation unit of the attention family (p5_attn.h): kernel selection and launch (declarations in p5_host.h).
+#include "p5_host.h"
+
+int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")) : 1;   // whole-(batch, head) attention forward (bf16, L <= 128)
+int g_opt_attn_small = getenv("P5_ATTN_SMALL") ? atoi(getenv("P5_ATTN_SMALL")) : 1;   // one-launch backward for Lq <= 16
+int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
+
+template <class T>
+static int launch_attn_fwd_impl(const P5AttnArgs& a, hipStream_t s) {
+  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  P5_PROF_FLOPS(4.0 * a.B * a.H * a.Lq * a.Lk * 64);
+  if constexpr (sizeof(T) == 2) {
+    // one workgroup per (batch, head): K and V fetched once, every load up front, one barrier (p5_attn.h)
+    if (g_opt_attn_fwd_wg && a.Lq <= 128 && a.Lk <= 128) {
+      if (a.Lq > 64) P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 8>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      return P5_KCHECK();
+    }
+  }
+  dim3 grid((a.Lq + 63) / 64, a.B * a.H), block(256);
+  if (a.Lk <= 64) P5_LAUNCH((p5_attn_fwd_kernel<T, 4>), grid, block, 0, s, a);
+  else if (a.Lk <= 128) P5_LAUNCH((p5_attn_fwd_kernel<T, 8>), grid, block, 0, s, a);
+  else if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_kernel<T, 16>), grid, block, 0, s, a);
+  else P5_LAUNCH((p5_attn_fwd_kernel<T, 32>), grid, block, 0, s, a);
+  return P5_KCHECK();
+}
+template <class T>
+static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
+  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
+  dim3 block(256);
+  // short query blocks (the decoder's self- and cross-attention): dQ, dK, dV in one launch, the four waves split the keys (p5_attn.h)
+  if (g_opt_attn_small && a.Lq <= 16) {
+    P5_LAUNCH((p5_attn_bwd_small_kernel<T>), dim3(1, a.B * a.H), block, 0, s, a);
+    return P5_KCHECK();
+  }
+  if constexpr (sizeof(T) == 2) {
+    // one workgroup per (batch, head) that reads Q, K, V, dO once (p5_attn.h)
+    if (g_opt_attn_fused && a.Lq <= 128 && a.Lk <= 128 && a.Lq > 16 && a.Lk > 16) {
+      P5_LAUNCH((p5_attn_bwd_fused_kernel<T>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      return P5_KCHECK();
+    }
+  }
+  P5_LAUNCH((p5_attn_bwd_dq_kernel<T>), dim3((a.Lq + 63) / 64, a.B * a.H), block, 0, s, a);
+  P5_TRY(P5_KCHECK());
+  P5_LAUNCH((p5_attn_bwd_dkv_kernel<T>), dim3((a.Lk + 63) / 64, a.B * a.H), block, 0, s, a);
+  return P5_KCHECK();
+}
+
+
+int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_fwd_impl<bf16>(a, s) : launch_attn_fwd_impl<float>(a, s); }
+int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_bwd_impl<bf16>(a, s) : launch_attn_bwd_impl<float>(a, s); }

@@ -113,7 +113,7 @@ struct P5Prof {
   }
   void end(hipStream_t s) { hipEventRecord(recs.back().b, s); }
 };
-static inline P5Prof& p5_prof() { static P5Prof p; return p; }
+inline P5Prof& p5_prof() { static P5Prof p; return p; }      // (one instance for all translation units of the library)
 #define P5_LAUNCH(kern, grid, block, shmem, stream, ...)                                   \
   do {                                                                                     \
     P5Prof& _pf = p5_prof();                                                               \

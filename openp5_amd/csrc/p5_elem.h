@@ -338,12 +338,13 @@ __global__ __launch_bounds__(256) void p5_reduce_rows_kernel(float* __restrict__
   reduce_rows_16col(dst, partial, nrows, d, blockIdx.x);
 }
 
-// the same for every T5LayerNorm of a backward stage in ONE launch: slot z = blockIdx.y reduces its partial rows into its weight's
-// gradient (32 launches per T5-small step -> 14)
+// the same for up to 32 T5LayerNorms in ONE launch: slot z = blockIdx.y reduces its partial rows into its weight's gradient (the whole
+// backward of T5-small: 32 norms -> one launch at its end; a staged, data-parallel backward flushes at the end of every stage)
+#define P5_REDUCE_MULTI_MAX 32
 struct P5ReduceMulti {
   int n, d;
-  int nrows[4];
-  long long dst_off[4], part_off[4];    // element offsets into the gradient arena / the partial-sum scratch
+  int nrows[P5_REDUCE_MULTI_MAX];
+  long long dst_off[P5_REDUCE_MULTI_MAX], part_off[P5_REDUCE_MULTI_MAX];    // element offsets into the gradient arena / the partial-sum scratch
 };
 __global__ __launch_bounds__(256) void p5_reduce_rows_multi_kernel(P5ReduceMulti a, float* __restrict__ G, const float* __restrict__ scratch) {
   const int z = blockIdx.y;

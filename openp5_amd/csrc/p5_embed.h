@@ -5,8 +5,9 @@
 // atomics of a repeated token land in changes from run to run, the last bits of shared.weight's gradient with it, and AdamW turns a
 // last-bit difference of a near-zero gradient into an O(lr) difference of the parameter (tools/diag_repro.py,
 // profiles/r04_repro_before_fix.txt): two runs of the same training differed by up to 2 x lr.  Here the rows are summed in a FIXED order:
-//   1. p5_embed_rank_kernel     stable rank of every lookup row by (key, row): sorted position, start and length of its key's segment
-//                               (brute-force counting against all keys staged through LDS -- no sort network, no integer atomics);
+//   1. p5_embed_sortchunk_kernel + p5_embed_rank_kernel
+//                               stable rank of every lookup row by (key, row): sorted position, start and length of its key's segment
+//                               (chunks of 256 rows sorted in LDS, then one binary search per row and chunk -- integer comparisons only);
 //   2. p5_embed_seg_kernel      one workgroup per block of 32 sorted positions: rows of one key are added in row order; a segment that
 //                               lies inside the block is added to the table row by its only owner (plain read-modify-write), pieces of
 //                               segments that cross block boundaries go to a partial buffer;
@@ -29,6 +30,7 @@ struct P5EmbSet {
   int n0, n1;
   int* perm; int* sstart; int* slen;            // [n] sorted position -> row, start / length of the position's key segment
   int* skey;                                    // [n] sorted position -> key
+  unsigned long long* csort;                    // [ceil(n / 256) * 256] scratch: (key << 32 | row), sorted inside each chunk of 256 rows
   float* part;                                  // [blocks][2][d] pieces of segments crossing block boundaries (0: continues from before, 1: continues after)
 };
 struct P5EmbArgs {
@@ -38,45 +40,77 @@ struct P5EmbArgs {
 
 __device__ static __forceinline__ int emb_key(const P5EmbSet& s, int r) { return (int)(r < s.n0 ? s.key0[r] : s.key1[r - s.n0]); }
 
-// grid (ceil(max n / 64), nsets), 256 threads: lane = one of 64 rows, wave = a quarter of every staged chunk of keys
-__global__ __launch_bounds__(256) void p5_embed_rank_kernel(P5EmbArgs a) {
-  constexpr int CH = 4096;
-  __shared__ __attribute__((aligned(16))) int skeys[CH];
-  __shared__ int scnt[3][4][64];
+// Stable rank by (key, row) in two levels -- O(n (log c + (n / c) log c)) instead of the n^2 / 2 comparisons of a brute-force count
+// (which took 98 us at n = 8704 and would take milliseconds at the 33k rows of a T5-large, L = 512 batch):
+//   p5_embed_sortchunk_kernel   one workgroup per chunk of 256 rows: bitonic sort of the composite 64-bit values (key << 32 | row) in LDS
+//                               -> `csort` (sorted chunks, back to back);
+//   p5_embed_rank_kernel        one thread per row: its rank = sum over ALL chunks of the number of values below its own (a binary
+//                               search per chunk, chunks staged through LDS), likewise the start and the end of its key's segment
+//                               (values below key << 32 / below (key + 1) << 32).
+// Integer comparisons only: the same permutation on every run.
+#define P5_EMB_CHUNK 256
+__global__ __launch_bounds__(256) void p5_embed_sortchunk_kernel(P5EmbArgs a) {
+  __shared__ unsigned long long sv[P5_EMB_CHUNK];
   const P5EmbSet& s = a.s[blockIdx.y];
   const int n = s.n0 + s.n1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= n) return;
-  const int k = r < n ? emb_key(s, r) : 0x7fffffff;
-  int less = 0, eq_before = 0, eq = 0;
-  for (int base = 0; base < n; base += CH) {
-    __syncthreads();
-    for (int j = threadIdx.x; j < CH; j += 256) skeys[j] = base + j < n ? emb_key(s, base + j) : 0x7fffffff;
-    __syncthreads();
-    const int j0 = wave * (CH / 4);
-    const int jn = n - base < CH ? n - base : CH;       // valid keys of this chunk
-    for (int j = j0; j < j0 + CH / 4 && j < jn; j += 4) {
-      const i32x4 kv = *(const i32x4*)(skeys + j);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = kv[q], rr = base + j + q;           // (padding keys 0x7fffffff are never < or == a real key)
-        less += kk < k ? 1 : 0;
-        const int e = kk == k ? 1 : 0;
-        eq += e;
-        eq_before += (e & (rr < r ? 1 : 0));
+  const int r = blockIdx.x * P5_EMB_CHUNK + threadIdx.x;
+  if (blockIdx.x * P5_EMB_CHUNK >= n) return;
+  sv[threadIdx.x] = r < n ? (((unsigned long long)(unsigned)emb_key(s, r)) << 32) | (unsigned)r : ~0ull;      // (padding sorts last)
+  __syncthreads();
+  for (int k = 2; k <= P5_EMB_CHUNK; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int i = threadIdx.x, l = i ^ j;
+      if (l > i) {
+        const unsigned long long x = sv[i], y = sv[l];
+        const bool up = (i & k) == 0;
+        if ((x > y) == up) { sv[i] = y; sv[l] = x; }
       }
+      __syncthreads();
     }
   }
-  scnt[0][wave][lane] = less; scnt[1][wave][lane] = eq_before; scnt[2][wave][lane] = eq;
-  __syncthreads();
-  if (wave == 0 && r < n) {
-    const int L = scnt[0][0][lane] + scnt[0][1][lane] + scnt[0][2][lane] + scnt[0][3][lane];
-    const int Bf = scnt[1][0][lane] + scnt[1][1][lane] + scnt[1][2][lane] + scnt[1][3][lane];
-    const int E = scnt[2][0][lane] + scnt[2][1][lane] + scnt[2][2][lane] + scnt[2][3][lane];
-    const int pos = L + Bf;
-    s.perm[pos] = r; s.skey[pos] = k; s.sstart[pos] = L; s.slen[pos] = E;
+  s.csort[(size_t)blockIdx.x * P5_EMB_CHUNK + threadIdx.x] = sv[threadIdx.x];
+}
+
+// number of values of the sorted array v[0..m) that are < x
+__device__ static __forceinline__ int emb_lower_bound(const unsigned long long* v, int m, unsigned long long x) {
+  int lo = 0, hi = m;
+#pragma unroll 1
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v[mid] < x) lo = mid + 1; else hi = mid;
   }
+  return lo;
+}
+
+// grid (ceil(max n / 256), nsets), 256 threads: one row each; the sorted chunks pass through LDS 16 at a time (32 KiB)
+__global__ __launch_bounds__(256) void p5_embed_rank_kernel(P5EmbArgs a) {
+  constexpr int CPB = 16;                 // chunks per LDS batch
+  __shared__ unsigned long long sc[CPB * P5_EMB_CHUNK];
+  const P5EmbSet& s = a.s[blockIdx.y];
+  const int n = s.n0 + s.n1;
+  if (blockIdx.x * 256 >= n) return;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int k = r < n ? emb_key(s, r) : 0;
+  const unsigned long long me = (((unsigned long long)(unsigned)k) << 32) | (unsigned)r;
+  const unsigned long long klo = ((unsigned long long)(unsigned)k) << 32, khi = ((unsigned long long)(unsigned)k + 1ull) << 32;
+  const int nchunks = (n + P5_EMB_CHUNK - 1) / P5_EMB_CHUNK;
+  int pos = 0, start = 0, end = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += CPB) {
+    const int nc = nchunks - c0 < CPB ? nchunks - c0 : CPB;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc * P5_EMB_CHUNK; i += 256) sc[i] = s.csort[(size_t)c0 * P5_EMB_CHUNK + i];
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const unsigned long long* v = sc + c * P5_EMB_CHUNK;
+      const int lo = emb_lower_bound(v, P5_EMB_CHUNK, klo);      // (padding values ~0 are above every real value)
+      start += lo;
+      // the chunk's values of this key form the run [lo, hi): search the rest inside it
+      const int hi = lo + emb_lower_bound(v + lo, P5_EMB_CHUNK - lo, khi);
+      end += hi;
+      pos += lo + emb_lower_bound(v + lo, hi - lo, me);
+    }
+  }
+  if (r < n) { s.perm[pos] = r; s.skey[pos] = k; s.sstart[pos] = start; s.slen[pos] = end - start; }
 }
 
 // value of lookup row `r`, columns c..c+1 (dropout of the forward re-applied)

@@ -12,51 +12,21 @@
 #include <cmath>
 #include <cstdlib>
 
-#include "p5_device.h"
-#include "p5_rng.h"
-#include "p5_gemm.h"
-#include "p5_gemm4.h"
-#include "p5_gemm5.h"
-#include "p5_attn.h"
+#include "p5_host.h"
 #include "p5_elem.h"
 #include "p5_embed.h"
 #include "p5_decode.h"
 #include "p5_decode2.h"
 #include "../../include/p5hip.h"
 
-static thread_local std::string g_err;
-static int fail(const std::string& m) { g_err = m; return -1; }
-#define P5_REQUIRE(cond, msg) do { if (!(cond)) return fail(std::string(msg) + " [" #cond "]"); } while (0)
-#define P5_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
-#ifdef P5_EMU
-#define P5_KCHECK() 0
-#else
-static int kcheck(const char* where) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(std::string(where) + ": " + hipGetErrorString(e));
-  return 0;
-}
-#define P5_KCHECK() kcheck(__func__)
-#endif
+thread_local std::string g_p5_err;
 
 // =====================================================================================================
 // launchers
 // =====================================================================================================
-// tuning knobs (p5_set_option / environment): gemm_v2 = LDS stages (2 or 3) of the hand-pipelined main loop, 0 = v1 loop
-static int g_opt_gemm_v2 = getenv("P5_GEMM_V2") ? atoi(getenv("P5_GEMM_V2")) : 0;
+// tuning knobs (p5_set_option / environment) of the engine and the decode step; the GEMM / attention families keep theirs in their own units
 static int g_opt_wgrad_group = getenv("P5_WGRAD_GROUP") ? atoi(getenv("P5_WGRAD_GROUP")) : 1;   // layer-grouped deferred weight gradients (bf16)
-static int g_opt_gemm_tile = getenv("P5_GEMM_TILE") ? atoi(getenv("P5_GEMM_TILE")) : 0;
-static int g_opt_gemm_ring = getenv("P5_GEMM_RING") ? atoi(getenv("P5_GEMM_RING")) : 1;      // ring kernel for weight gradients
-static int g_opt_gemm_xcd_rect = getenv("P5_GEMM_XCD_RECT") ? atoi(getenv("P5_GEMM_XCD_RECT")) : 1;   // rectangular per-XCD tile blocks
-static int g_opt_gemm_small_ring = getenv("P5_GEMM_SMALL_RING") ? atoi(getenv("P5_GEMM_SMALL_RING")) : 1;   // 8-slot ring for sub-CU-count problems
-static int g_opt_gemm_ring32 = getenv("P5_GEMM_RING32") ? atoi(getenv("P5_GEMM_RING32")) : 128;   // 32x64 ring tiles for problems of at most this many 64x64 tiles (0 = off)
-static int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")) : 1;   // whole-(batch, head) attention forward (bf16, L <= 128)
-static int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
-static int g_opt_gemm_small_ring_tiles = getenv("P5_GEMM_SMALL_RING_TILES") ? atoi(getenv("P5_GEMM_SMALL_RING_TILES")) : 256;   // ... up to this many 64x64 tiles
-static int g_opt_gemm_ring_stages = getenv("P5_GEMM_RING_STAGES") ? atoi(getenv("P5_GEMM_RING_STAGES")) : 4;
-static int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING_WGS")) : 160;      // target tiles x splits (in-step sweep: 96..192 equal, 256 +1.5 %)
 static int g_opt_decode_fused = getenv("P5_DECODE_FUSED") ? atoi(getenv("P5_DECODE_FUSED")) : 1;   // RMSNorm folded into the decode-step GEMMs
-static int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 static int g_opt_decode_v2 = getenv("P5_DECODE_V2") ? atoi(getenv("P5_DECODE_V2")) : 1;   // latency-shaped decode step (p5_decode2.h)
 static int g_opt_dec_nb = getenv("P5_DEC_NB") ? atoi(getenv("P5_DEC_NB")) : 0;           // skinny GEMM: forced column-tile width (0 = auto)
 static int g_opt_dec_kw = getenv("P5_DEC_KW") ? atoi(getenv("P5_DEC_KW")) : 0;           // skinny GEMM: forced K range per workgroup (0 = auto)
@@ -65,289 +35,6 @@ static int g_opt_dgrad_t = getenv("P5_DGRAD_T") ? atoi(getenv("P5_DGRAD_T")) : 1
 static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS")) : 3;   // 3 = MFMA cross-attention, 2 = scalar score / PV loops
 static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
 static int g_opt_dec_head_nv = getenv("P5_DEC_HEAD_NV") ? atoi(getenv("P5_DEC_HEAD_NV")) : 0;   // streaming head: forced E rows per workgroup (0 = auto)
-
-#ifdef P5_EMU
-#define P5_PROF_FLOPS(x) ((void)0)
-#define P5_PROF_TAG(x) ((void)0)
-#else
-#define P5_PROF_FLOPS(x) (p5_prof().pending_flops = (x))
-#define P5_PROF_TAG(x) (p5_prof().pending_tag = (x))
-#endif
-template <class T, int BM, int BN>
-static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
-  P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
-  P5_PROF_TAG(sizeof(T) == 2 ? (BM == 256 ? "bf16 256x256" : BM == 128 ? (g.a_ks ? "bf16 128x128 KS" : "bf16 128x128 KC") : (g.a_ks ? "bf16 64x64 KS" : (g.b_ks ? "bf16 64x64 KC/KS" : "bf16 64x64 KC")))
-                             : (BM == 128 ? "f32 128x128" : "f32 64x64"));
-  g.xcd_bm = g.xcd_bn = 0;
-  if (g_opt_gemm_xcd_rect) {
-    // exact cover of the gx x gy tile grid by 8 equal rectangles; keep the one with the smallest half-perimeter, and only if
-    // it beats the contiguous-run order (runs of q tiles: ~ceil(q / gx) rows x min(q, gx) columns)
-    const int gx = (int)grid.x, gy = (int)grid.y;
-    if ((gx * gy) % 8 == 0) {
-      const int q = gx * gy / 8;
-      int best = (q + gx - 1) / gx + (q < gx ? q : gx);
-      for (int bn = 1; bn <= gx; ++bn) {
-        if (gx % bn || q % bn) continue;
-        const int bm = q / bn;
-        if (bm > gy || gy % bm || (gx / bn) * (gy / bm) != 8) continue;
-        if (bm + bn < best) { best = bm + bn; g.xcd_bm = bm; g.xcd_bn = bn; }
-      }
-    }
-  }
-  const int mode = g.a_ks * 2 + g.b_ks;
-  // direct-to-LDS staging for K-contiguous operands whenever every K-step is full (fast-mode dtype only)
-  const bool dma = sizeof(T) == 2 && (g.K % (TT<T>::KCH * 2)) == 0;
-  const int v2 = g_opt_gemm_v2;
-  if constexpr (sizeof(T) == 2 && BM == 256) {
-    P5_REQUIRE(mode == 0 && dma, "gemm: 256x256 tiles need bf16 K-contiguous operands with K % 64 == 0");
-    P5_LAUNCH((p5_gemm3_kernel<BM, BN, 2, 4>), grid, dim3(512), 0, s, g);
-    return P5_KCHECK();
-  }
-  if constexpr (sizeof(T) == 2 && BM == 128) {
-    if (mode == 0 && dma && g.ring && v2 == 0) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4>), grid, block, 0, s, g); return P5_KCHECK(); }
-    if (mode == 0 && dma && v2 == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3>), grid, block, 0, s, g); return P5_KCHECK(); }
-    if (mode == 0 && dma && v2 == 2) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 2>), grid, block, 0, s, g); return P5_KCHECK(); }
-    if (mode == 3 && dma && (v2 >= 3 || g.ring)) {
-      if (v2 == 3 || (v2 == 0 && g_opt_gemm_ring_stages == 3)) P5_LAUNCH((p5_gemm2_kernel<BM, BN, 3, true, true>), grid, block, 0, s, g);
-      else P5_LAUNCH((p5_gemm2_kernel<BM, BN, 4, true, true>), grid, block, 0, s, g);
-      return P5_KCHECK();
-    }
-  }
-  if constexpr (sizeof(T) == 2 && BM == 64) {
-    // small problems (fewer tiles than CUs): the K loop of a lone workgroup is a chain of load latencies, ~1 us per step with
-    // one stage of lookahead.  Eight 16 KiB ring slots keep seven K-steps in flight (K = 512 is fetched entirely up front):
-    // 512x512x512 8.2 -> ~4 us.  This is what the decoder and the decode step are made of.
-    if (g.ring && dma) {
-      if (mode == 0) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, false>), grid, block, 0, s, g); return P5_KCHECK(); }
-      if (mode == 1) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, true>), grid, block, 0, s, g); return P5_KCHECK(); }
-      if (mode == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, true, true>), grid, block, 0, s, g); return P5_KCHECK(); }
-    }
-  }
-  if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
-  else if (mode == 0) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false>), grid, block, 0, s, g);
-  else if (mode == 1 && dma && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
-  else if (mode == 3 && dma && g_opt_gemm_ksdma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
-  else if (mode == 1 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, sizeof(T) == 2, false>), grid, block, 0, s, g);
-  else if (mode == 1) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, true, 2, false, false>), grid, block, 0, s, g);
-  else if (mode == 3) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, true, true, 2, false, false>), grid, block, 0, s, g);
-  else return fail("gemm: (A strided, B contiguous) is not instantiated");
-  return P5_KCHECK();
-}
-
-// ---- persistent ring GEMM (p5_gemm4.h): one launch over a group of problems, bf16 operands, K % (64 * splitk) == 0 ----
-static int g_opt_gemm_wide = getenv("P5_GEMM_WIDE") ? atoi(getenv("P5_GEMM_WIDE")) : 1;         // 256x128 persistent ring for wide outputs
-static int g_opt_gemm_wide_min_tiles = getenv("P5_GEMM_WIDE_MIN_TILES") ? atoi(getenv("P5_GEMM_WIDE_MIN_TILES")) : 160;
-static int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RING_N512")) : 1;   // ring kernel for N = d_model, K >= 1024
-static int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
-static int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
-static int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
-enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2, P5_G5_256x128 = 3 };
-template <int BM, int BN, int WMW, int WNW, int NST, bool KS, int OCC = 1>
-static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
-  int units = 0;
-  for (int i = 0; i < grp.nprob; ++i) {
-    P5GemmArgs& g = grp.p[i];
-    if (g.splitk < 1) g.splitk = 1;
-    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm4: K must be a multiple of 64 x split-K");
-    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm4: operand alignment");
-    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm4: split-K needs the atomic epilogue");
-    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm4: accumulate epilogues need fp32 C");
-    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    g.g4_tiles_n = tn;
-    g.g4_nk = g.K / 64 / g.splitk;
-    grp.unit_begin[i] = units;
-    units += tm * tn * g.splitk;
-  }
-  grp.unit_begin[grp.nprob] = units;
-  grp.total_units = units;
-  int nwg = ((units + 7) / 8) * 8;
-  if (nwg > g_opt_g4_wgs * OCC) nwg = g_opt_g4_wgs * OCC;
-  {
-    double fl = 0.0;
-    for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
-    P5_PROF_FLOPS(fl);
-    P5_PROF_TAG(KS ? (BM == 256 ? "256x128 KS" : "128x128 KS") : (BM == 256 ? "256x128 KC" : "128xN KC"));
-  }
-  P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
-  return P5_KCHECK();
-}
-template <bool KS>
-static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit bookkeeping as launch_gemm4_cfg<256, 128, ...>, 4 loader + 4 compute waves
-  int units = 0;
-  for (int i = 0; i < grp.nprob; ++i) {
-    P5GemmArgs& g = grp.p[i];
-    if (g.splitk < 1) g.splitk = 1;
-    P5_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 64 * g.splitk && g.K % (64 * g.splitk) == 0, "gemm5: K must be a multiple of 64 x split-K");
-    P5_REQUIRE(g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm5: operand alignment");
-    P5_REQUIRE(g.splitk == 1 || g.epi == P5_EPI_ATOMIC, "gemm5: split-K needs the atomic epilogue");
-    if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm5: accumulate epilogues need fp32 C");
-    g.g4_tiles_n = (g.N + 127) / 128;
-    g.g4_nk = g.K / 64 / g.splitk;
-    grp.unit_begin[i] = units;
-    units += ((g.M + 255) / 256) * g.g4_tiles_n * g.splitk;
-  }
-  grp.unit_begin[grp.nprob] = units;
-  grp.total_units = units;
-  int nwg = ((units + 7) / 8) * 8;
-  if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
-  {
-    double fl = 0.0;
-    for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
-    P5_PROF_FLOPS(fl);
-    P5_PROF_TAG(KS ? "KS: grouped weight gradients" : "KC: forward / data-gradient GEMMs");
-  }
-  P5_LAUNCH((p5_gemm5_kernel<KS>), dim3(nwg), dim3(512), 0, s, grp);
-  return P5_KCHECK();
-}
-static int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
-  P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
-  if (cfg == P5_G5_256x128 || (cfg == P5_G4_256x128 && (g_opt_gemm_ws & (ks ? 2 : 1)))) return ks ? launch_gemm5<true>(grp, s) : launch_gemm5<false>(grp, s);
-  if (ks) {
-    if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, true>(grp, s);
-    P5_REQUIRE(cfg == P5_G4_128x128, "gemm4: K-strided operands run on 128x128 or 256x128 tiles");
-    if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, true, 2>(grp, s);     // two-slot ring, two workgroups per CU
-    if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, true>(grp, s);
-    if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, true>(grp, s);
-    return launch_gemm4_cfg<128, 128, 2, 2, 5, true>(grp, s);
-  }
-  if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, false>(grp, s);
-  if (cfg == P5_G4_128x256) return launch_gemm4_cfg<128, 256, 2, 4, 3, false>(grp, s);
-  if (g_opt_g4_nst == 2) return launch_gemm4_cfg<128, 128, 2, 2, 2, false, 2>(grp, s);
-  if (g_opt_g4_nst == 3) return launch_gemm4_cfg<128, 128, 2, 2, 3, false>(grp, s);
-  if (g_opt_g4_nst == 4) return launch_gemm4_cfg<128, 128, 2, 2, 4, false>(grp, s);
-  return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
-}
-
-template <class T>
-static int launch_gemm(P5GemmArgs g, hipStream_t s) {
-  constexpr int EPF = TT<T>::EPF;
-  P5_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem");
-  P5_REQUIRE(g.lda % EPF == 0 && g.ldb % EPF == 0, "gemm: leading dims must be multiples of 16 bytes");
-  P5_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");
-  if (!g.a_ks) P5_REQUIRE(g.K % EPF == 0 || g.lda >= ((g.K + EPF - 1) / EPF) * EPF, "gemm: A K-extent");
-  if (!g.b_ks) P5_REQUIRE(g.K % EPF == 0 || g.ldb >= ((g.K + EPF - 1) / EPF) * EPF, "gemm: B K-extent");
-  if (g.a_ks) P5_REQUIRE(g.M % EPF == 0 || g.lda >= ((g.M + EPF - 1) / EPF) * EPF, "gemm: A M-extent (KS)");
-  if (g.b_ks) P5_REQUIRE(g.N % EPF == 0 || g.ldb >= ((g.N + EPF - 1) / EPF) * EPF, "gemm: B N-extent (KS)");
-  if (g.epi == P5_EPI_ATOMIC || g.epi == P5_EPI_ACCUM) P5_REQUIRE(g.c_f32, "gemm: accumulate epilogues need fp32 C");
-  const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  const int force_tile = g_opt_gemm_tile;
-  if constexpr (sizeof(T) == 2) {
-    const bool kc = !g.a_ks && !g.b_ks && (g.K % 64) == 0 && g.splitk <= 1 && (g.lda % 64) == 0 && (g.ldb % 64) == 0 && !force_tile && !g_opt_gemm_v2;
-    // wide outputs: 256x128 tiles, eight waves, persistent three-slot ring (p5_gemm4.h) once there are enough of them to occupy most
-    // CUs -- 0.75 of the L2->LDS bytes per MAC of a 128x128 tile and two waves per SIMD to overlap LDS reads with MFMAs
-    // (tools/lab, round 3: 8192x2048x512 25.3 vs 27.6 us, 8192x3072x768 47 vs 54, 8192x4096x1024 73 vs 87 (128x128) / 125 (256x256
-    // eight-wave two-slot kernel), 8192^2 x 2048 252 vs 382 us)
-    if (kc && g_opt_gemm_wide && (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= g_opt_gemm_wide_min_tiles && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
-      P5GemmGroup grp;
-      memset(&grp, 0, sizeof(grp));
-      grp.nprob = 1;
-      grp.p[0] = g;
-      grp.p[0].splitk = 1;
-      return launch_gemm4(P5_G4_256x128, false, grp, s);
-    }
-    // narrow outputs (N = d_model) with a long reduction: one 128x128 tile per CU on the four-slot ring instead of 64x64 tiles
-    if (kc && g_opt_gemm_ring_n512 && t128 >= 128 && t128 <= 256 && g.K >= 1024 && g.epi != P5_EPI_ATOMIC) {
-      g.ring = 1;
-      g.splitk = 1;
-      return launch_gemm_tile<T, 128, 128>(g, s);
-    }
-  }
-  static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
-  // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
-  bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
-  // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
-  // split-K so that tiles x splits ~ 160: in isolation ~256 (every CU) is fastest, inside the step fewer, longer workgroups leave
-  // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;
-  // below 48 tiles the 64x64 kernel still wins)
-  if (sizeof(T) == 2 && !force_tile && g_opt_gemm_ring && g.a_ks && g.b_ks && g.epi == P5_EPI_ATOMIC && g.splitk <= 0 && t128 >= 48 &&
-      t128 <= 256 && g.K >= 2048 && (g.K % 64) == 0) {
-    g.ring = 1;
-    big = true;
-    int sk = (int)((g_opt_gemm_ring_wgs + t128 / 2) / t128);
-    const int maxs = g.K / 64 / 8;
-    g.splitk = sk < 1 ? 1 : (sk > maxs ? maxs : sk);
-  }
-  const long tiles = big ? t128 : (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-  if (sizeof(T) == 2 && !big && !force_tile && g_opt_gemm_small_ring && !g.ring && tiles <= g_opt_gemm_small_ring_tiles && g.K >= 256 && (g.K % 64) == 0 &&
-      (g.a_ks == 0 || g.b_ks == 1) &&
-      (g.epi != P5_EPI_ATOMIC || g.K <= 1024)) {
-    g.ring = 1;                      // (long-K atomic problems keep the split-K path below)
-    if (g.splitk <= 0) g.splitk = 1;
-  }
-  if (g.splitk <= 0) {
-    g.splitk = 1;
-    if (g.epi == P5_EPI_ATOMIC) {
-      const int nkc = (g.K + TT<T>::KCH - 1) / TT<T>::KCH;
-      int want = (int)(((g.K >= 16384 ? 384 : split_target) + tiles - 1) / tiles);
-      int maxs = nkc / 8 > 0 ? nkc / 8 : 1;
-      g.splitk = want < maxs ? want : maxs;
-      if (g.splitk < 1) g.splitk = 1;
-    }
-  }
-  if (g.splitk > 1) P5_REQUIRE(g.epi == P5_EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
-  if (g.c_split_stride > 0) return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);    // (blockIdx.z = split index)
-  if constexpr (sizeof(T) == 2) {
-    // 256x256 tiles halve the L2->LDS bytes per MAC; they pay off once every CU gets a tile and the K loop is long enough to
-    // amortise the un-overlapped prologue/epilogue of the single resident workgroup (tools/gemm_v2_bench.py: 8192x2048x2048
-    // 80 -> 63 us, 4096^3 150 -> 110 us; at K = 512 it is a wash)
-    const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    const bool kc_dma = !g.a_ks && !g.b_ks && (g.K % 64) == 0;
-    if (force_tile == 256 || (!force_tile && kc_dma && t256 >= 256 && g.K >= 1024 && g.splitk <= 1)) {
-      if (g.splitk <= 0) g.splitk = 1;
-      return launch_gemm_tile<T, 256, 256>(g, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    // the decoder's 512-row problems: 64 tiles of 64x64 use a quarter of the CUs, each pulling 128 KiB through its ring; 32x64
-    // tiles double the workgroups and halve the A rows each one waits for
-    if (!big && g.ring && !g.a_ks && !g.b_ks && g.splitk <= 1 && tiles <= g_opt_gemm_ring32) {
-      dim3 grid((g.N + 63) / 64, (g.M + 31) / 32, 1);
-      g.xcd_bm = g.xcd_bn = 0;
-      g.splitk = 1;
-      P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
-      P5_LAUNCH((p5_gemm2_kernel<32, 64, 8, false, false>), grid, dim3(256), 0, s, g);
-      return P5_KCHECK();
-    }
-  }
-  return big ? launch_gemm_tile<T, 128, 128>(g, s) : launch_gemm_tile<T, 64, 64>(g, s);
-}
-
-template <class T>
-static int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) {
-  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
-  P5_PROF_FLOPS(4.0 * a.B * a.H * a.Lq * a.Lk * 64);
-  if constexpr (sizeof(T) == 2) {
-    // one workgroup per (batch, head): K and V fetched once, every load up front, one barrier (p5_attn.h)
-    if (g_opt_attn_fwd_wg && a.Lq <= 128 && a.Lk <= 128) {
-      if (a.Lq > 64) P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 8>), dim3(a.B * a.H), dim3(512), 0, s, a);
-      else P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
-      return P5_KCHECK();
-    }
-  }
-  dim3 grid((a.Lq + 63) / 64, a.B * a.H), block(256);
-  if (a.Lk <= 64) P5_LAUNCH((p5_attn_fwd_kernel<T, 4>), grid, block, 0, s, a);
-  else if (a.Lk <= 128) P5_LAUNCH((p5_attn_fwd_kernel<T, 8>), grid, block, 0, s, a);
-  else if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_kernel<T, 16>), grid, block, 0, s, a);
-  else P5_LAUNCH((p5_attn_fwd_kernel<T, 32>), grid, block, 0, s, a);
-  return P5_KCHECK();
-}
-template <class T>
-static int launch_attn_bwd(const P5AttnArgs& a, hipStream_t s) {
-  P5_REQUIRE(a.Lk >= 1 && a.Lk <= 512 && a.Lq >= 1 && a.Lq <= 512, "attention: 1 <= L <= 512");
-  dim3 block(256);
-  if constexpr (sizeof(T) == 2) {
-    // one workgroup per (batch, head) that reads Q, K, V, dO once (p5_attn.h); short decoder blocks stay on the two-kernel path
-    if (g_opt_attn_fused && a.Lq <= 128 && a.Lk <= 128 && a.Lq > 16 && a.Lk > 16) {
-      P5_LAUNCH((p5_attn_bwd_fused_kernel<T>), dim3(a.B * a.H), dim3(512), 0, s, a);
-      return P5_KCHECK();
-    }
-  }
-  P5_LAUNCH((p5_attn_bwd_dq_kernel<T>), dim3((a.Lq + 63) / 64, a.B * a.H), block, 0, s, a);
-  P5_TRY(P5_KCHECK());
-  P5_LAUNCH((p5_attn_bwd_dkv_kernel<T>), dim3((a.Lk + 63) / 64, a.B * a.H), block, 0, s, a);
-  return P5_KCHECK();
-}
 
 __global__ __launch_bounds__(256) void p5_shift_right_kernel(int64_t* out, const int64_t* labels, int B, int T, int64_t start) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -457,6 +144,7 @@ struct P5Engine {
   float* dw_scratch = nullptr;   // [norm slots][<=1024 workgroups][d] partial norm-weight gradients
   // deterministic embedding gradients (p5_embed.h): set 0 = tied table E over the encoder ids followed by the decoder ids, set 1 = whole-word table
   int* emb_idx[P5_EMB_MAXSETS] = {};     // perm | skey | sstart | slen, n ints each
+  unsigned long long* emb_csort[P5_EMB_MAXSETS] = {};
   float* emb_part[P5_EMB_MAXSETS] = {};
   float* dres_dec0 = nullptr;            // [Md, d] gradient of the decoder's embedding rows (kept until the last stage)
   float* dres_out_override = nullptr;    // the next swap_norm_bwd writes its residual gradient here
@@ -950,6 +638,8 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     {
       const size_t n0 = M + Md, n1 = M;
       e->emb_idx[0] = (int*)b.take(4 * n0 * 4); e->emb_idx[1] = (int*)b.take(4 * n1 * 4);
+      e->emb_csort[0] = (unsigned long long*)b.take(((n0 + P5_EMB_CHUNK - 1) / P5_EMB_CHUNK) * P5_EMB_CHUNK * 8);
+      e->emb_csort[1] = (unsigned long long*)b.take(((n1 + P5_EMB_CHUNK - 1) / P5_EMB_CHUNK) * P5_EMB_CHUNK * 8);
       e->emb_part[0] = (float*)b.take(((n0 + P5_EMB_SEG - 1) / P5_EMB_SEG) * 2 * d * 4);
       e->emb_part[1] = (float*)b.take(((n1 + P5_EMB_SEG - 1) / P5_EMB_SEG) * 2 * d * 4);
       e->dres_dec0 = (float*)b.take((Md > 0 ? Md : 1) * d * 4);
@@ -1167,7 +857,7 @@ static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_o
   // the per-workgroup partials are summed off the critical path, all norms of the stage in one launch (norm_flush)
   {
     P5ReduceMulti& r = e->nr_pending;
-    if (r.n == 4) P5_TRY(norm_flush(e, s));
+    if (r.n == P5_REDUCE_MULTI_MAX) P5_TRY(norm_flush(e, s));
     r.d = d;
     r.nrows[r.n] = nblk;
     r.dst_off[r.n] = ln_off;
@@ -1325,8 +1015,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       P5_TRY(dgrad_w<T>(e, side2 ? e->side : s, e->dkv_all, ldkv, e->dec[0].ca.k, e->d_enc, d, M, ldkv, d, P5_EPI_STORE,
                              nullptr, 0, 1.f, 1));
     }
-    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s, e->G + e->off_dec_rel,
-              (const float*)(e->rel_partial + (size_t)rel_slots(e->B, e->L) * c.rel_buckets * H), c.rel_buckets * H, rel_slots(e->B, e->T));
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((c.rel_buckets * H + 15) / 16), dim3(256), 0, s, e->G + e->off_dec_rel,
+              (const float*)(e->rel_partial + (size_t)rel_slots(e->B, e->L) * c.rel_buckets * H), rel_slots(e->B, e->T), c.rel_buckets * H);
     P5_TRY(P5_KCHECK());
 #ifndef P5_EMU
     // shared.weight's gradient: the tied head's weight gradient adds with plain read-modify-writes (side stream, stage 0); the
@@ -1375,8 +1065,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
 #ifndef P5_EMU
     if (e->side) { fork_to_side(e, s); s2 = e->side; }
 #endif
-    P5_LAUNCH(p5_reduce_copies_kernel, dim3((c.rel_buckets * H + 255) / 256), dim3(256), 0, s2, e->G + e->off_enc_rel,
-              (const float*)e->rel_partial, c.rel_buckets * H, rel_slots(e->B, e->L));
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((c.rel_buckets * H + 15) / 16), dim3(256), 0, s2, e->G + e->off_enc_rel,
+              (const float*)e->rel_partial, rel_slots(e->B, e->L), c.rel_buckets * H);
     P5_TRY(P5_KCHECK());
     if (g_opt_embed_det) {
       // embedding gradients without atomics (p5_embed.h): tied table over (encoder ids ++ decoder ids), whole-word table over the encoder's
@@ -1391,8 +1081,11 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
         q.table = e->G + (k == 0 ? e->off_E : e->off_WW);
         q.perm = e->emb_idx[k]; q.skey = q.perm + n[k]; q.sstart = q.skey + n[k]; q.slen = q.sstart + n[k];
         q.part = e->emb_part[k];
+        q.csort = e->emb_csort[k];
       }
-      P5_LAUNCH(p5_embed_rank_kernel, dim3((n[0] + 63) / 64, 2), dim3(256), 0, s, ea);
+      P5_LAUNCH(p5_embed_sortchunk_kernel, dim3((n[0] + P5_EMB_CHUNK - 1) / P5_EMB_CHUNK, 2), dim3(256), 0, s, ea);
+      P5_TRY(P5_KCHECK());
+      P5_LAUNCH(p5_embed_rank_kernel, dim3((n[0] + 255) / 256, 2), dim3(256), 0, s, ea);
       P5_TRY(P5_KCHECK());
       const int nblk = (n[0] + P5_EMB_SEG - 1) / P5_EMB_SEG;
       P5_LAUNCH(p5_embed_seg_kernel, dim3(nblk, 2), dim3(256), 0, s, ea);
@@ -1890,7 +1583,7 @@ __global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restri
 
 extern "C" {
 
-const char* p5_last_error(void) { return g_err.c_str(); }
+const char* p5_last_error(void) { return g_p5_err.c_str(); }
 int p5_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_v2")) g_opt_gemm_v2 = value;
   else if (!strcmp(name, "gemm_tile")) g_opt_gemm_tile = value;
@@ -1901,6 +1594,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_small_ring_tiles")) g_opt_gemm_small_ring_tiles = value;
   else if (!strcmp(name, "attn_fused")) g_opt_attn_fused = value;
   else if (!strcmp(name, "attn_fwd_wg")) g_opt_attn_fwd_wg = value;
+  else if (!strcmp(name, "attn_small")) g_opt_attn_small = value;
   else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
   else if (!strcmp(name, "decode_v2")) g_opt_decode_v2 = value;
@@ -1920,6 +1614,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
+  else if (!strcmp(name, "gemm_wide_min_tiles")) g_opt_gemm_wide_min_tiles = value;
+  else if (!strcmp(name, "wgrad_wide_min")) g_opt_wgrad_wide_min = value;
   else if (!strcmp(name, "grad_store_first")) g_opt_grad_store_first = value;
   else if (!strcmp(name, "embed_det")) g_opt_embed_det = value;
   else if (!strcmp(name, "g4_nst")) g_opt_g4_nst = value;
@@ -2393,7 +2089,7 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
   }
   P5_TRY(dtype == 1 ? launch_attn_bwd<bf16>(a, s) : launch_attn_bwd<float>(a, s));
   if (d_rel_table) {
-    P5_LAUNCH(p5_reduce_copies_kernel, dim3((rel_buckets * H + 255) / 256), dim3(256), 0, s, d_rel_table, (const float*)d_rel_scratch, rel_buckets * H, rel_slots(B, Lq));
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((rel_buckets * H + 15) / 16), dim3(256), 0, s, d_rel_table, (const float*)d_rel_scratch, rel_slots(B, Lq), rel_buckets * H);
     P5_TRY(P5_KCHECK());
   }
   return 0;

@@ -30,10 +30,32 @@ def write_prompt_file(path):
     return path
 
 
-def make_user_sequences(dataset, seed=2023, n_users=None, n_items=None, n_inter=None):
+def make_user_sequences(dataset, seed=2023, n_users=None, n_items=None, n_inter=None, signal=None):
+    """`signal="chain"`: a LEARNABLE stand-in -- every user walks one fixed random cycle over the items from a random start, with a
+    jump to a random item every ~12 steps: the next item is a function of the last one, so a model trained on it becomes confident
+    (tests/test_gpu_dataset.py needs decision margins well above the bf16 score error).  Default: Zipf popularity, no structure."""
     u, i, n = STATS[dataset]
     n_users, n_items, n_inter = n_users or u, n_items or i, n_inter or n
     rng = np.random.default_rng(seed)
+    if signal == "chain":
+        succ = rng.permutation(n_items)                       # one cycle-ish successor map
+        nxt = np.empty(n_items, dtype=np.int64)
+        nxt[succ] = np.roll(succ, -1)
+        k = max(6, min(n_items // 3, int(round(n_inter / n_users))))
+        lines = []
+        for uid in range(n_users):
+            cur, seq, seen = int(rng.integers(n_items)), [], set()
+            while len(seq) < k:
+                if cur in seen or rng.random() < 1.0 / 12.0:
+                    cand = [x for x in rng.permutation(n_items)[:8] if int(x) not in seen]
+                    if not cand:
+                        break
+                    cur = int(cand[0])
+                seq.append(cur)
+                seen.add(cur)
+                cur = int(nxt[cur])
+            lines.append(f"U{uid} " + " ".join(f"I{it}" for it in seq))
+        return lines
     lens = 5 + rng.lognormal(mean=np.log(max(2.0, n_inter / n_users - 5)) - 0.5, sigma=1.0, size=n_users)
     lens = np.clip(np.round(lens * (n_inter / lens.sum())), 5, n_items).astype(int)
     pop = 1.0 / np.arange(1, n_items + 1) ** 1.0

@@ -345,7 +345,7 @@ def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6):
     assert torch.equal(oa, ob), float((oa - ob).abs().max())
 
 
-def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
+def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"attn_fused"):
     """bf16 attention backward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_bwd_fused_kernel) against the
     two-kernel path on identical inputs (same forward output, lse and counter-based masks).  Both round P and dS to bf16 at the
     same point, so they differ only by the order of fp32 accumulation."""
@@ -371,7 +371,7 @@ def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
                                    3 * inner, 3 * inner, inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_fwd")
     res = []
     for fused in (1, 0):
-        be.check(be.lib.p5_set_option(b"attn_fused", fused), "set_option")
+        be.check(be.lib.p5_set_option(option, fused), "set_option")
         dqkv = dev(be, torch.zeros(B * L, 3 * inner, dtype=tt))
         dtab = dev(be, torch.zeros(32, H))
         dscr = dev(be, torch.zeros(B * ((L + 63) // 64), 32 * H))
@@ -381,7 +381,7 @@ def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5):
                                        3 * inner, 3 * inner, 3 * inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_bwd")
         sync(be)
         res.append((dqkv.cpu().float(), dtab.cpu().clone()))
-    be.check(be.lib.p5_set_option(b"attn_fused", 1), "set_option")
+    be.check(be.lib.p5_set_option(option, 1), "set_option")
     (ga, ta), (gb, tb) = res
     assert gb.abs().max() > 0.05
     e_g = (ga - gb).abs().max().item() / gb.abs().max().item()

@@ -122,7 +122,7 @@ def test_rmsnorm(emu, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 20, 20), ("enc", 70, 70), ("dec", 6, 6), ("dec", 18, 18), ("cross", 7, 33), ("cross", 17, 70)])
+@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 20, 20), ("enc", 70, 70), ("dec", 6, 6), ("dec", 18, 18), ("cross", 7, 33), ("cross", 17, 70), ("cross", 16, 140), ("dec", 16, 16)])
 def test_attention(emu, dtype, mode, Lq, Lk):
     cases.attn_case(emu, dtype, 2, 2, Lq, Lk, mode)
 
@@ -142,6 +142,13 @@ def test_attention_bf16_full_block(emu, L):
 def test_attention_forward_whole_head_matches_blocked(emu, mode, Lq, Lk):
     """bf16, dropout on: one workgroup per (batch, head) == the 64-query-block kernel, bit for bit"""
     cases.attn_fwd_wg_case(emu, 3, 2, Lq, Lk, mode)
+
+
+@pytest.mark.parametrize("mode,L", [("dec", 8), ("dec", 16), ("enc", 12), ("dec", 5)])
+def test_attention_short_block_backward_matches_split(emu, mode, L):
+    """bf16, dropout on: the one-launch backward for Lq <= 16 (p5_attn_bwd_small_kernel: the four waves split the keys) against the
+    dQ + dK/dV kernel pair on the same inputs and masks"""
+    cases.attn_fused_bwd_case(emu, 3, 2, L, mode, option=b"attn_small")
 
 
 @pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 50), ("dec", 24)])

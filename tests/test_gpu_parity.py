@@ -59,7 +59,7 @@ def test_rmsnorm(hip, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("mode,Lq,Lk", [("enc", 20, 20), ("enc", 70, 70), ("enc", 128, 128), ("enc", 200, 200), ("enc", 512, 512),
-                                        ("dec", 6, 6), ("dec", 18, 18), ("cross", 7, 33), ("cross", 9, 130), ("cross", 17, 300)])
+                                        ("dec", 6, 6), ("dec", 18, 18), ("cross", 7, 33), ("cross", 9, 130), ("cross", 17, 300), ("cross", 8, 128), ("cross", 16, 500), ("dec", 16, 16)])
 def test_attention(hip, dtype, mode, Lq, Lk):
     cases.attn_case(hip, dtype, 2, 3, Lq, Lk, mode)
 
@@ -78,7 +78,14 @@ def test_attention_forward_whole_head_matches_blocked(hip, mode, Lq, Lk):
     cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode)
 
 
-@pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 120), ("enc", 50), ("dec", 24)])
+@pytest.mark.parametrize("mode,L", [("dec", 8), ("dec", 16), ("enc", 12), ("dec", 5)])
+def test_attention_short_block_backward_matches_split(hip, mode, L):
+    """bf16, dropout on: the one-launch backward for Lq <= 16 (p5_attn_bwd_small_kernel: the four waves split the keys) against the
+    dQ + dK/dV kernel pair on the same inputs and masks"""
+    cases.attn_fused_bwd_case(hip, 3, 2, L, mode, option=b"attn_small")
+
+
+@pytest.mark.parametrize("mode,L", [("enc", 128), ("enc", 50), ("dec", 24)])
 def test_attention_fused_backward_matches_split(hip, mode, L):
     """bf16, dropout on: the fused dQ/dK/dV kernel against the two-kernel backward on the same inputs and masks"""
     cases.attn_fused_bwd_case(hip, 4, 8, L, mode)

@@ -7,7 +7,7 @@ from openp5_amd.model import P5ModelConfig, P5T5Native
 from openp5_amd.trie import prefix_allowed_tokens_fn
 be = hip_backend()
 cfg = P5ModelConfig.from_backbone("t5-small", vocab_size=bench.V, dropout_rate=0.1)
-model = P5T5Native(cfg, dtype="bf16", backend=be, seed=2023); model.eval()
+model = P5T5Native(cfg, dtype=os.environ.get("P5_GEN_DTYPE", "bf16"), backend=be, seed=2023); model.eval()
 fn = prefix_allowed_tokens_fn(bench.synth_item_trie(3416, 7))
 gB = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ids, ww, mask, _, _ = bench.synth_batch(gB, 128, 8, be.device, 500)
