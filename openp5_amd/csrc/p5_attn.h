@@ -705,20 +705,26 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
 //   dV += P^T dO, dK += dS^T Q (its own 16 keys: stored per chunk), dQ += dS K (accumulated over all chunks, the four waves' partial
 //   sums added in wave order at the end).  Same element arithmetic as the other kernels (recomputed P from the saved log-sum-exp).
 // ------------------------------------------------------------------------------------------------------------
+#ifdef P5_EMU
+#define P5_ATTN_SMALL_OCC
+#else
+#define P5_ATTN_SMALL_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))      // two workgroups per CU (<= 256 registers, <= 80 KiB of LDS in bf16)
+#endif
 template <class T>
-__global__ __launch_bounds__(256) void p5_attn_bwd_small_kernel(P5AttnArgs a) {
+__global__ __launch_bounds__(256) P5_ATTN_SMALL_OCC void p5_attn_bwd_small_kernel(P5AttnArgs a) {
   using C = AttnC<T>;
   constexpr int KR = C::KCH;                 // reduction elements of one mma16 (32 bf16 / 16 f32) = rows of a K-strided fragment chunk
   constexpr int RS = 64 + 16;                // row stride (bytes) of the small A-operand images: KR elements + pad
-  __shared__ __attribute__((aligned(16))) char tileK[64 * C::TS];
-  __shared__ __attribute__((aligned(16))) char tileV[64 * C::TS];
-  __shared__ __attribute__((aligned(16))) char tileQ[32 * C::TS];       // rows >= Lq are zero
+    __shared__ __attribute__((aligned(16))) char tileKV[2 * 64 * C::TS];
+  char* const tileK = tileKV;
+  char* const tileV = tileKV + 64 * C::TS; __shared__ __attribute__((aligned(16))) char tileQ[32 * C::TS];       // rows >= Lq are zero
   __shared__ __attribute__((aligned(16))) char tileDO[32 * C::TS];
   __shared__ __attribute__((aligned(16))) char aP[4][16 * RS];          // per wave: P^T  [key][query]   (A operand of dV)
   __shared__ __attribute__((aligned(16))) char aS[4][16 * RS];          //           dS^T [key][query]   (A operand of dK)
   __shared__ __attribute__((aligned(16))) char bS[4][16 * RS];          //           dS   [query][key of the wave's KR-row chunk]  (A operand of dQ)
   __shared__ __attribute__((aligned(16))) char wscr[4][16 * C::TS];     // wave scratch of the row stores
-  __shared__ __attribute__((aligned(16))) float sdq[4][16][68];
+  static_assert(2 * 64 * C::TS >= 4 * 16 * 68 * 4, "the dQ partial sums reuse the K and V tiles");
+  float (*sdq)[16][68] = (float (*)[16][68])tileKV;                     // [4][16][68] fp32 partial dQ, after the last chunk
   __shared__ __attribute__((aligned(16))) float sbias[1024];
   __shared__ float sdb[4][528];
   __shared__ __attribute__((aligned(16))) float slse[16];
@@ -846,6 +852,7 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_small_kernel(P5AttnArgs a) {
     }
   }
   // ---- dQ: the four waves' partial sums (each over its keys of every chunk), added in wave order ----
+  __syncthreads();                 // (every wave is done with the K / V tiles: their storage now holds the partial sums)
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll

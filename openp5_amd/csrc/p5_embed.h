@@ -82,14 +82,17 @@ __device__ static __forceinline__ int emb_lower_bound(const unsigned long long* 
   return lo;
 }
 
-// grid (ceil(max n / 256), nsets), 256 threads: one row each; the sorted chunks pass through LDS 16 at a time (32 KiB)
+// grid (ceil(max n / 64), nsets), 256 threads: lane = one of 64 rows, wave w searches the chunks c = w (mod 4) of every LDS batch
+// (16 sorted chunks = 32 KiB at a time); the four waves' counts are added through LDS
 __global__ __launch_bounds__(256) void p5_embed_rank_kernel(P5EmbArgs a) {
   constexpr int CPB = 16;                 // chunks per LDS batch
   __shared__ unsigned long long sc[CPB * P5_EMB_CHUNK];
+  __shared__ int scnt[3][4][64];
   const P5EmbSet& s = a.s[blockIdx.y];
   const int n = s.n0 + s.n1;
-  if (blockIdx.x * 256 >= n) return;
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 64 >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
   const int k = r < n ? emb_key(s, r) : 0;
   const unsigned long long me = (((unsigned long long)(unsigned)k) << 32) | (unsigned)r;
   const unsigned long long klo = ((unsigned long long)(unsigned)k) << 32, khi = ((unsigned long long)(unsigned)k + 1ull) << 32;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void p5_embed_rank_kernel(P5EmbArgs a) {
     __syncthreads();
     for (int i = threadIdx.x; i < nc * P5_EMB_CHUNK; i += 256) sc[i] = s.csort[(size_t)c0 * P5_EMB_CHUNK + i];
     __syncthreads();
-    for (int c = 0; c < nc; ++c) {
+    for (int c = wave; c < nc; c += 4) {
       const unsigned long long* v = sc + c * P5_EMB_CHUNK;
       const int lo = emb_lower_bound(v, P5_EMB_CHUNK, klo);      // (padding values ~0 are above every real value)
       start += lo;
@@ -110,7 +113,14 @@ __global__ __launch_bounds__(256) void p5_embed_rank_kernel(P5EmbArgs a) {
       pos += lo + emb_lower_bound(v + lo, hi - lo, me);
     }
   }
-  if (r < n) { s.perm[pos] = r; s.skey[pos] = k; s.sstart[pos] = start; s.slen[pos] = end - start; }
+  scnt[0][wave][lane] = pos; scnt[1][wave][lane] = start; scnt[2][wave][lane] = end;
+  __syncthreads();
+  if (wave == 0 && r < n) {
+    pos = scnt[0][0][lane] + scnt[0][1][lane] + scnt[0][2][lane] + scnt[0][3][lane];
+    start = scnt[1][0][lane] + scnt[1][1][lane] + scnt[1][2][lane] + scnt[1][3][lane];
+    end = scnt[2][0][lane] + scnt[2][1][lane] + scnt[2][2][lane] + scnt[2][3][lane];
+    s.perm[pos] = r; s.skey[pos] = k; s.sstart[pos] = start; s.slen[pos] = end - start;
+  }
 }
 
 // value of lookup row `r`, columns c..c+1 (dropout of the forward re-applied)

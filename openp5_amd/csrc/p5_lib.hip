@@ -476,6 +476,12 @@ static int wgrad_flush(P5Engine* e, hipStream_t main, bool is_head, bool on_side
   e->wg_sets = 0;
   return 0;
 }
+// ONE predicate for "every weight gradient of this step's backward takes the deferred, layer-grouped path" (token counts that are
+// multiples of 64; the other conditions of linear_wgrad -- leading dimensions, 16-byte alignment -- hold by construction of the layout):
+// the folded-norm forward, the storing backward and linear_wgrad itself all depend on it and must not drift apart.
+template <class T> static bool wg_all_deferred(const P5Engine* e) {
+  return sizeof(T) == 2 && g_opt_wgrad_group != 0 && (e->M % 64) == 0 && (e->Md % 64) == 0;
+}
 template <class T>
 static int linear_wgrad(P5Engine* e, hipStream_t main, const void* dy, int lddy, const void* x, int ldx, float* dW, int M, int N_out, int K_in,
                         float alpha = 1.f) {
@@ -489,7 +495,9 @@ static int linear_wgrad(P5Engine* e, hipStream_t main, const void* dy, int lddy,
     if (e->sub >= 0) e->wg_sets |= 1u << (e->sub % P5_NSETS);
     return 0;
   }
-  // (split-K atomics: on a storing backward the target has not been cleared)
+  // an immediate weight gradient: under the folded-norm forward it would read the normalised rows before the norm backward has written
+  // them, under a storing backward its target has not been cleared -- both modes require wg_all_deferred, which this problem contradicts
+  P5_REQUIRE(!(e->Md > 0 && wg_all_deferred<T>(e)), "linear_wgrad: a weight gradient fell off the grouped path although wg_all_deferred holds (leading dimension / alignment)");
   if (e->wg_epi == P5_EPI_STORE) hipMemsetAsync(dW, 0, (size_t)N_out * K_in * 4, wgrad_stream(e, main));
   return linear_wgrad_on<T>(wgrad_stream(e, main), dy, lddy, x, ldx, dW, M, N_out, K_in, alpha);
 }
@@ -667,8 +675,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
 static int g_opt_norm_fuse = getenv("P5_NORM_FUSE") ? atoi(getenv("P5_NORM_FUSE")) : 1;
 // (the weight gradients must be the deferred, layer-grouped ones: they run after the sub-layer's norm backward has written n)
 template <class T> static bool norm_fused(const P5Engine* e) {
-  return sizeof(T) == 2 && e->Sf != nullptr && g_opt_norm_fuse != 0 &&
-         (e->Md == 0 || (g_opt_wgrad_group != 0 && (e->M % 64) == 0 && (e->Md % 64) == 0));
+  return sizeof(T) == 2 && e->Sf != nullptr && g_opt_norm_fuse != 0 && (e->Md == 0 || wg_all_deferred<T>(e));
 }
 template <class T> static const T* Wnf(const P5Engine* e, int64_t off) { return (const T*)((const bf16*)e->Sf + off); }
 
@@ -900,7 +907,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
   if (stage == 0) {
     if (e->grads_keep) {
       e->wg_epi = P5_EPI_ACCUM;                 // a later micro-batch of an accumulation group: everything adds
-    } else if (sizeof(T) == 2 && g_opt_grad_store_first && g_opt_wgrad_group && (M % 64) == 0 && (Md % 64) == 0) {
+    } else if (g_opt_grad_store_first && wg_all_deferred<T>(e)) {
       // (token counts that are multiples of 64 -- every batch of 64 sequences -- put ALL weight gradients on the grouped, storing
       //  path; ragged counts keep the clear-then-add form below: their split-K atomics need a cleared target anyway)
       if (!e->grads_zeroed) P5_TRY(zero_small_grads(e, s));
@@ -1085,7 +1092,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
       }
       P5_LAUNCH(p5_embed_sortchunk_kernel, dim3((n[0] + P5_EMB_CHUNK - 1) / P5_EMB_CHUNK, 2), dim3(256), 0, s, ea);
       P5_TRY(P5_KCHECK());
-      P5_LAUNCH(p5_embed_rank_kernel, dim3((n[0] + 255) / 256, 2), dim3(256), 0, s, ea);
+      P5_LAUNCH(p5_embed_rank_kernel, dim3((n[0] + 63) / 64, 2), dim3(256), 0, s, ea);
       P5_TRY(P5_KCHECK());
       const int nblk = (n[0] + P5_EMB_SEG - 1) / P5_EMB_SEG;
       P5_LAUNCH(p5_embed_seg_kernel, dim3(nblk, 2), dim3(256), 0, s, ea);

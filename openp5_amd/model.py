@@ -157,6 +157,7 @@ class P5T5Native(nn.Module):
         self._fold = None
         self._fold_dirty = True
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
+        self._grads_dead = False    # zero_grad(set_to_none=True) was called and no backward has run since: `.grad` holds stale values
         self._tr_dirty = True
         self._build(seed)
 
@@ -416,6 +417,7 @@ class P5T5Native(nn.Module):
         backward, where torch would show None.  set_to_none=False: the arena is cleared now."""
         if set_to_none:
             self._be.check(self._lib.p5_engine_discard_grads(self._engine), "discard_grads")
+            self._grads_dead = True         # (FusedAdamW.step refuses to apply them again before a backward has rewritten them)
         else:
             self._be.check(self._lib.p5_engine_clear_grads(self._engine, self._be.stream_ptr()), "clear_grads")
 
@@ -522,6 +524,7 @@ class P5T5Native(nn.Module):
                 self.ddp_wait_ms.append((ev0, ev1))     # (read by bench.py after a synchronize: main-stream time between the end of the backward and the last bucket)
         else:
             self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
+        self._grads_dead = False
         for name, p in self.named_parameters():
             if p.grad is None:
                 off, n, shape = self._views[name]

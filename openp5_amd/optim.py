@@ -42,6 +42,10 @@ class FusedAdamW:
         """`grad_accum`: the arena holds the SUM over that many micro-batches (and, after the all-reduce, over ranks); the
         mean is taken by the update kernel's gradient scale."""
         mdl = self.model
+        if getattr(mdl, "_grads_dead", False):
+            # zero_grad() only marks the gradient arena dead (model.zero_grad docstring); torch would hold p.grad = None here and skip
+            # every parameter -- re-applying the previous step's gradients instead would be a silent error
+            raise RuntimeError("FusedAdamW.step(): the gradients were discarded by zero_grad() and no backward has run since")
         be, lib = mdl._be, mdl._lib
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         sp = be.stream_ptr()

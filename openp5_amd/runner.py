@@ -248,10 +248,9 @@ class DistributedRunner:
         rng = [int(x) for x in getattr(self.model, "_rng_cpu", [0, 0])]
         rng_ranks = [rng]
         if self.world > 1:
-            t = torch.tensor(rng, dtype=torch.int64, device=self.device)
-            parts = [torch.zeros_like(t) for _ in range(self.world)]
-            dist.all_gather(parts, t)
-            rng_ranks = [[int(v) for v in p.tolist()] for p in parts]
+            parts = [None] * self.world          # (through the object channel: no device-tensor collective, works on every backend)
+            dist.all_gather_object(parts, rng)
+            rng_ranks = [[int(v) for v in p] for p in parts]
         if self.rank != 0:
             return
         ck = {"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},

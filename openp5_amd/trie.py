@@ -115,7 +115,8 @@ class CompiledTrie:
                 if total == 0:
                     break
                 starts = np.repeat(lo - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt)
-                frontier = self.child_node[starts + np.arange(total, dtype=np.int64)].astype(np.int64)
+                # (unique: a grafted trie is a DAG whose sub-trie is shared by every graft point -- the frontier must count nodes, not paths)
+                frontier = np.unique(self.child_node[starts + np.arange(total, dtype=np.int64)].astype(np.int64))
                 depth += 1
                 assert depth <= self.n_nodes, "CompiledTrie: the child table has a cycle"
             self._max_depth = depth

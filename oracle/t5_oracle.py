@@ -370,6 +370,23 @@ def p5_forward_nll(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_wo
     return nll
 
 
+def sequence_scores(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_ids: Tensor, attention_mask: Tensor,
+                    sequences: Tensor) -> Tensor:
+    """Teacher-forced score of GIVEN hypotheses, the quantity HF's beam search ranks by (generation/utils.py:3182 with
+    length_penalty 1.0; DistributedRunner.py:361-374 reads it as `sequences_scores`): sum over the generated tokens -- up to and
+    including </s> -- of log_softmax(full-vocabulary logits)[token], divided by their number.  `sequences` [B, K, T] start with the
+    decoder start token (pad) and are pad-filled after </s>.  Used by the dataset-level gate to check every score a lower-precision
+    search returns against this oracle's arithmetic on the SAME sequence, whatever the searches decided on the way."""
+    B, K, T = sequences.shape
+    labels = sequences[:, :, 1:].reshape(B * K, T - 1)
+    rep = lambda t: t.repeat_interleave(K, dim=0)      # noqa: E731
+    nll = p5_forward_nll(P, cfg, rep(input_ids), rep(whole_word_ids), rep(attention_mask), labels).view(B * K, T - 1)
+    is_eos = labels == cfg.eos_id
+    n = torch.where(is_eos.any(dim=1), is_eos.float().argmax(dim=1) + 1, torch.full((B * K,), T - 1))
+    keep = torch.arange(T - 1)[None, :] < n[:, None]
+    return (-(nll * keep).sum(dim=1) / n.clamp(min=1)).view(B, K)
+
+
 def runner_loss(nll: Tensor, output_attention: Tensor) -> Tensor:
     """DistributedRunner.py:72-77."""
     B, T = output_attention.shape

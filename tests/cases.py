@@ -734,6 +734,44 @@ def collect_rankings(runner, gen_fn, K, max_length=50):
     return out
 
 
+def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol, oracle_rankings=None):
+    """Every hypothesis a search returned, scored by the ORACLE on the same token sequence (O.sequence_scores): per user
+    (a) max |returned score - oracle score of that sequence|, (b) the largest inversion of the returned order under the oracle's
+    scores, (c) how far the oracle's own list holds an item the search missed above the search's K-th item (oracle scores).  Unlike
+    the margin-based robustness classes this check applies to EVERY user: it does not ask the two searches to have decided alike,
+    only that what the search returns is correctly scored and ordered."""
+    out = {"users": 0, "max_score_err": 0.0, "max_inversion": 0.0, "score_viol": 0, "order_viol": 0, "missed": []}
+    li = 0
+    for loader, users in zip(runner.testloaders, rankings):
+        ui = 0
+        for batch in loader:
+            B = batch[0].shape[0]
+            chunk = users[ui:ui + B]
+            T = 1 + max(len(it) for _, ranked, _ in chunk for it in ranked)
+            seqs = torch.zeros(B, K, T + 1, dtype=torch.long)
+            for b, (_, ranked, _) in enumerate(chunk):
+                for j, it in enumerate(ranked):
+                    seqs[b, j, 1:1 + len(it)] = torch.tensor(it)
+            with torch.no_grad():
+                ref = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1], seqs)
+            for b, (_, ranked, sc) in enumerate(chunk):
+                err = max(abs(float(ref[b, j]) - sc[j]) for j in range(K))
+                inv = max([float(ref[b, j + 1] - ref[b, j]) for j in range(K - 1)] + [0.0])
+                out["users"] += 1
+                out["max_score_err"] = max(out["max_score_err"], err)
+                out["max_inversion"] = max(out["max_inversion"], inv)
+                out["score_viol"] += int(err > score_tol)
+                out["order_viol"] += int(inv > order_tol)
+                if oracle_rankings is not None:
+                    _, ro, so = oracle_rankings[li][ui + b]
+                    kth = float(ref[b].min())
+                    miss = max([so[i] - kth for i, it in enumerate(ro) if it not in ranked] + [0.0])
+                    out["missed"].append(miss)
+            ui += B
+        li += 1
+    return out
+
+
 def rankings_metrics(rankings, metrics=("hit@5", "hit@10", "ndcg@5", "ndcg@10")):
     from openp5_amd import evaluate
     res = []

@@ -200,6 +200,13 @@ def test_model_edge_shapes(hip, B, L, T):
     cases.model_train_case(hip, O.T5Cfg.named("tiny"), B, L, T, "fp32", 0.0, nll_tol=5e-5, grad_tol=5e-4)
 
 
+def test_generate_ids_longer_than_64_tokens(hip):
+    """max_length 65 .. P5_MAX_LEN = 128 on the device: the decode step's self-attention takes the 16-pass build, the beam bookkeeping holds
+    128 positions per hypothesis (OpenP5 itself decodes <= 50 tokens, DistributedRunner.py:361-371); token-exact against the oracle."""
+    cases.generate_case(hip, O.T5Cfg.named("tiny"), 2, 12, 3, 100, 12, id_len=(66, 80), seed=3)
+    cases.generate_case(hip, O.T5Cfg.named("tiny"), 2, 12, 4, 128, 10, id_len=(100, 120), seed=4)
+
+
 def test_generate_truncated_by_max_length(hip):
     cases.generate_case(hip, O.T5Cfg.named("tiny"), 2, 9, 4, 5, 30, seed=13)
 

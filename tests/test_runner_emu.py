@@ -537,3 +537,23 @@ def test_data_parallel_bf16_buckets(emu, tmp_path):
         gs.append(m._grads.clone())
     want = gs[0].to(torch.bfloat16).float() + gs[1].to(torch.bfloat16).float()
     assert torch.allclose(r0["grads"], want, atol=1e-6, rtol=2 ** -7)
+
+
+def test_teacher_forced_check_on_engine_rankings(emu, tmp_path):
+    """the dataset gate's universal check (tests/test_gpu_dataset.py) on the host emulation: every hypothesis the fp32 engine returns for
+    a toy pipeline carries the score the oracle assigns to that very sequence, in the oracle's order."""
+    from oracle import t5_oracle as O
+    from tests import cases
+    from openp5_amd.model import P5ModelConfig
+    cfg = P5ModelConfig(d_model=64, d_ff=128, num_layers=1, num_decoder_layers=1, num_heads=1, dropout_rate=0.0)
+    runner, model, tok, args = cases.make_pipeline(emu, str(tmp_path), "fp32", dataset="Toy", n_users=12, n_items=24, n_inter=90,
+                                                   flags=["--epochs", "1", "--eval_batch_size", "6"], dropout=0.0, model_cfg=cfg, vocab=VOCAB)
+    model.eval()
+    K = 4
+    r = cases.collect_rankings(runner, cases.engine_gen_fn(model), K)
+    sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    ocfg = O.T5Cfg(vocab_size=model.config.vocab_size, d_model=64, d_ff=128, num_heads=1, num_layers=1, num_decoder_layers=1, dropout=0.0)
+    params = {k: sd[k] for k in O.param_shapes(ocfg)}
+    r_or = cases.collect_rankings(runner, cases.oracle_gen_fn(params, ocfg), K)
+    tf = cases.teacher_forced_check(runner, params, ocfg, r, K, 1e-4, 1e-4, r_or)
+    assert tf["users"] == sum(len(u) for u in r) > 0 and tf["score_viol"] == 0 and tf["order_viol"] == 0 and max(tf["missed"]) <= 1e-4, tf
