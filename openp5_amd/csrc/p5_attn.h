@@ -153,7 +153,7 @@ __device__ static __forceinline__ void stage_bias_mask(const P5AttnArgs& a, int 
 // table with a plain read-modify-write: slot `slot` is touched by exactly one workgroup per launch, and the launches of a backward
 // (one per layer) are ordered by the stream.  p5_reduce_copies_kernel sums the slots in index order.  No fp32 atomics anywhere:
 // rounds 1-3 used LDS and global float atomics here, whose arrival order changed the last bits of the table's gradient from run to run.
-// `scratch`: >= 128 ints + nrel bytes of LDS that are dead by now.  Called by the NT threads of a workgroup (NT > 64: contains
+// `scratch`: LDS that is dead by now -- 128 ints + nrel bytes (one wave) / 4 KiB (a whole workgroup: + NT / 64 partial sums per bucket).  Called by the NT threads of a workgroup (NT > 64: contains
 // workgroup barriers) or by ONE wave (NT == 64: wave-level ordering only, the other waves of the workgroup carry on).
 template <int NT>
 __device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, int h, int slot, const float* sv, void* scratch, int tid) {
@@ -171,13 +171,37 @@ __device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, 
     atomicMax(&shi[bk], i);
   }
   P5_RB_SYNC();
-#undef P5_RB_SYNC
-  if (tid < 64 && shi[tid] >= 0) {
+  if constexpr (NT == 64) {
+    if (shi[tid] >= 0) {
+      float acc = 0.f;
+      for (int i = slo[tid]; i <= shi[tid]; ++i) acc += (sid[i] == tid) ? sv[i] : 0.f;
+      float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
+      *dst += acc;
+    }
+  } else {
+    // NT / 64 threads per bucket: each adds a contiguous part of the bucket's interval in order, the parts are added in order
+    // (at L = 512 the outermost bucket holds ~400 relative positions: one thread walking them alone took ~17 us per workgroup)
+    static_assert(NT % 64 == 0 && NT / 64 <= 4, "rel_bias_grad_flush: at most four threads per bucket");
+    constexpr int NP = NT / 64;
+    float* spart = (float*)scratch + 512;          // [NP][64] behind the interval bounds and the nrel <= 1023 bucket ids (scratch: >= 4 KiB)
+    const int bk = tid & 63, part = tid >> 6;
     float acc = 0.f;
-    for (int i = slo[tid]; i <= shi[tid]; ++i) acc += (sid[i] == tid) ? sv[i] : 0.f;
-    float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
-    *dst += acc;
+    if (shi[bk] >= 0) {
+      const int lo = slo[bk], len = shi[bk] - lo + 1, per = (len + NP - 1) / NP;
+      const int i0 = lo + part * per, i1 = i0 + per < lo + len ? i0 + per : lo + len;
+      for (int i = i0; i < i1; ++i) acc += (sid[i] == bk) ? sv[i] : 0.f;
+    }
+    spart[part * 64 + bk] = acc;
+    __syncthreads();
+    if (tid < 64 && shi[tid] >= 0) {
+      float t = spart[tid];
+#pragma unroll
+      for (int q = 1; q < NP; ++q) t += spart[q * 64 + tid];
+      float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
+      *dst += t;
+    }
   }
+#undef P5_RB_SYNC
 }
 
 // ------------------------------------------------------------------------------------------------------------

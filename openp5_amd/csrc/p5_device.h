@@ -94,10 +94,11 @@ template <> struct TT<bf16> { static constexpr int EPF = 8; static constexpr int
 #include <vector>
 #include <string>
 struct P5Prof {
-  struct Rec { const char* name; const char* tag; unsigned gx, gy, gz, bx; double flops; hipEvent_t a, b; };
+  struct Rec { const char* name; const char* tag; unsigned gx, gy, gz, bx; int m, n, k; double flops; hipEvent_t a, b; };
   int on = 0;
   double pending_flops = 0.0;       // set by a launcher right before its P5_LAUNCH (algorithmic FLOPs of that launch)
   const char* pending_tag = "";     // ... and what the template parameters of the stringified kernel name stand for
+  int pm = 0, pn = 0, pk = 0;       // ... and the problem shape of a single-problem GEMM launch (0 = not given)
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -106,8 +107,8 @@ struct P5Prof {
     return pool[used++];
   }
   void begin(const char* name, dim3 g, dim3 b, hipStream_t s) {
-    Rec r{name, pending_tag, g.x, g.y, g.z, b.x, pending_flops, get(), get()};
-    pending_flops = 0.0; pending_tag = "";
+    Rec r{name, pending_tag, g.x, g.y, g.z, b.x, pm, pn, pk, pending_flops, get(), get()};
+    pending_flops = 0.0; pending_tag = ""; pm = pn = pk = 0;
     hipEventRecord(r.a, s);
     recs.push_back(r);
   }
@@ -118,7 +119,7 @@ inline P5Prof& p5_prof() { static P5Prof p; return p; }      // (one instance fo
   do {                                                                                     \
     P5Prof& _pf = p5_prof();                                                               \
     if (_pf.on) _pf.begin(#kern, dim3(grid), dim3(block), (stream));                       \
-    else { _pf.pending_flops = 0.0; _pf.pending_tag = ""; }                                \
+    else { _pf.pending_flops = 0.0; _pf.pending_tag = ""; _pf.pm = _pf.pn = _pf.pk = 0; } \
     hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__);             \
     if (_pf.on) _pf.end((stream));                                                         \
   } while (0)

@@ -18,6 +18,8 @@ int g_opt_gemm_ring_wgs = getenv("P5_GEMM_RING_WGS") ? atoi(getenv("P5_GEMM_RING
 int g_opt_gemm_ksdma = getenv("P5_GEMM_KSDMA") ? atoi(getenv("P5_GEMM_KSDMA")) : 1;   // direct-to-LDS copies of K-strided operands
 int g_opt_gemm_wide = getenv("P5_GEMM_WIDE") ? atoi(getenv("P5_GEMM_WIDE")) : 1;         // 256x128 persistent ring for wide outputs
 int g_opt_gemm_wide_min_tiles = getenv("P5_GEMM_WIDE_MIN_TILES") ? atoi(getenv("P5_GEMM_WIDE_MIN_TILES")) : 160;
+int g_opt_gemm_ring128_min_k = getenv("P5_GEMM_RING128_MIN_K") ? atoi(getenv("P5_GEMM_RING128_MIN_K")) : 1024;       // ... from this reduction length on
+int g_opt_gemm_ring128_min_tiles = getenv("P5_GEMM_RING128_MIN_TILES") ? atoi(getenv("P5_GEMM_RING128_MIN_TILES")) : 128;   // ... and this many 128x128 tiles
 int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RING_N512")) : 1;   // ring kernel for N = d_model, K >= 1024
 int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
@@ -27,6 +29,7 @@ template <class T, int BM, int BN>
 static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.splitk), block(256);
   P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
+  P5_PROF_SHAPE(g.M, g.N, g.K);
   P5_PROF_TAG(sizeof(T) == 2 ? (BM == 256 ? "bf16 256x256" : BM == 128 ? (g.a_ks ? "bf16 128x128 KS" : "bf16 128x128 KC") : (g.a_ks ? "bf16 64x64 KS" : (g.b_ks ? "bf16 64x64 KC/KS" : "bf16 64x64 KC")))
                              : (BM == 128 ? "f32 128x128" : "f32 64x64"));
   g.xcd_bm = g.xcd_bn = 0;
@@ -111,6 +114,7 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
     for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
     P5_PROF_FLOPS(fl);
     P5_PROF_TAG(KS ? (BM == 256 ? "256x128 KS" : "128x128 KS") : (BM == 256 ? "256x128 KC" : "128xN KC"));
+    if (grp.nprob == 1) P5_PROF_SHAPE(grp.p[0].M, grp.p[0].N, grp.p[0].K);
   }
   P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
   return P5_KCHECK();
@@ -139,6 +143,7 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
     for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
     P5_PROF_FLOPS(fl);
     P5_PROF_TAG(KS ? "KS: grouped weight gradients" : "KC: forward / data-gradient GEMMs");
+    if (grp.nprob == 1) P5_PROF_SHAPE(grp.p[0].M, grp.p[0].N, grp.p[0].K);
   }
   P5_LAUNCH((p5_gemm5_kernel<KS>), dim3(nwg), dim3(512), 0, s, grp);
   return P5_KCHECK();
@@ -190,7 +195,7 @@ static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
       return launch_gemm4(P5_G4_256x128, false, grp, s);
     }
     // narrow outputs (N = d_model) with a long reduction: one 128x128 tile per CU on the four-slot ring instead of 64x64 tiles
-    if (kc && g_opt_gemm_ring_n512 && t128 >= 128 && t128 <= 256 && g.K >= 1024 && g.epi != P5_EPI_ATOMIC) {
+    if (kc && g_opt_gemm_ring_n512 && t128 >= g_opt_gemm_ring128_min_tiles && t128 <= 256 && g.K >= g_opt_gemm_ring128_min_k && g.epi != P5_EPI_ATOMIC) {
       g.ring = 1;
       g.splitk = 1;
       return launch_gemm_tile<T, 128, 128>(g, s);
@@ -249,6 +254,7 @@ static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
       g.xcd_bm = g.xcd_bn = 0;
       g.splitk = 1;
       P5_PROF_FLOPS(2.0 * g.M * g.N * g.K);
+      P5_PROF_SHAPE(g.M, g.N, g.K);
       P5_LAUNCH((p5_gemm2_kernel<32, 64, 8, false, false>), grid, dim3(256), 0, s, g);
       return P5_KCHECK();
     }

@@ -19,6 +19,7 @@ static inline int fail(const std::string& m) { g_p5_err = m; return -1; }
 #define P5_KCHECK() 0
 #define P5_PROF_FLOPS(x) ((void)0)
 #define P5_PROF_TAG(x) ((void)0)
+#define P5_PROF_SHAPE(m, n, k) ((void)0)
 #else
 static inline int kcheck(const char* where) {
   hipError_t e = hipGetLastError();
@@ -28,6 +29,7 @@ static inline int kcheck(const char* where) {
 #define P5_KCHECK() kcheck(__func__)
 #define P5_PROF_FLOPS(x) (p5_prof().pending_flops = (x))
 #define P5_PROF_TAG(x) (p5_prof().pending_tag = (x))
+#define P5_PROF_SHAPE(m, n, k) (p5_prof().pm = (m), p5_prof().pn = (n), p5_prof().pk = (k))
 #endif
 
 // ---- tuning knobs defined in p5_gemm_tu.hip / p5_attn_tu.hip (p5_set_option / environment) ----
@@ -44,6 +46,8 @@ extern int g_opt_gemm_ksdma;
 extern int g_opt_gemm_wide;
 extern int g_opt_gemm_wide_min_tiles;
 extern int g_opt_gemm_ring_n512;
+extern int g_opt_gemm_ring128_min_k;
+extern int g_opt_gemm_ring128_min_tiles;
 extern int g_opt_g4_nst;
 extern int g_opt_g4_wgs;
 extern int g_opt_gemm_ws;

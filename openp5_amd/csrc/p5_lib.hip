@@ -1622,6 +1622,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
   else if (!strcmp(name, "gemm_wide_min_tiles")) g_opt_gemm_wide_min_tiles = value;
+  else if (!strcmp(name, "gemm_ring128_min_k")) g_opt_gemm_ring128_min_k = value;
+  else if (!strcmp(name, "gemm_ring128_min_tiles")) g_opt_gemm_ring128_min_tiles = value;
   else if (!strcmp(name, "wgrad_wide_min")) g_opt_wgrad_wide_min = value;
   else if (!strcmp(name, "grad_store_first")) g_opt_grad_store_first = value;
   else if (!strcmp(name, "embed_det")) g_opt_embed_det = value;
@@ -1652,7 +1654,9 @@ int p5_profile_end(char* report, int cap) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
     char k[512];
-    snprintf(k, sizeof(k), "%s%s%s%s grid=(%u,%u,%u) block=%u", r.name, r.tag[0] ? " [" : "", r.tag, r.tag[0] ? "]" : "", r.gx, r.gy, r.gz, r.bx);
+    char shp[64] = "";
+    if (r.m > 0) snprintf(shp, sizeof(shp), " %dx%dx%d", r.m, r.n, r.k);
+    snprintf(k, sizeof(k), "%s%s%s%s grid=(%u,%u,%u) block=%u%s", r.name, r.tag[0] ? " [" : "", r.tag, r.tag[0] ? "]" : "", r.gx, r.gy, r.gz, r.bx, shp);
     size_t i = 0;
     for (; i < agg.size(); ++i) if (agg[i].key == k) break;
     if (i == agg.size()) agg.push_back({k, 0, 0.0, 0.0});

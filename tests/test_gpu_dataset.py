@@ -70,14 +70,15 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
     #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
     assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
-    # Hard floors over ALL users.  They are counts of discrete outcomes on a barely-trained model whose own decision margins are
-    # small (see the quantiles printed below), so they move with the trained weights: three different (all valid) bf16 training
-    # trajectories of this test gave 187 / 200 / 201 / 202 identical lists, 235 / 238 / 239 identical gold ranks, 236-240 lists identical up to
-    # swaps of items the ORACLE scores within TIE_TOL of each other, and Hit@5 moved by one user (1/120) in one of them.  The
-    # floors sit below the lowest observation; what must hold EXACTLY is asserted per user further down (every user whose oracle
-    # margins exceed TIE_TOL), and the dataset metrics may differ by at most the fragile users that actually moved.
+    # Floors over ALL users on what a tie cannot explain: the ranked list up to swaps of items the ORACLE scores within TIE_TOL of each
+    # other, the top-10 SET, the gold item's rank.  (The raw count of bit-identical lists is printed, not gated: with the oracle's median
+    # gap between consecutive final scores at 0.006 and a bf16 score error of up to 0.008 it counts near-ties, not errors -- five training
+    # trajectories of this test gave 158 / 187 / 200 / 201 / 202 identical lists with 236-240 lists identical up to ties every time; what a
+    # returned list must satisfy for EVERY user is the teacher-forced check above.  Training is bit-reproducible since round 4, so the
+    # trajectory of a given build no longer changes from run to run.)
+    print(f"[dataset] bf16: {c16['identical_lists']}/{c16['users']} bit-identical lists, {c16['identical_up_to_ties']} identical up to oracle ties <= {TIE_TOL}")
     assert c16["identical_up_to_ties"] >= 0.95 * c16["users"], c16
-    assert c16["identical_lists"] >= 0.70 * c16["users"], c16
+    assert c16["same_topk_set"][10] >= 0.95 * c16["users"] and c16["same_topk_set"][5] >= 0.95 * c16["users"], c16
     assert c16["same_gold_rank"] >= 0.95 * c16["users"], c16
     for mb, mo in zip(m_bf16, m_or):
         assert abs(mb["hit@5"] - mo["hit@5"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)

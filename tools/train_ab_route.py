@@ -1,4 +1,4 @@
-"""A/Bs in one process (C2 step): routing of the N = d_model GEMMs, the one-launch attention backward for short query blocks."""
+"""A/Bs in one process (C2 step): routing knobs of the GEMM family, the one-launch attention backward for short query blocks."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -11,10 +11,13 @@ def run(name, **opts):
     for k, v in opts.items():
         assert be.lib.p5_set_option(k.encode(), int(v)) == 0, k
     dt, loss = bench.time_training(model, opt, batch, 20, 5, 1, dev)
-    print(f"{name:72s} {dt / 20 * 1e3:7.3f} ms/step", flush=True)
+    print(f"{name:76s} {dt / 20 * 1e3:7.3f} ms/step", flush=True)
+base = dict(gemm_wide_min_tiles=160, attn_small=1, embed_det=1, gemm_ring128_min_k=1024, gemm_ring128_min_tiles=128)
 for rep in range(3):
-    run("defaults", gemm_wide_min_tiles=160, attn_small=1, embed_det=1)
-    run("wide kernel from 128 tiles (N = 512 outputs on p5_gemm5<KC>)", gemm_wide_min_tiles=128)
-    run("wide kernel from 64 tiles", gemm_wide_min_tiles=64)
-    run("defaults, short-block attention backward as dQ + dK/dV launches", gemm_wide_min_tiles=160, attn_small=0)
-    run("defaults, embedding gradients by atomic scatter", attn_small=1, embed_det=0)
+    run("defaults", **base)
+    run("128x128 ring kernel for K >= 512 (o-projection 8192x512x512 and its dgrad)", **dict(base, gemm_ring128_min_k=512))
+    run("128x128 ring kernel for K >= 512, from 64 tiles", **dict(base, gemm_ring128_min_k=512, gemm_ring128_min_tiles=64))
+    if rep == 0:
+        run("wide kernel from 128 tiles (N = 512 outputs on p5_gemm5<KC>)", **dict(base, gemm_wide_min_tiles=128))
+        run("short-block attention backward as dQ + dK/dV launches", **dict(base, attn_small=0))
+        run("embedding gradients by atomic scatter", **dict(base, embed_det=0))
