@@ -196,7 +196,7 @@ int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void*
                    const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
                    int ldv, int ldo, int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream);
 /* d_rel_table [rel_buckets, H] (+=, may be NULL): the gradient of the relative-bias table is reduced WITHOUT fp32 atomics -- every
- * workgroup adds into its own slot of d_rel_scratch (caller-provided float[B * ceil(Lq / 64)][rel_buckets * H], cleared here) and the
+ * workgroup stores into its own slot of d_rel_scratch (caller-provided, room for float[B * ceil(Lq / 64)][rel_buckets * H]; the slots the launch uses are written in full, nothing is cleared) and the
  * slots are summed in index order, so the result is bit-reproducible. */
 int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                    float* Dvec, void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch,

@@ -35,7 +35,7 @@ struct P5AttnArgs {
   int B, H, Lq, Lk;
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int causal;
-  int rel_copies;        // d_rel_table holds this many partial copies (stride rel_stride floats) to spread atomics; 0/1 = one
+  int rel_copies;        // number of buckets of the relative-bias table: the workgroup STORES that many sums per head into its slot of d_rel_table
   int rel_stride;
   P5Drop drop;
 };
@@ -149,9 +149,10 @@ __device__ static __forceinline__ void stage_bias_mask(const P5AttnArgs& a, int 
 // d(relative-bias table), deterministic: `sv[i]` holds this workgroup's sum of dS over relative position i - (Lq - 1) (already in a
 // fixed association).  Positions -> buckets: thread t < 64 owns bucket t and adds the positions that map to it in increasing order
 // (it scans only [first, last] position of its bucket -- T5's bucket function is monotone on either side of 0, so that interval holds
-// nothing else; integer LDS min/max give the same interval on every run), then adds its sum to THIS workgroup's slot of the partial
-// table with a plain read-modify-write: slot `slot` is touched by exactly one workgroup per launch, and the launches of a backward
-// (one per layer) are ordered by the stream.  p5_reduce_copies_kernel sums the slots in index order.  No fp32 atomics anywhere:
+// nothing else; integer LDS min/max give the same interval on every run), then STORES its sum into THIS workgroup's slot of the partial
+// table (`rel_copies` buckets per head, zeros for buckets without positions): a slot belongs to exactly one workgroup of one launch --
+// the caller gives every layer's launch its own block of slots -- so nothing is read, cleared or added on the way, and the store is in
+// flight while the workgroup carries on.  The fixed-association reducer (p5_elem.h) sums the slots in index order.  No fp32 atomics:
 // rounds 1-3 used LDS and global float atomics here, whose arrival order changed the last bits of the table's gradient from run to run.
 // `scratch`: LDS that is dead by now -- 128 ints + nrel bytes (one wave) / 4 KiB (a whole workgroup: + NT / 64 partial sums per bucket).  Called by the NT threads of a workgroup (NT > 64: contains
 // workgroup barriers) or by ONE wave (NT == 64: wave-level ordering only, the other waves of the workgroup carry on).
@@ -172,11 +173,10 @@ __device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, 
   }
   P5_RB_SYNC();
   if constexpr (NT == 64) {
-    if (shi[tid] >= 0) {
+    if (tid < a.rel_copies) {          // (a bucket without positions stores 0: the slot is written in full, nobody clears it)
       float acc = 0.f;
       for (int i = slo[tid]; i <= shi[tid]; ++i) acc += (sid[i] == tid) ? sv[i] : 0.f;
-      float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
-      *dst += acc;
+      a.d_rel_table[(size_t)slot * a.rel_stride + tid * a.H + h] = acc;
     }
   } else {
     // NT / 64 threads per bucket: each adds a contiguous part of the bucket's interval in order, the parts are added in order
@@ -193,12 +193,11 @@ __device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, 
     }
     spart[part * 64 + bk] = acc;
     __syncthreads();
-    if (tid < 64 && shi[tid] >= 0) {
+    if (tid < a.rel_copies) {
       float t = spart[tid];
 #pragma unroll
       for (int q = 1; q < NP; ++q) t += spart[q * 64 + tid];
-      float* dst = a.d_rel_table + (size_t)slot * a.rel_stride + tid * a.H + h;
-      *dst += t;
+      a.d_rel_table[(size_t)slot * a.rel_stride + tid * a.H + h] = t;
     }
   }
 #undef P5_RB_SYNC

@@ -47,5 +47,12 @@ static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
 }
 
 
+// how many slots of the relative-bias partial table one backward launch writes (slot = b * (slots / B) + query block): the whole-head
+// kernels have one workgroup per (batch, head), the blocked dQ kernel one per 64 queries -- must mirror launch_attn_bwd_impl's choice
+int p5l_attn_bwd_slots(int bf16_mode, int B, int Lq, int Lk) {
+  if (g_opt_attn_small && Lq <= 16) return B;
+  if (bf16_mode && g_opt_attn_fused && Lq <= 128 && Lk <= 128 && Lq > 16 && Lk > 16) return B;
+  return B * ((Lq + 63) / 64);
+}
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_fwd_impl<bf16>(a, s) : launch_attn_fwd_impl<float>(a, s); }
 int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_bwd_impl<bf16>(a, s) : launch_attn_bwd_impl<float>(a, s); }

@@ -62,6 +62,7 @@ int p5l_gemm_f32(P5GemmArgs g, hipStream_t s);
 int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s);
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);
 int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);
+int p5l_attn_bwd_slots(int bf16_mode, int B, int Lq, int Lk);
 template <class T> static inline int launch_gemm(const P5GemmArgs& g, hipStream_t s) { return sizeof(T) == 2 ? p5l_gemm_bf16(g, s) : p5l_gemm_f32(g, s); }
 template <class T> static inline int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) { return p5l_attn_fwd(sizeof(T) == 2, a, s); }
 template <class T> static inline int launch_attn_bwd(const P5AttnArgs& a, hipStream_t s) { return p5l_attn_bwd(sizeof(T) == 2, a, s); }

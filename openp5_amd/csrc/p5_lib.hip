@@ -526,8 +526,8 @@ static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw,
   return P5_KCHECK();
 }
 
-// relative-bias gradient: one slot of [rel_buckets, H] partial sums per attention-backward workgroup (batch item x 64-query block),
-// written with plain read-modify-writes by that workgroup only and summed in slot order (p5_attn.h rel_bias_grad_flush)
+// relative-bias gradient: one slot of [rel_buckets, H] partial sums per attention-backward workgroup (layer x batch item x 64-query block),
+// stored by that workgroup only and summed in slot order (p5_attn.h rel_bias_grad_flush)
 static int rel_slots(int B, int Lq) { return B * ((Lq + 63) / 64); }
 static constexpr int P5_HEAD_SPLITS = 32;      // most K-splits of the tied head's input-gradient GEMM (slices of its partial-product buffer)
 
@@ -641,7 +641,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     }
     e->d_enc = (float*)b.take(M * d * 4);
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
-    e->rel_partial = (float*)b.take((size_t)(rel_slots(B, L) + rel_slots(B, T > 0 ? T : 1)) * c.rel_buckets * H * 4);
+    e->rel_partial = (float*)b.take(((size_t)c.n_enc_layers * rel_slots(B, L) + (size_t)c.n_dec_layers * rel_slots(B, T > 0 ? T : 1)) * c.rel_buckets * H * 4);
     e->dw_scratch = (float*)b.take((size_t)(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2) * 1024 * d * 4);
     {
       const size_t n0 = M + Md, n1 = M;
@@ -887,8 +887,12 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.dQ = e->dqkv; a.dK = (T*)e->dqkv + in; a.dV = (T*)e->dqkv + 2 * in; a.Dvec = e->Dvec;
   a.rel_table = e->P + (is_dec ? e->off_dec_rel : e->off_enc_rel);
   a.rel_stride = c.rel_buckets * H;
-  a.rel_copies = 0;
-  a.d_rel_table = e->rel_partial + (is_dec ? (size_t)rel_slots(e->B, e->L) * a.rel_stride : 0);      // encoder slots, then decoder slots
+  a.rel_copies = c.rel_buckets;
+  // every layer's launch stores into its own block of slots (encoder layers first, then decoder layers): nothing to clear, nothing to add to
+  // (blocks of exactly as many slots as the launch writes -- p5l_attn_bwd_slots -- so that a stack's blocks are contiguous rows for the reducer)
+  const int sl_enc = p5l_attn_bwd_slots(sizeof(T) == 2, e->B, e->L, e->L), sl_dec = p5l_attn_bwd_slots(sizeof(T) == 2, e->B, e->T, e->T);
+  a.d_rel_table = e->rel_partial + (is_dec ? ((size_t)c.n_enc_layers * rel_slots(e->B, e->L) + (size_t)li * sl_dec) * a.rel_stride
+                                           : (size_t)li * sl_enc * a.rel_stride);
   a.bucket_lut = is_dec ? e->lut_dec : e->lut_enc; a.lut_half = e->lut_half; a.kmask = is_dec ? nullptr : e->mask;
   a.B = e->B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.lddo = in;
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
@@ -918,7 +922,6 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     }
     e->grads_zeroed = false;
     e->grads_keep = false;
-    hipMemsetAsync(e->rel_partial, 0, (size_t)(rel_slots(e->B, e->L) + rel_slots(e->B, e->T)) * c.rel_buckets * H * 4, s);
     e->d_enc_started = false;
     e->sub = -1;
     e->norm_slot = 0;
@@ -1023,7 +1026,8 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
                              nullptr, 0, 1.f, 1));
     }
     P5_LAUNCH(p5_reduce_rows_kernel, dim3((c.rel_buckets * H + 15) / 16), dim3(256), 0, s, e->G + e->off_dec_rel,
-              (const float*)(e->rel_partial + (size_t)rel_slots(e->B, e->L) * c.rel_buckets * H), rel_slots(e->B, e->T), c.rel_buckets * H);
+              (const float*)(e->rel_partial + (size_t)c.n_enc_layers * rel_slots(e->B, e->L) * c.rel_buckets * H),
+              c.n_dec_layers * p5l_attn_bwd_slots(sizeof(T) == 2, e->B, e->T, e->T), c.rel_buckets * H);
     P5_TRY(P5_KCHECK());
 #ifndef P5_EMU
     // shared.weight's gradient: the tied head's weight gradient adds with plain read-modify-writes (side stream, stage 0); the
@@ -1073,7 +1077,7 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     if (e->side) { fork_to_side(e, s); s2 = e->side; }
 #endif
     P5_LAUNCH(p5_reduce_rows_kernel, dim3((c.rel_buckets * H + 15) / 16), dim3(256), 0, s2, e->G + e->off_enc_rel,
-              (const float*)e->rel_partial, rel_slots(e->B, e->L), c.rel_buckets * H);
+              (const float*)e->rel_partial, c.n_enc_layers * p5l_attn_bwd_slots(sizeof(T) == 2, e->B, e->L, e->L), c.rel_buckets * H);
     P5_TRY(P5_KCHECK());
     if (g_opt_embed_det) {
       // embedding gradients without atomics (p5_embed.h): tied table over (encoder ids ++ decoder ids), whole-word table over the encoder's
@@ -2091,16 +2095,16 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
   a.Q = Q; a.K = K; a.V = V; a.O = (void*)O; a.dO = dO; a.lse = (float*)lse; a.Dvec = Dvec; a.dQ = dQ; a.dK = dK; a.dV = dV;
   a.rel_table = rel_table; a.d_rel_table = nullptr; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
-  a.lddv = lddv; a.causal = causal; a.rel_copies = 0; a.rel_stride = rel_buckets * H; a.drop = op_drop(rng_state, site, drop_p);
+  a.lddv = lddv; a.causal = causal; a.rel_copies = rel_buckets; a.rel_stride = rel_buckets * H; a.drop = op_drop(rng_state, site, drop_p);
   hipStream_t s = (hipStream_t)stream;
   if (d_rel_table) {
     P5_REQUIRE(d_rel_scratch && rel_buckets >= 1 && rel_buckets <= 64, "attn_bwd: d_rel_table needs d_rel_scratch [B * ceil(Lq / 64)][rel_buckets * H] and rel_buckets <= 64");
-    hipMemsetAsync(d_rel_scratch, 0, (size_t)rel_slots(B, Lq) * rel_buckets * H * 4, s);
     a.d_rel_table = d_rel_scratch;
   }
   P5_TRY(dtype == 1 ? launch_attn_bwd<bf16>(a, s) : launch_attn_bwd<float>(a, s));
   if (d_rel_table) {
-    P5_LAUNCH(p5_reduce_rows_kernel, dim3((rel_buckets * H + 15) / 16), dim3(256), 0, s, d_rel_table, (const float*)d_rel_scratch, rel_slots(B, Lq), rel_buckets * H);
+    P5_LAUNCH(p5_reduce_rows_kernel, dim3((rel_buckets * H + 15) / 16), dim3(256), 0, s, d_rel_table, (const float*)d_rel_scratch,
+              p5l_attn_bwd_slots(dtype == 1, B, Lq, Lk), rel_buckets * H);
     P5_TRY(P5_KCHECK());
   }
   return 0;
