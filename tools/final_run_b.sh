@@ -6,6 +6,8 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 bash profiles/profile.sh final_train python bench.py --steps 10 --warmup 3 --no-cpu --no-gen --legs none
 bash profiles/profile.sh final_gen python tools/gen_bench.py 20 5
+# the fp32 (list-identical) generation mode with narrower column tiles of the norm-fused projections (two workgroups per CU)
+for nb in 0 16; do P5_GEN_DTYPE=fp32 P5_DEC_NB=$nb timeout 200 python tools/gen_bench.py 20 10 2>&1 | grep -v amdgpu | sed "s/^/fp32 generation, dec_nb=$nb  /"; done | tee gpurun_out/ab_gen_fp32_nb.txt
 if [ -d tools/r03_snapshot ]; then
   : > gpurun_out/ab_r03_r04.txt
   for rep in 1 2 3; do
