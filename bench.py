@@ -618,7 +618,9 @@ def main():
             line["gemm_family"] = {"tflops": sum(c["flops_per_step"] for c in gemm_cls) / max(1e-9, sum(c["us_per_step"] for c in gemm_cls)) / 1e6,
                                    "us_per_step": sum(c["us_per_step"] for c in gemm_cls), "launches_per_step": sum(c["launches_per_step"] for c in gemm_cls)}
             line["step_kernels"] = [{"kernel": c["kernel"], "launches_per_step": c["launches_per_step"], "us_per_step": round(c["us_per_step"], 2),
-                                     "tflops": (round(c["flops_per_step"] / max(c["us_per_step"], 1e-9) / 1e6, 1) if c["flops_per_step"] > 0 else None)} for c in cls]
+                                     "tflops": (round(c["flops_per_step"] / max(c["us_per_step"], 1e-9) / 1e6, 1) if c["flops_per_step"] > 0 else None),
+                                     "by_grid": ([{"grid": g["grid"], "launches_per_step": g["launches_per_step"], "avg_us": round(g["avg_us"], 2), "tflops": round(g["tflops"], 1)}
+                                                  for g in c["grids"]] if c["flops_per_step"] > 0 and len(c["grids"]) > 1 else None)} for c in cls]
             line["step_launches"] = sum(c["launches_per_step"] for c in cls)
         else:
             line["roofline"] = dict(bound="mfma", kernel=k_wg, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **wg_alone)

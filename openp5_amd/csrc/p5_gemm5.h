@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     int epi, N, ldc, ldaux, ssq_nt, rowss_nt;
     uint32_t thr, hseed;
     float dscale, alpha, invd, eps;
-    bool fast, do_drop;
+    bool fast, fast32, do_drop;
   };
   auto load_ctx = [&](const Unit& u) {
     const P5GemmArgs& g = grp.p[u.pi];
@@ -324,7 +324,11 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     } else {
       const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
       c.fast = inside && vec_ok && !g.c_f32 && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM && (g.ssq_out == nullptr || g.ssq_nt > 0);
+      // plain fp32 store of a whole tile (the tied head's logits: 66 MB per step): straight from the accumulators, two 16-byte stores
+      // per lane and row block -- the general path below re-reads the descriptor per element (87 us for the 512 x 32100 x 512 head GEMM)
+      c.fast32 = inside && g.c_f32 && g.epi == P5_EPI_STORE && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && g.ssq_out == nullptr && g.rowss == nullptr;
     }
+    if constexpr (KS) c.fast32 = false;
     return c;
   };
   auto epilogue = [&](const Unit& u, const EpiCtx& cx) {
@@ -346,6 +350,23 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     // fields where it uses them, and with the accumulators holding the scalar registers' spill space hipcc re-issues those kernarg
     // loads (s_load + lgkmcnt(0), ~100 ns each) in every row block -- measured 7-9 us per 256x128 tile, more than the tile's
     // MFMAs (tools/lab lab4, round 3).
+    if constexpr (!KS) {
+      if (cx.fast32) {
+        const float alpha = cx.alpha;
+        float* cp = (float*)cx.C + (size_t)(u.m0 + wm * WTM + (le & 15)) * cx.ldc + (u.n0 + wn * WTN + (le >> 4) * 8);
+        const size_t step = (size_t)16 * cx.ldc;
+        auto rows32 = [&](const f32x4(&a)[TN]) {
+#pragma unroll
+          for (int h = 0; h < TN / 2; ++h) {
+            *(f32x4*)(cp + h * 32) = (f32x4){a[2 * h][0] * alpha, a[2 * h][1] * alpha, a[2 * h][2] * alpha, a[2 * h][3] * alpha};
+            *(f32x4*)(cp + h * 32 + 4) = (f32x4){a[2 * h + 1][0] * alpha, a[2 * h + 1][1] * alpha, a[2 * h + 1][2] * alpha, a[2 * h + 1][3] * alpha};
+          }
+          cp += step;
+        };
+        rows32(acc[0]); rows32(acc[1]); rows32(acc[2]); rows32(acc[3]); rows32(acc[4]); rows32(acc[5]); rows32(acc[6]); rows32(acc[7]);
+        return;
+      }
+    }
     if (cx.fast) {
       if constexpr (!KS) {
         const int epi = cx.epi, N = cx.N, ldc = cx.ldc, ldaux = cx.ldaux;

@@ -75,7 +75,8 @@ def test_gemm_wave_specialised(emu, wgs):
     probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1), (40, 72, 192, 3, 0, 1), (264, 72, 640, 4, 1, 2),
              (72, 100, 128, 0, 1, 1), (136, 64, 256, 6, 1, 1)]
     cases.gemm_group_case(emu, 3, 0, probs, wgs=wgs, drop_p=0.1)
-    whole_tiles = [(512, 256, 128, 1, 0, 1), (256, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (512, 128, 128, 0, 0, 1), (300, 256, 64, 2, 0, 1)]
+    whole_tiles = [(512, 256, 128, 1, 0, 1), (256, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (512, 128, 128, 0, 0, 1), (300, 256, 64, 2, 0, 1),
+                   (512, 300, 128, 0, 1, 1)]        # (fp32 store: whole tiles straight from the accumulators -- the tied head's logits -- next to a ragged one)
     cases.gemm_group_case(emu, 3, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=1)      # (the descriptor-hoisted epilogue of whole tiles)
 
 
