@@ -737,10 +737,11 @@ def collect_rankings(runner, gen_fn, K, max_length=50):
 def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol, oracle_rankings=None):
     """Every hypothesis a search returned, scored by the ORACLE on the same token sequence (O.sequence_scores): per user
     (a) max |returned score - oracle score of that sequence|, (b) the largest inversion of the returned order under the oracle's
-    scores, (c) how far the oracle's own list holds an item the search missed above the search's K-th item (oracle scores).  Unlike
+    scores, (c) `missed` / `extra`: how far the oracle's own list holds an item the search missed above the search's K-th item, and how far an
+    item only the search returns falls below the oracle's K-th item (oracle scores) -- set differences at the list's boundary.  Unlike
     the margin-based robustness classes this check applies to EVERY user: it does not ask the two searches to have decided alike,
     only that what the search returns is correctly scored and ordered."""
-    out = {"users": 0, "max_score_err": 0.0, "max_inversion": 0.0, "score_viol": 0, "order_viol": 0, "missed": []}
+    out = {"users": 0, "max_score_err": 0.0, "max_inversion": 0.0, "score_viol": 0, "order_viol": 0, "missed": [], "extra": []}
     li = 0
     for loader, users in zip(runner.testloaders, rankings):
         ui = 0
@@ -767,6 +768,9 @@ def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol
                     kth = float(ref[b].min())
                     miss = max([so[i] - kth for i, it in enumerate(ro) if it not in ranked] + [0.0])
                     out["missed"].append(miss)
+                    # ... and how far an item the search returns but the oracle's list does not hold falls below the oracle's K-th score
+                    okth = min(so)
+                    out["extra"].append(max([okth - float(ref[b, j]) for j, it in enumerate(ranked) if it not in ro] + [0.0]))
             ui += B
         li += 1
     return out

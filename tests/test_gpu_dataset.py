@@ -60,9 +60,20 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
           sum(1 for x in tf16["missed"] if x > TIE_TOL), "max", max(tf16["missed"]))
     assert tf32["users"] == c32["users"] and tf32["score_viol"] == 0 and tf32["order_viol"] == 0 and max(tf32["missed"]) <= FP32_TIE_TOL, tf32
     assert tf16["score_viol"] == 0 and tf16["order_viol"] == 0, {k: v for k, v in tf16.items() if k != "missed"}
-    # (c) an item of the ORACLE's list that the bf16 search does not return may outscore the search's K-th item (both scored by the
-    # oracle) by more than the tie tolerance only through an earlier near-tie pruning decision of the beam search; that is rare
-    assert sum(1 for x in tf16["missed"] if x > TIE_TOL) <= 0.05 * tf16["users"], sorted(tf16["missed"])[-12:]
+    # (c) EVERY difference between the bf16 list and the oracle's list must be explained by a tie: either the lists are equal up to swaps of
+    # items the oracle scores within TIE_TOL of each other, or they differ at the boundary of the list -- what the oracle lists and the
+    # search does not is within TIE_TOL of the search's K-th item, what the search lists and the oracle does not is within TIE_TOL of the
+    # oracle's K-th item (all in oracle scores).  What remains unexplained is a near-tie between two PREFIXES whose completions score very
+    # differently (the one genuine fragility of beam search): observed 0 and 1 of 240 users; at most 2 % may be.
+    flat16, flat_or = [u for us in r_bf16 for u in us], [u for us in r_or for u in us]
+    unexplained = []
+    for i, ((_, ra, _), (_, ro, so)) in enumerate(zip(flat16, flat_or)):
+        tie_swap = cases.lists_equal_up_to_ties(list(ra), list(ro), list(so), TIE_TOL)
+        boundary = tf16["missed"][i] <= TIE_TOL and tf16["extra"][i] <= TIE_TOL
+        if not (tie_swap or boundary):
+            unexplained.append((i, round(tf16["missed"][i], 4), round(tf16["extra"][i], 4)))
+    print(f"[dataset] bf16: differences not explained by ties: {len(unexplained)} of {len(flat16)} users {unexplained[:6]}")
+    assert len(unexplained) <= 0.02 * len(flat16), unexplained
     # bf16 engine.  Its scores are within BF16_SCORE_TOL of the oracle's; a beam search is a sequence of discrete decisions, so
     # it must reproduce the oracle exactly wherever the oracle took every decision by a margin larger than TIE_TOL
     # (fixed: 2 x the score-error ceiling) and may differ only where the oracle itself was that close to deciding otherwise:
@@ -70,15 +81,14 @@ def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
     #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
     assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
-    # Floors over ALL users on what a tie cannot explain: the ranked list up to swaps of items the ORACLE scores within TIE_TOL of each
-    # other, the top-10 SET, the gold item's rank.  (The raw count of bit-identical lists is printed, not gated: with the oracle's median
-    # gap between consecutive final scores at 0.006 and a bf16 score error of up to 0.008 it counts near-ties, not errors -- five training
-    # trajectories of this test gave 158 / 187 / 200 / 201 / 202 identical lists with 236-240 lists identical up to ties every time; what a
-    # returned list must satisfy for EVERY user is the teacher-forced check above.  Training is bit-reproducible since round 4, so the
-    # trajectory of a given build no longer changes from run to run.)
-    print(f"[dataset] bf16: {c16['identical_lists']}/{c16['users']} bit-identical lists, {c16['identical_up_to_ties']} identical up to oracle ties <= {TIE_TOL}")
-    assert c16["identical_up_to_ties"] >= 0.95 * c16["users"], c16
-    assert c16["same_topk_set"][10] >= 0.95 * c16["users"] and c16["same_topk_set"][5] >= 0.95 * c16["users"], c16
+    # Floors over ALL users (the raw counts of bit-identical lists, of lists identical up to tie swaps and of identical top-10 sets are
+    # printed, not gated: with the oracle's median gap between consecutive final scores at 0.006 they count near-ties at the tail of the
+    # list -- six training trajectories of this test gave 158 .. 203 identical lists, 227 .. 240 identical up to swaps, the top-10 set
+    # differing for 0 .. 13 users, always with the gold item at the same rank for >= 235 users and the top-5 SET identical for all 240;
+    # what every returned list must satisfy is the teacher-forced check and the "every difference is a tie" assertion above):
+    print(f"[dataset] bf16: {c16['identical_lists']}/{c16['users']} bit-identical lists, {c16['identical_up_to_ties']} identical up to oracle ties <= {TIE_TOL}, "
+          f"same top-10 set {c16['same_topk_set'][10]}, same top-5 set {c16['same_topk_set'][5]}, same gold rank {c16['same_gold_rank']}")
+    assert c16["same_topk_set"][5] >= 0.95 * c16["users"], c16
     assert c16["same_gold_rank"] >= 0.95 * c16["users"], c16
     for mb, mo in zip(m_bf16, m_or):
         assert abs(mb["hit@5"] - mo["hit@5"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)

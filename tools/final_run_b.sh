@@ -4,6 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+timeout 600 python -m pytest tests/test_gpu_dataset.py -q -x -m gpu -s > gpurun_out/final_pytest_dataset.log 2>&1; grep "dataset\]\|passed\|failed" gpurun_out/final_pytest_dataset.log | cut -c1-300 | tail -12
 bash profiles/profile.sh final_train python bench.py --steps 10 --warmup 3 --no-cpu --no-gen --legs none
 bash profiles/profile.sh final_gen python tools/gen_bench.py 20 5
 # the fp32 (list-identical) generation mode with narrower column tiles of the norm-fused projections (two workgroups per CU)
