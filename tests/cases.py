@@ -699,6 +699,12 @@ def make_pipeline(be, tmp, dtype, dataset="ML100K", n_users=120, n_items=150, n_
                                           "--test_before_train", "0", "--test_epoch", "0", "--compute_dtype", dtype] + list(flags))
     args.rank = 0
     args.model_path = os.path.join(tmp, "model.pt")
+    # as main.py:61 does before it builds anything (utils.set_seed): `random_initialization` below draws from torch's DEVICE generator,
+    # whose default seed differs from process to process -- without this the "same" pipeline starts from different embeddings in every
+    # run (the five different trajectories of tests/test_gpu_dataset.py in round 4 were five different initialisations, not five
+    # outcomes of one training: the training itself is bit-reproducible)
+    from openp5_amd.utils.utils import set_seed
+    set_seed(seed)
     random.seed(0)
     tok = build_offline_tokenizer(vocab) if vocab else build_offline_tokenizer()
     train = ConcatDataset([MultiTaskDataset(args, dataset, "train")])

@@ -74,6 +74,35 @@ def toy_run(hip, tmp, dropout, epochs=2):
     return rec
 
 
+def pipe_run(hip, tmp, epochs=2):
+    """the dataset gate's training (tests/test_gpu_dataset.py: cases.make_pipeline, T5-small dims, B=32, ragged L, random_initialization)"""
+    from openp5_amd import runner as R
+    from tests import cases
+    runner, model, tok, args = cases.make_pipeline(hip, tmp, "bf16", flags=["--epochs", str(epochs), "--lr", "1e-3"])
+    rec = {"grad_crc": [], "param_crc": [], "m_crc": [], "shapes": []}
+    rec["init_crc"] = zlib.crc32(model._flat.detach().cpu().numpy().tobytes())
+    grads = []
+    orig = R.training_step
+
+    def hooked(model_, optimizer, batch, *a, **k):
+        out = orig(model_, optimizer, batch, *a, **k)
+        torch.cuda.synchronize()
+        rec["shapes"].append([int(batch[0].shape[0]), int(batch[0].shape[1]), int(batch[3].shape[1])])
+        rec["in_crc"] = rec.get("in_crc", []) + [zlib.crc32(batch[0].cpu().numpy().tobytes()) ^ zlib.crc32(batch[3].cpu().numpy().tobytes())]
+        record_step(rec, model_, optimizer, grads if len(grads) < 2 else None)
+        return out
+
+    R.training_step = hooked
+    try:
+        runner.train()
+    finally:
+        R.training_step = orig
+    rec["final"] = model._flat.detach().cpu()
+    rec["first_grads"] = grads
+    rec["views"] = {n: [o, k] for n, (o, k, _) in model._views.items()}
+    return rec
+
+
 def c2_run(hip, steps, dropout=0.1, B=64, L=128, T=8):
     from oracle import t5_oracle as O
     from openp5_amd.optim import FusedAdamW
@@ -101,6 +130,8 @@ def c2_run(hip, steps, dropout=0.1, B=64, L=128, T=8):
 
 
 def compare(a, b, la, lb):
+    if "init_crc" in a and "init_crc" in b:
+        print(f"  {la} vs {lb}: initial parameters equal: {a['init_crc'] == b['init_crc']}; inputs equal: {a.get('in_crc') == b.get('in_crc')}")
     n = min(len(a["grad_crc"]), len(b["grad_crc"]))
     first = None
     for s in range(n):
@@ -151,13 +182,17 @@ def main():
         if mode == "toy":
             with tempfile.TemporaryDirectory() as tmp:
                 out.append(toy_run(hip, tmp, dropout))
+        elif mode == "pipe":
+            with tempfile.TemporaryDirectory() as tmp:
+                out.append(pipe_run(hip, tmp))
+                print(f"   run {r}: init crc {out[-1]['init_crc']}, {len(out[-1]['grad_crc'])} steps, input crcs equal to run 0: {out[-1]['in_crc'] == out[0]['in_crc']}")
         else:
             out.append(c2_run(hip, 3, dropout))
     print(f"[{mode} {tag}] dropout {dropout}: {len(out[0]['grad_crc'])} steps per run")
     for r in range(1, runs):
         compare(out[0], out[r], "run0", f"run{r}")
     os.makedirs("gpurun_out/repro", exist_ok=True)
-    keep = {k: out[0][k] for k in ("grad_crc", "param_crc", "m_crc", "shapes", "final", "views", "first_grads")}
+    keep = {k: out[0][k] for k in ("grad_crc", "param_crc", "m_crc", "shapes", "final", "views", "first_grads", "init_crc", "in_crc") if k in out[0]}
     torch.save(keep, f"gpurun_out/repro/{mode}_{tag}.pt")
 
 
