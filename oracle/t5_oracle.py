@@ -371,12 +371,14 @@ def p5_forward_nll(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_wo
 
 
 def sequence_scores(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_ids: Tensor, attention_mask: Tensor,
-                    sequences: Tensor) -> Tensor:
+                    sequences: Tensor, return_token_logprobs: bool = False):
     """Teacher-forced score of GIVEN hypotheses, the quantity HF's beam search ranks by (generation/utils.py:3182 with
     length_penalty 1.0; DistributedRunner.py:361-374 reads it as `sequences_scores`): sum over the generated tokens -- up to and
     including </s> -- of log_softmax(full-vocabulary logits)[token], divided by their number.  `sequences` [B, K, T] start with the
     decoder start token (pad) and are pad-filled after </s>.  Used by the dataset-level gate to check every score a lower-precision
-    search returns against this oracle's arithmetic on the SAME sequence, whatever the searches decided on the way."""
+    search returns against this oracle's arithmetic on the SAME sequence, whatever the searches decided on the way.
+    return_token_logprobs: also return the per-token log-probabilities [B, K, T-1] (0 after </s>) -- their running sums are the scores
+    the search's intermediate decisions compare (beam_search: `running_scores`) -- and the token counts [B, K]."""
     B, K, T = sequences.shape
     labels = sequences[:, :, 1:].reshape(B * K, T - 1)
     rep = lambda t: t.repeat_interleave(K, dim=0)      # noqa: E731
@@ -384,7 +386,10 @@ def sequence_scores(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_w
     is_eos = labels == cfg.eos_id
     n = torch.where(is_eos.any(dim=1), is_eos.float().argmax(dim=1) + 1, torch.full((B * K,), T - 1))
     keep = torch.arange(T - 1)[None, :] < n[:, None]
-    return (-(nll * keep).sum(dim=1) / n.clamp(min=1)).view(B, K)
+    scores = (-(nll * keep).sum(dim=1) / n.clamp(min=1)).view(B, K)
+    if return_token_logprobs:
+        return scores, (-(nll * keep)).view(B, K, T - 1), n.view(B, K)
+    return scores
 
 
 def runner_loss(nll: Tensor, output_attention: Tensor) -> Tensor:
@@ -437,7 +442,9 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
     decision_margins (test instrumentation, optional dict, filled in place): for every batch item the smallest score margin by
     which this search took any of its discrete decisions -- "set" [B]: membership of the top-2K candidates, the K running beams,
     the rank < K condition on EOS candidates, the top-K merge of finished hypotheses, the early-stop comparison;
-    "order" [B, nret-1]: gaps between consecutive final scores.  A lower-precision search whose scores stay within half of a
+    "order" [B, nret-1]: gaps between consecutive final scores; "set_per_token" [B]: as "set", with the comparisons of running SUMS
+    (the first three) divided by the number of generated tokens they sum over, i.e. in the unit of the final scores, which are per-token
+    means (a lower-precision search's error on a sum grows with the number of terms).  A lower-precision search whose scores stay within half of a
     margin of these cannot decide differently; where it does differ, the margin says whether it was allowed to.
 
     Per step: log_softmax over the FULL vocab, then -inf outside allowed_fn(batch_id, prefix)
@@ -468,14 +475,17 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
     neg_inf = float("-inf")
     LIVE = -1.0e8                                            # scores above this are real candidates (dead ones carry <= -1e9)
     set_margin = torch.full((B,), float("inf"), dtype=torch.float64)
+    set_margin_per_token = torch.full((B,), float("inf"), dtype=torch.float64)
 
-    def _gap(hi: Tensor, lo: Tensor, cond: Optional[Tensor] = None):
-        nonlocal set_margin
+    def _gap(hi: Tensor, lo: Tensor, cond: Optional[Tensor] = None, tokens: int = 1):
+        # `tokens`: how many generated tokens the two compared scores sum over (1 for scores that are already per-token means)
+        nonlocal set_margin, set_margin_per_token
         ok = (hi > LIVE) & (lo > LIVE)
         if cond is not None:
             ok = ok & cond
         g = torch.where(ok, (hi - lo).abs().to(torch.float64), torch.full_like(hi, float("inf"), dtype=torch.float64))
         set_margin = torch.minimum(set_margin, g)
+        set_margin_per_token = torch.minimum(set_margin_per_token, g / tokens)
 
     while True:
         flat = running[:, :, :cur_len].reshape(B * K, cur_len)
@@ -494,7 +504,7 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         if decision_margins is not None:
             wide = torch.topk(lp, k=min(beams_to_keep + 1, lp.shape[1]))[0]
             if wide.shape[1] > beams_to_keep:
-                _gap(wide[:, beams_to_keep - 1], wide[:, beams_to_keep], unsat[:, 0])               # membership of the top-2K
+                _gap(wide[:, beams_to_keep - 1], wide[:, beams_to_keep], unsat[:, 0], cur_len)      # membership of the top-2K
         topk_lp, topk_idx = torch.topk(lp, k=beams_to_keep)
         topk_beam = topk_idx // V
         topk_tok = topk_idx % V
@@ -506,8 +516,8 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         nxt = torch.topk(run_lp, k=K)[1]
         if decision_margins is not None:
             rs = torch.sort(run_lp, dim=1, descending=True)[0]
-            _gap(rs[:, K - 1], rs[:, K], unsat[:, 0])                                              # the K running beams
-            _gap(topk_lp[:, K - 1], topk_lp[:, K], unsat[:, 0] & (hits[:, K - 1] | hits[:, K]))    # EOS candidate ranked < K or not
+            _gap(rs[:, K - 1], rs[:, K], unsat[:, 0], cur_len)                                     # the K running beams
+            _gap(topk_lp[:, K - 1], topk_lp[:, K], unsat[:, 0] & (hits[:, K - 1] | hits[:, K]), cur_len)   # EOS candidate ranked < K or not
         running = torch.take_along_dim(topk_seq, nxt[:, :, None], dim=1)
         running_scores = torch.take_along_dim(run_lp, nxt, dim=1)
         # f. finished beams
@@ -544,5 +554,6 @@ def beam_search(P: Dict[str, Tensor], cfg: T5Cfg, input_ids: Tensor, whole_word_
         og = (fs[:, :-1] - fs[:, 1:]).abs()
         og = torch.where((fs[:, :-1] > LIVE) & (fs[:, 1:] > LIVE), og, torch.full_like(og, float("inf")))
         decision_margins["set"] = set_margin
+        decision_margins["set_per_token"] = set_margin_per_token
         decision_margins["order"] = og
     return seqs[:, :out_len], scores

@@ -740,27 +740,74 @@ def collect_rankings(runner, gen_fn, K, max_length=50):
     return out
 
 
+def _pack_sequences(chunk, K, which=1):
+    T = 1 + max(len(it) for u in chunk for it in u[which])
+    seqs = torch.zeros(len(chunk), K, T + 1, dtype=torch.long)
+    for b, u in enumerate(chunk):
+        for j, it in enumerate(u[which]):
+            seqs[b, j, 1:1 + len(it)] = torch.tensor(it)
+    return seqs
+
+
+def dropped_gap(x, x_lp, ranked, ranked_lp):
+    """How an item `x` that a beam search does NOT return can have been dropped, judged in the oracle's scores (`x_lp`, `ranked_lp`:
+    oracle per-token log-probabilities of x and of the K returned items).  A beam search drops a path at the first step t at which its
+    prefix is not among the kept ones, and every prefix it kept to the end scored at least as high there: so for SOME t from the first
+    step at which x[:t] is no prefix of a returned item, the running sum of x must not exceed the smallest running sum of the returned
+    items that are at least t tokens long -- or, at t = len(x), its final (per-token mean) score must not exceed theirs.  Returns the
+    smallest violation over those t, per token (0.0 = the drop is consistent with an exact search; a lower-precision search is allowed
+    its tie tolerance).  inf if x shares every prefix with a returned item (cannot happen for x not returned)."""
+    best = float("inf")
+    for t in range(1, len(x) + 1):
+        if any(tuple(y[:t]) == tuple(x[:t]) for y in ranked):
+            continue
+        peers = [sum(lp[:t]) for y, lp in zip(ranked, ranked_lp) if len(y) >= t]
+        if not peers:
+            continue
+        best = min(best, max(0.0, (sum(x_lp[:t]) - min(peers)) / t))
+    return best
+
+
+def list_difference(ranked, ref, r_lp, ro, so, o_lp):
+    """What separates the list a search returned (`ranked`, oracle scores `ref`, oracle per-token log-probabilities `r_lp`) from the
+    oracle's own list (`ro`, `so`, `o_lp`), all in ORACLE scores (per-token means):
+      missed   -- how far an item only the oracle lists lies above the search's K-th item, and
+      extra    -- how far an item only the search lists lies below the oracle's K-th item (both 0 on an exact ranking BY FINAL SCORE --
+                  which a beam search is not: the K-th item can be one whose forced completion is poor and that both lists hold, e.g.
+                  the gate's trie, where one five-token prefix is in every user's top 10 and its </s> costs -3.8: `missed` then says 0.6
+                  for an exchange between two items that tie to 1e-3);
+      exchange -- the best item only the oracle lists minus the worst item only the search lists: the final-score gap of what was
+                  actually exchanged;
+      dropped  -- the largest dropped_gap of the items only the oracle lists: whether the search was entitled to drop them."""
+    kth, okth = min(ref), min(so)
+    only_o = [i for i, it in enumerate(ro) if it not in ranked]
+    only_s = [j for j, it in enumerate(ranked) if it not in ro]
+    return {"missed": max([so[i] - kth for i in only_o] + [0.0]),
+            "extra": max([okth - ref[j] for j in only_s] + [0.0]),
+            "exchange": max(0.0, max(so[i] for i in only_o) - min(ref[j] for j in only_s)) if only_o and only_s else 0.0,
+            "dropped": max([dropped_gap(ro[i], o_lp[i], ranked, r_lp) for i in only_o] + [0.0])}
+
+
 def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol, oracle_rankings=None):
     """Every hypothesis a search returned, scored by the ORACLE on the same token sequence (O.sequence_scores): per user
     (a) max |returned score - oracle score of that sequence|, (b) the largest inversion of the returned order under the oracle's
-    scores, (c) `missed` / `extra`: how far the oracle's own list holds an item the search missed above the search's K-th item, and how far an
-    item only the search returns falls below the oracle's K-th item (oracle scores) -- set differences at the list's boundary.  Unlike
-    the margin-based robustness classes this check applies to EVERY user: it does not ask the two searches to have decided alike,
-    only that what the search returns is correctly scored and ordered."""
-    out = {"users": 0, "max_score_err": 0.0, "max_inversion": 0.0, "score_viol": 0, "order_viol": 0, "missed": [], "extra": []}
+    scores, (c) what separates the returned list from the oracle's own (`list_difference`: missed / extra / exchange / dropped, one
+    entry per user).  Unlike the margin-based robustness classes this check applies to EVERY user: it does not ask the two searches to
+    have decided alike, only that what the search returns is correctly scored and ordered and that what it dropped could be dropped.
+    `detail` keeps the per-token log-probabilities of both lists (for a dump)."""
+    out = {"users": 0, "max_score_err": 0.0, "max_inversion": 0.0, "score_viol": 0, "order_viol": 0, "missed": [], "extra": [], "exchange": [],
+           "dropped": [], "detail": []}
     li = 0
     for loader, users in zip(runner.testloaders, rankings):
         ui = 0
         for batch in loader:
             B = batch[0].shape[0]
             chunk = users[ui:ui + B]
-            T = 1 + max(len(it) for _, ranked, _ in chunk for it in ranked)
-            seqs = torch.zeros(B, K, T + 1, dtype=torch.long)
-            for b, (_, ranked, _) in enumerate(chunk):
-                for j, it in enumerate(ranked):
-                    seqs[b, j, 1:1 + len(it)] = torch.tensor(it)
             with torch.no_grad():
-                ref = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1], seqs)
+                ref, tok, _ = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1], _pack_sequences(chunk, K), True)
+                if oracle_rankings is not None:
+                    _, otok, _ = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1],
+                                                   _pack_sequences(oracle_rankings[li][ui:ui + B], K), True)
             for b, (_, ranked, sc) in enumerate(chunk):
                 err = max(abs(float(ref[b, j]) - sc[j]) for j in range(K))
                 inv = max([float(ref[b, j + 1] - ref[b, j]) for j in range(K - 1)] + [0.0])
@@ -771,12 +818,11 @@ def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol
                 out["order_viol"] += int(inv > order_tol)
                 if oracle_rankings is not None:
                     _, ro, so = oracle_rankings[li][ui + b]
-                    kth = float(ref[b].min())
-                    miss = max([so[i] - kth for i, it in enumerate(ro) if it not in ranked] + [0.0])
-                    out["missed"].append(miss)
-                    # ... and how far an item the search returns but the oracle's list does not hold falls below the oracle's K-th score
-                    okth = min(so)
-                    out["extra"].append(max([okth - float(ref[b, j]) for j, it in enumerate(ranked) if it not in ro] + [0.0]))
+                    r_lp = [tok[b, j].tolist() for j in range(K)]
+                    o_lp = [otok[b, j].tolist() for j in range(K)]
+                    for k, v in list_difference(ranked, ref[b].tolist(), r_lp, ro, so, o_lp).items():
+                        out[k].append(v)
+                    out["detail"].append((r_lp, o_lp))
             ui += B
         li += 1
     return out
@@ -802,7 +848,8 @@ def engine_gen_fn(model):
 
 def oracle_gen_fn(params, ocfg, margins=None):
     """`margins` (optional list): receives, per user in evaluation order, (set_margin, [gaps between consecutive final scores])
-    -- the smallest score margins by which the oracle's beam search took its decisions for that user (oracle/t5_oracle.py)."""
+    -- the smallest score margins by which the oracle's beam search took its decisions for that user (oracle/t5_oracle.py), all in
+    the unit of the final scores (per-token means: comparisons of running sums are divided by the number of tokens summed)."""
     def fn(batch, trie, ct, K, max_length):
         dm = {} if margins is not None else None
         with torch.no_grad():
@@ -810,7 +857,7 @@ def oracle_gen_fn(params, ocfg, margins=None):
                                 decision_margins=dm)
         if margins is not None:
             for b in range(batch[0].shape[0]):
-                margins.append((float(dm["set"][b]), [float(x) for x in dm["order"][b]]))
+                margins.append((float(dm["set_per_token"][b]), [float(x) for x in dm["order"][b]]))
         return out
     return fn
 
@@ -1266,3 +1313,141 @@ def generate_wide_fanout_case(be, ocfg, B, L, K, n_wide, dtype="fp32", seed=3, s
         s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, 12)
     compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
     return out
+
+
+# ---- the dataset-level gate (tests/test_gpu_dataset.py on the GPU; tests/test_runner_emu.py runs the same body on the host emulation)
+FP32_TIE_TOL = 1e-4   # fp32 engine vs oracle: two items whose oracle scores differ by less than the fp32 score tolerance of the
+                      # generation tests (1e-4) may swap places (measured: 2 of 240 users, score gaps <= 1.2e-5)
+BF16_SCORE_TOL = 0.02   # bf16 engine: ceiling on the largest |score - oracle score| of an item both list (measured 0.003 .. 0.016,
+                        # depending on the weights the few training epochs produce)
+TIE_TOL = 2.0 * BF16_SCORE_TOL   # FIXED decision margin of the ORACLE below which the bf16 engine may decide differently: score errors
+                                 # below BF16_SCORE_TOL per score can flip decisions whose margin is at most twice that.  (Round 2
+                                 # scaled this with the error measured in the same run, so a regression widened its own excuse.)
+
+
+def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, **pipeline):
+    """The dataset-level evaluation gate of tests/test_gpu_dataset.py (its docstring says what is compared); `be` is the backend (the HIP
+    library on the GPU box; the host emulation runs the same body on a tiny model in tests/test_runner_emu.py), `pipeline` the
+    make_pipeline arguments, `ocfg_of(vocab_size)` the oracle's configuration of the same model."""
+    runner, model, tok, args = make_pipeline(be, tmp, "bf16", **pipeline)
+    losses = runner.train()
+    assert losses[-1] < 0.7 * losses[0], losses
+    model.eval()
+    r_bf16 = collect_rankings(runner, engine_gen_fn(model), K)
+    sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    from openp5_amd.model import P5T5Native
+    m32 = P5T5Native(model.config, dtype="fp32", backend=be, seed=1)
+    m32.load_state_dict(sd, strict=False)
+    m32.eval()
+    r_fp32 = collect_rankings(runner, engine_gen_fn(m32), K)
+    ocfg = ocfg_of(model.config.vocab_size)
+    margins = []
+    r_or = collect_rankings(runner, oracle_gen_fn({k: sd[k] for k in O.param_shapes(ocfg)}, ocfg, margins), K)
+    m_bf16, m_fp32, m_or = rankings_metrics(r_bf16), rankings_metrics(r_fp32), rankings_metrics(r_or)
+    c32 = compare_rankings(r_fp32, r_or, tie_tol=FP32_TIE_TOL)
+    c16 = compare_rankings(r_bf16, r_or, tie_tol=TIE_TOL)
+    print("[dataset] oracle metrics", m_or)
+    print("[dataset] bf16 metrics  ", m_bf16)
+    print("[dataset] fp32 engine vs oracle", {k: v for k, v in c32.items()})
+    print("[dataset] bf16 engine vs oracle", {k: v for k, v in c16.items()})
+    assert sum(len(u) for u in r_or) >= min_users and any(v > 0 for m in m_or for v in m.values())
+    # fp32 engine: every user's ranked list identical to the oracle's up to swaps of items the ORACLE scores within 1e-4 of each
+    # other, the gold item at the same rank for every user, hence every Hit@k / NDCG@k identical
+    assert c32["identical_up_to_ties"] == c32["users"] and c32["max_score_diff"] <= 1e-4, c32
+    assert c32["identical_lists"] >= 0.98 * c32["users"], c32
+    assert c32["same_gold_rank"] == c32["users"] and m_fp32 == m_or
+    # ---- teacher-forced check, EVERY user, EVERY returned hypothesis (teacher_forced_check): the oracle scores the very token
+    # sequences an engine returned (O.sequence_scores).  This does not depend on the two searches having decided alike, so it is not
+    # vacuous on a model whose own decision margins are small: (a) each returned score equals the oracle's score of that sequence
+    # within the mode's tolerance, (b) the returned order is the oracle's order of those sequences up to the tie tolerance.
+    params_o = {k: sd[k] for k in O.param_shapes(ocfg)}
+    tf32 = teacher_forced_check(runner, params_o, ocfg, r_fp32, K, 1e-4, FP32_TIE_TOL, r_or)
+    tf16 = teacher_forced_check(runner, params_o, ocfg, r_bf16, K, BF16_SCORE_TOL, TIE_TOL, r_or)
+    print("[dataset] teacher-forced, fp32 engine:", {k: v for k, v in tf32.items() if not isinstance(v, list)}, "max missed", max(tf32["missed"]))
+    print("[dataset] teacher-forced, bf16 engine:", {k: v for k, v in tf16.items() if not isinstance(v, list)}, "missed > TIE_TOL:",
+          sum(1 for x in tf16["missed"] if x > TIE_TOL), "max", max(tf16["missed"]))
+    assert tf32["users"] == c32["users"] and tf32["score_viol"] == 0 and tf32["order_viol"] == 0 and max(tf32["missed"]) <= FP32_TIE_TOL, tf32
+    assert tf16["score_viol"] == 0 and tf16["order_viol"] == 0, {k: v for k, v in tf16.items() if not isinstance(v, list)}
+    # (c) EVERY difference between the bf16 list and the oracle's list must be explained by a tie in ORACLE scores:
+    #   * the lists are equal up to swaps of items the oracle scores within TIE_TOL of each other, or
+    #   * every item the oracle lists and the search does not could be dropped (dropped_gap): at some step of the search its running
+    #     score was within TIE_TOL (per token) of -- or below -- the lowest running score among the items the search kept to the end.  At
+    #     the last step that is a tie of final scores; at an earlier step a tie between two PREFIXES, whose completions may score
+    #     differently.
+    # Nothing may remain unexplained.  On this trie every item is 6 tokens with 4 distinct 4th tokens, so the whole search is ONE decision:
+    # the 10 best of 150 five-token prefixes, each followed by a forced </s>.  Seeded trajectory (`gpurun_out` dump analysed in
+    # profiles/r04_dataset_gate.txt): the top-10 set differs for 10 of 240 users, each time ONE item exchanged for another whose final
+    # score is within 0.002 (`exchange`) and whose prefix score is within 0.0024 per token (`dropped`).  `missed` says 0.60 for the same
+    # users: one popular prefix is in all 240 users' top 10 and its </s> costs -3.8, so the K-th item of BOTH lists is that item at
+    # -1.2 .. -1.3 and "above the K-th" measures nothing -- which is why the assertion is on `dropped`, the quantity a beam search decides by.
+    rob = robust_users(r_or, margins, TIE_TOL)
+    flat16, flat_or = [u for us in r_bf16 for u in us], [u for us in r_or for u in us]
+    dump = os.environ.get("P5_DATASET_DUMP")
+    if dump:
+        torch.save({"r_bf16": r_bf16, "r_fp32": r_fp32, "r_or": r_or, "margins": margins, "tf16": tf16, "tf32": tf32, "c16": c16, "c32": c32,
+                    "m": (m_bf16, m_fp32, m_or), "rob": rob, "losses": losses}, dump)
+    unexplained, set_diff, prefix_only = [], 0, 0
+    for i, ((_, ra, _), (_, ro, so)) in enumerate(zip(flat16, flat_or)):
+        set_diff += int(set(ra) != set(ro))
+        if list(ra) == list(ro) or lists_equal_up_to_ties(list(ra), list(ro), list(so), TIE_TOL):
+            continue
+        if tf16["dropped"][i] <= TIE_TOL:
+            prefix_only += int(tf16["exchange"][i] > TIE_TOL)
+            continue
+        unexplained.append((i, round(tf16["exchange"][i], 4), round(tf16["dropped"][i], 4)))
+    print(f"[dataset] bf16: differences not explained by ties: {len(unexplained)} of {len(flat16)} users {unexplained[:6]}; top-{K} set differs for "
+          f"{set_diff} users: largest final-score gap of what was exchanged {max(tf16['exchange']):.4f}, largest dropped_gap {max(tf16['dropped']):.4f} "
+          f"(fp32 engine {max(tf32['dropped']):.2e}), explained by a tie between prefixes only: {prefix_only}, largest 'missed above the K-th' "
+          f"{max(tf16['missed']):.3f}")
+    assert max(tf32["dropped"]) <= FP32_TIE_TOL, max(tf32["dropped"])
+    assert len(unexplained) == 0, unexplained
+    # bf16 engine.  Its scores are within BF16_SCORE_TOL of the oracle's; a beam search is a sequence of discrete decisions, so
+    # it must reproduce the oracle exactly wherever the oracle took every decision by a margin larger than TIE_TOL
+    # (fixed: 2 x the score-error ceiling) and may differ only where the oracle itself was that close to deciding otherwise:
+    #   * list-robust users   -> identical ranked lists;
+    #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
+    #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
+    assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
+    # Floors over ALL users (the raw counts of bit-identical lists, of lists identical up to tie swaps and of identical top-10 sets are
+    # printed, not gated: with the oracle's median gap between consecutive final scores at 0.006 they count near-ties at the tail of the
+    # list -- six training trajectories of this test gave 158 .. 203 identical lists, 227 .. 240 identical up to swaps, the top-10 set
+    # differing for 0 .. 13 users, always with the gold item at the same rank for >= 235 users and the top-5 SET identical for all 240;
+    # what every returned list must satisfy is the teacher-forced check and the "every difference is a tie" assertion above.  Those
+    # trajectories started from different embeddings -- `random_initialization` draws from torch's device generator, which make_pipeline
+    # did not seed; it does now, and the training itself is bit-reproducible, so a given build gives ONE trajectory):
+    print(f"[dataset] bf16: {c16['identical_lists']}/{c16['users']} bit-identical lists, {c16['identical_up_to_ties']} identical up to oracle ties <= {TIE_TOL}, "
+          f"same top-10 set {c16['same_topk_set'][10]}, same top-5 set {c16['same_topk_set'][5]}, same gold rank {c16['same_gold_rank']}")
+    assert c16["same_topk_set"][5] >= 0.95 * c16["users"], c16
+    assert c16["same_gold_rank"] >= 0.95 * c16["users"], c16
+    for mb, mo in zip(m_bf16, m_or):
+        assert abs(mb["hit@5"] - mo["hit@5"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)
+        assert abs(mb["hit@10"] - mo["hit@10"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)
+    flat_b, flat_o = flat16, flat_or
+    n_list = n_metric = n_fragile_moved = 0
+    for (list_ok, metric_ok), (g, ra, sa), (_, ro, so), (set_m, gaps) in zip(rob, flat_b, flat_o, margins):
+        ka, ko = (ra.index(g) if g in ra else -1), (ro.index(g) if g in ro else -1)
+        if list_ok:
+            n_list += 1
+            assert ra == ro, ("list-robust user differs", set_m, gaps, ra, ro)
+        if metric_ok:
+            n_metric += 1
+            assert ka == ko, ("metric-robust user: gold rank moved", set_m, gaps, ka, ko)
+        elif ka != ko:
+            n_fragile_moved += 1
+            print(f"[dataset] tie report: gold rank {ko} (oracle) vs {ka} (bf16); oracle's smallest set margin {set_m:.4f}, "
+                  f"final-score gaps around the gold item {[round(x, 4) for x in gaps[max(0, ko - 1):ko + 1]] if ko >= 0 else '-'}")
+    n = len(rob)
+    print(f"[dataset] bf16: {n_list}/{n} users list-robust (all identical), {n_metric}/{n} metric-robust (gold rank identical), "
+          f"{n - n_metric} fragile of which {n_fragile_moved} moved")
+    sm = sorted(m[0] for m in margins)
+    print(f"[dataset] TIE_TOL {TIE_TOL:.4f}; oracle set-margin quantiles 10/50/90%: {sm[n // 10]:.4f} {sm[n // 2]:.4f} {sm[9 * n // 10]:.4f}")
+    # (the oracle's OWN decision margins on this barely-trained model are small -- median 0.025, 90 % below 0.06 -- so most users are
+    # fragile at any tolerance a bf16 score error of 0.005 .. 0.016 allows; the floors asserted above are what holds for ALL users)
+    # (how many users are robust at TIE_TOL depends on the trained weights: 18 of 240 on one trajectory of this test, 0 on another --
+    #  the per-user exactness above is asserted for whoever is robust; the floors over ALL users are the gate that always applies)
+    print(f"[dataset] robust population at TIE_TOL: {n_metric}/{n}")
+    for mb, mo in zip(m_bf16, m_or):      # dataset-level metrics: equal up to the fragile users that moved
+        for k in mo:
+            assert abs(mb[k] - mo[k]) <= n_fragile_moved / (n / len(m_or)) + 1e-12, (k, mb[k], mo[k])
+    if n_fragile_moved == 0:
+        assert m_bf16 == m_or, (m_bf16, m_or)
