@@ -625,8 +625,6 @@ def main():
         else:
             line["roofline"] = dict(bound="mfma", kernel=k_wg, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **wg_alone)
         line["roofline_fwd"] = dict(bound="mfma", kernel=k_fwd, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **fwd_alone)
-        if True:
-            pass
         if gen:
             S = gen["decoded_len"] - 1
             timed = (timing or {}).get("decode_ms")
@@ -659,6 +657,7 @@ def main():
                 line["cpu_baseline_generation"] = cpu_baseline_generation()
         print(json.dumps(line), flush=True)
     if world > 1:
+        barrier(world)      # rank 0 times its stand-alone kernels after the last collective: the others wait here, then all tear down together
         _dist().destroy_process_group()
 
 

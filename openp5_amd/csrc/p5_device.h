@@ -103,18 +103,20 @@ struct P5Prof {
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   hipEvent_t get() {
-    if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
     return pool[used++];
   }
   void begin(const char* name, dim3 g, dim3 b, hipStream_t s) {
     Rec r{name, pending_tag, g.x, g.y, g.z, b.x, pm, pn, pk, pending_flops, get(), get()};
     pending_flops = 0.0; pending_tag = ""; pm = pn = pk = 0;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     recs.push_back(r);
   }
-  void end(hipStream_t s) { hipEventRecord(recs.back().b, s); }
+  void end(hipStream_t s) { (void)hipEventRecord(recs.back().b, s); }
 };
-inline P5Prof& p5_prof() { static P5Prof p; return p; }      // (one instance for all translation units of the library)
+// one instance per host thread, shared by all translation units of the library: a launcher notes the FLOPs / shape of the launch it is
+// about to make, P5_LAUNCH consumes the note -- both on the calling thread, so two threads driving two engines do not see each other's
+inline P5Prof& p5_prof() { static thread_local P5Prof p; return p; }
 #define P5_LAUNCH(kern, grid, block, shmem, stream, ...)                                   \
   do {                                                                                     \
     P5Prof& _pf = p5_prof();                                                               \
