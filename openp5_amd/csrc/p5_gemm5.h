@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           u32x4 auxv[TN / 2];
           if constexpr (EK >= 3) {
 #pragma unroll
-            for (int h = 0; h < TN / 2; ++h) auxv[h] = ap ? ld16(ap + h * 32) : (u32x4){0u, 0u, 0u, 0u};
+            for (int h = 0; h < TN / 2; ++h) auxv[h] = (ap && (ABL & 64) == 0) ? ld16(ap + h * 32) : (u32x4){0u, 0u, 0u, 0u};      // (ABL 64, lab: no residual / saved-hidden read)
           }
           float sq = 0.f;
 #pragma unroll
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
               for (int e = 0; e < 8; ++e) {
                 float x = v[e];
                 if constexpr (EK == 1 || EK == 2) x = x > 0.f ? x : 0.f;
-                if constexpr (EK == 2 || EK == 4) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? x * dscale : 0.f;
+                if constexpr ((EK == 2 || EK == 4) && (ABL & 32) == 0) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? x * dscale : 0.f;      // (ABL 32, lab: no dropout hash)
                 if constexpr (EK == 3 || EK == 4) x += av[e];
                 if constexpr (EK == 5) x = av[e] > 0.f ? x : 0.f;
                 v[e] = x;

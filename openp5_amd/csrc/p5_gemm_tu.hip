@@ -145,7 +145,11 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
     P5_PROF_TAG(KS ? "KS: grouped weight gradients" : "KC: forward / data-gradient GEMMs");
     if (grp.nprob == 1) P5_PROF_SHAPE(grp.p[0].M, grp.p[0].N, grp.p[0].K);
   }
+#ifdef P5_GEMM5_ABL      // lab builds only (tools/lab/build_ablations.sh): the forward / data-gradient instance with parts of it removed, timed INSIDE the step
+  P5_LAUNCH((p5_gemm5_kernel<KS, KS ? 0 : P5_GEMM5_ABL>), dim3(nwg), dim3(512), 0, s, grp);
+#else
   P5_LAUNCH((p5_gemm5_kernel<KS>), dim3(nwg), dim3(512), 0, s, grp);
+#endif
   return P5_KCHECK();
 }
 int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
