@@ -106,7 +106,9 @@ int p5_forward_loss(P5Engine* e, const int64_t* input_ids, const int64_t* whole_
 int p5_backward_num_stages(const P5Engine* e);
 int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream);
 int p5_backward(P5Engine* e, const float* dnll, void* stream);
-/* arena range [begin,end) whose gradients are final once `stage` has run (for bucketed all-reduce) */
+/* LAYOUT ONLY: the arena range [begin,end) of the parameters whose gradients `stage` computes.  It does NOT say when they are final:
+ * with the default two-layer weight-gradient groups a stage's gradients may be written by a LATER stage's grouped launch.  A data-parallel
+ * caller exchanges the range reported by p5_backward_final_range after each stage (below), never this one. */
 int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_t* end);
 /* What a data-parallel caller exchanges after each p5_backward_stage call: the gradient range that became FINAL with that call -- the
  * union of the stage ranges whose kernels have all been launched (empty while a two-layer weight-gradient group of the encoder is still
@@ -144,6 +146,32 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                 const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,
                 const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
+/* ---- verified generation: the bf16 search proposes, an fp32 pass decides (openp5_amd/csrc/p5_verify.h) ----
+ * The reference ranks by the fp32 scores of HF beam search (DistributedRunner.py:361-387, utils/evaluate.py:37-58).  Protocol, two engines
+ * over the SAME master parameter arena (a bf16 one for the draft, an fp32 one -- dtype 0 -- for the verification), one stream:
+ *   p5_generate_draft (bf16 engine, beam width Kw = K + a few)   -> results ignored, `hist` = what the search kept alive at every step
+ *   p5_verify_plan    (fp32 engine)   -> the distinct live prefixes of every user ("rows"); p5_verify_plan_header()[0] = the largest
+ *                                        row count of any user -- the ONE number the host reads (copy it asynchronously, then enqueue ...)
+ *   p5_verify_encode  (fp32 engine)   -> fp32 encoder pass + cross-attention K/V (independent of the plan: runs while the host reads)
+ *   p5_verify_run     (fp32 engine, rows_per_user >= that number, multiple of 16 recommended)
+ *                                     -> one teacher-forced fp32 decoder pass over all rows, full-vocabulary log-sum-exp and the trie
+ *                                        children's log-probabilities per row, then HF's beam search of the REAL width K replayed on
+ *                                        those numbers.  out_* as p5_generate; out_missing int32 [B]: 1 = the replay needed a prefix the
+ *                                        draft had dropped -- that user's result is NOT the fp32 search's and the caller must re-run the
+ *                                        user through p5_generate on the fp32 engine (openp5_amd/model.py does).
+ * A returned, unflagged list is the fp32 search's list: no bf16 number takes part in any decision or score.  Limits: K <= 22, Kw <= 64. */
+int64_t p5_generate_history_count(int B, int K, int max_len);      /* ints in `hist` for a draft of beam width K */
+int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
+                      int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
+                      const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len,
+                      int* hist, void* ws, int64_t ws_bytes, void* stream);
+int64_t p5_verify_workspace_bytes(const P5Engine* e, int B, int L, int K, int Kw, int max_len, int max_children, int excluded_words);
+int p5_verify_plan(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
+                   const int* child_node, const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes, void* stream);
+const int* p5_verify_plan_header(const P5Engine* e);     /* device int[4]: max rows per user, draft steps, total rows, overflow */
+int p5_verify_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, void* stream);
+int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len,
+                  int* out_missing, void* stream);
 /* Device-time brackets of p5_generate for benchmarks: p5_generate_timing(e, 1, NULL, NULL) arms it; after a p5_generate call,
  * p5_generate_timing(e, enable, &encode_ms, &decode_ms) WAITS for that call to finish and returns the time between its start and
  * its first decode step (encoder pass + cross-attention K/V projection + beam state) and the time of the decode loop itself. */
@@ -185,6 +213,7 @@ typedef struct P5GemmProblem {
   int M, N, K, lda, ldb, ldc, ldaux, epi, c_f32, splitk;
   float alpha;
   const float* rowss; float rowss_eps; float* ssq_out;
+  int rowss_nt, ssq_nt;    /* > 0: the statistics are [rows, nt] partial sums (one per 64 columns), summed in index order / stored per tile; 0: one value per row */
 } P5GemmProblem;
 int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,
                      void* stream);

@@ -17,7 +17,7 @@ class P5Config(C.Structure):
 
 class P5GemmProblem(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("aux", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
-                ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp)]
+                ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp), ("rowss_nt", i32), ("ssq_nt", i32)]
 
 
 # name -> (restype, argtypes)
@@ -55,6 +55,13 @@ PROTOTYPES = {
     "p5_engine_discard_grads": (i32, [vp]),
     "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
     "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "p5_generate_history_count": (i64, [i32, i32, i32]),
+    "p5_generate_draft": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp]),
+    "p5_verify_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32, i32]),
+    "p5_verify_plan": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+    "p5_verify_plan_header": (vp, [vp]),
+    "p5_verify_encode": (i32, [vp, vp, vp, vp, vp]),
+    "p5_verify_run": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
     "p5_generate_timing": (i32, [vp, i32, C.POINTER(f32), C.POINTER(f32)]),
     "p5_decode_begin": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
     "p5_decode_step": (i32, [vp, vp]),

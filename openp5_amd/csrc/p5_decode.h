@@ -255,6 +255,8 @@ struct P5BeamState {
   float* x32;                        // optional [R, d] fp32 residual stream of the latency-shaped decode step: the beam step writes
   const float* E32;                  //   the NEXT step's input embeddings E32[token] into it (one launch per step fewer)
   int d;
+  int* hist;                         // optional (p5_generate_draft): per executed step and beam (parent beam, token, trie node, live) -- what the
+                                     //   fp32 verification pass (p5_verify.h) needs to know about the search; [0] = steps executed
 };
 
 // ---- shared tail of the beam step: HF steps d-g (utils.py:3131-3204, 3008-3075) from the item's top-2K candidate list in
@@ -393,6 +395,10 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
     st.run_node[b * Kb + tid] = top_node[i];
     st.last_tok[b * Kb + tid] = (int64_t)top_tok[i];
     st.run_score[b * Kb + tid] = run_sc[tid];
+    if (st.hist) {     // history of the search for the verification pass (p5_verify.h): step `cur_len` produced the token at position cur_len
+      int* hrec = st.hist + 4 + (size_t)cur_len * 4 * R + b * Kb + tid;
+      hrec[0] = top_beam[i]; hrec[R] = top_tok[i]; hrec[2 * (size_t)R] = top_node[i]; hrec[3 * (size_t)R] = run_sc[tid] > -1.0e8f ? 1 : 0;
+    }
   }
   if (st.x32) {      // decoder input of the next step: x32[row, :] = E32[token, :]  (fp32 master table, P5_T5.py:94-100 for the decoder)
     const int d4 = st.d >> 2;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   }
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
-  __shared__ float cs[P5_MAX_K * P5_MAX_K2];
+  __shared__ __attribute__((aligned(16))) float cs[P5_MAX_K * P5_MAX_K2];
   __shared__ P5BeamSh sh;
   float* top_lp = sh.top_lp;
   int* top_beam = sh.top_beam; int* top_tok = sh.top_tok; int* top_node = sh.top_node;
@@ -451,23 +457,29 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   }
   if (tid == 0) s_nothit = 0;
   __syncthreads();
-  __shared__ int ckey[1024];
+  __shared__ __attribute__((aligned(16))) int ckey[1024 + 4];
   const bool by_rank = Kb * K2 <= 1024;
   if (by_rank) {
     // every candidate computes its own rank in the (score desc, beam*max_c + child asc) order -- all in parallel instead of
     // 2K rounds of block-wide arg-max; the 2K best land at their rank
     for (int t = tid; t < Kb * K2; t += 256)
       ckey[t] = (cs[t] == P5_NEG_INF) ? 0x7fffffff : (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2];
+    if (tid < 4) { cs[Kb * K2 + tid] = P5_NEG_INF; ckey[Kb * K2 + tid] = 0x7fffffff; }     // (the rank loop below reads four at a time)
     if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }   // fewer than 2K candidates
     __syncthreads();
+    const int n4 = (Kb * K2 + 3) >> 2;
     for (int t = tid; t < Kb * K2; t += 256) {
       const float v = cs[t];
       if (v == P5_NEG_INF) continue;
       const int key = ckey[t];
+      // four candidates per LDS round trip (16-byte reads): at beam 16 the one-at-a-time loop was 78 us of this kernel's 95 -- 512
+      // dependent read pairs per candidate (round 5, profiles/r05_generate_verified_*.md)
       int rank = 0;
-      for (int u = 0; u < Kb * K2; ++u) {
-        const float vu = cs[u];
-        rank += (vu > v || (vu == v && ckey[u] < key)) ? 1 : 0;
+      for (int u = 0; u < n4; ++u) {
+        const f32x4 vu = ((const f32x4*)cs)[u];
+        const u32x4 ku = ((const u32x4*)ckey)[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rank += (vu[q] > v || (vu[q] == v && (int)ku[q] < key)) ? 1 : 0;
       }
       if (rank < K2) {
         const int j = t / K2, c = key - j * max_c;
@@ -799,4 +811,5 @@ __global__ __launch_bounds__(256) void p5_beam_finalize_kernel(int* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < R * max_len) out_seq[i] = src[i];
   if (i < R) { out_score[i] = st.fin_score[i]; out_len[i] = st.fin_len[i]; }
+  if (st.hist && i == 0) st.hist[0] = steps;
 }

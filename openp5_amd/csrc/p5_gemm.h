@@ -58,6 +58,7 @@ struct P5GemmArgs {
   // Deterministic split-K (fp32 C, epilogue kind P5_EPI_ATOMIC): when > 0, split z STORES its partial product at C + z * stride
   // (elements) instead of adding to C with atomics; the caller sums the active splits in index order (p5_reduce_splits_kernel).
   long long c_split_stride;
+  int mm_split;          // fp32 operands, K-contiguous: products on the f16 matrix cores from a two-term split of each operand (below); 0 = exact fp32 MFMAs
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets
@@ -477,8 +478,123 @@ __device__ static __forceinline__ void gemm_epilogue(const P5GemmArgs& g, f32x4 
   }
 }
 
-template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool BDMA>
+// ---------------------------------------------------------------------------------------------------------
+// fp32 operands on the f16 matrix cores (round 5; the verification pass of p5_verify.h).  v_mfma_f32_16x16x4_f32 runs at 1/16 of the
+// f16 / bf16 MFMA rate.  Each operand element is split exactly as  x = hi + lo / 4096  with hi = fp16(x) (11 significant bits) and
+// lo = fp16((x - hi) * 4096) (the next 11 bits; the scaling keeps lo a normal fp16 number for |x| > 2^-14 * 2^-1, far below anything a
+// T5 weight or activation needs), and  a.b = hi_a hi_b + (hi_a lo_b + lo_a hi_b) / 4096 [+ lo_a lo_b / 4096^2]  is accumulated in two
+// fp32 accumulators by three (P5_SPLIT_TERMS = 4: four) v_mfma_f32_16x16x32_f16 per 32 values of K -- 51 (68) matrix-pipe cycles where
+// the fp32 instruction needs 256.  Every product of two fp16 numbers is exact in fp32, so what is lost is the dropped lo.lo term: 2^-22
+// relative per product (with four terms: nothing down to 2^-33), against fp32's own 2^-24 rounding of each product.
+// The split is done ONCE per staged element on its way into LDS (not per fragment use), into the SAME LDS images: the two 64-byte
+// chunks of a K-step hold the hi halves and the lo halves -- a 16-byte piece = 8 fp16 = [4 elements of chunk 0, 4 of chunk 1] of
+// that row and piece index, the same K-permutation for A and B -- so the fragment loads are the fp32 kernel's own.
+// Limits: |x| < 65504 (fp16 range; T5 activations behind a T5LayerNorm and its weights are O(1)).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef P5_SPLIT_TERMS
+#define P5_SPLIT_TERMS 3
+#endif
+__host__ __device__ static __forceinline__ unsigned short p5_f2h_bits(float f) {      // round-to-nearest-even, subnormals kept, overflow -> inf
+  union { float f; unsigned u; } c; c.f = f;
+  const unsigned sign = (c.u >> 16) & 0x8000u, ex = (c.u >> 23) & 0xFFu, man = c.u & 0x7FFFFFu;
+  if (ex == 0xFFu) return (unsigned short)(sign | 0x7C00u | (man ? 0x200u : 0u));
+  const int e = (int)ex - 127 + 15;
+  if (e >= 31) return (unsigned short)(sign | 0x7C00u);
+  if (e <= 0) {
+    if (e < -10) return (unsigned short)sign;
+    const unsigned m = man | 0x800000u;
+    const int sh = 14 - e;                       // 24-bit significand -> 10-bit field of a subnormal
+    unsigned r = m >> sh;
+    const unsigned rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    if (rem > half || (rem == half && (r & 1u))) ++r;
+    return (unsigned short)(sign | r);
+  }
+  unsigned r = ((unsigned)e << 10) | (man >> 13);
+  const unsigned rem = man & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;      // (a carry into the exponent is the right answer, up to inf)
+  return (unsigned short)(sign | r);
+}
+__host__ __device__ static __forceinline__ float p5_h2f_bits(unsigned short h) {
+  const unsigned sign = ((unsigned)h & 0x8000u) << 16, ex = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+  union { float f; unsigned u; } c;
+  if (ex == 0) {
+    if (man == 0) { c.u = sign; return c.f; }
+    c.f = (float)man * 5.9604644775390625e-8f;    // 2^-24
+    c.u |= sign;
+    return c.f;
+  }
+  if (ex == 31) { c.u = sign | 0x7F800000u | (man << 13); return c.f; }
+  c.u = sign | ((ex - 15 + 127) << 23) | (man << 13);
+  return c.f;
+}
+// 4 + 4 fp32 elements (one piece of chunk 0 and of chunk 1 of a K-step) -> 8 hi halves, 8 lo halves
+__device__ static __forceinline__ void p5_split8(const u32x4& x0, const u32x4& x1, u32x4& hi, u32x4& lo) {
+  float f[8];
+  unpack16<float>(x0, f);
+  unpack16<float>(x1, f + 4);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P5_EMU)
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const _Float16 h0 = (_Float16)f[2 * q], h1 = (_Float16)f[2 * q + 1];
+    const _Float16 l0 = (_Float16)((f[2 * q] - (float)h0) * 4096.f), l1 = (_Float16)((f[2 * q + 1] - (float)h1) * 4096.f);
+    hi[q] = __builtin_bit_cast(unsigned, (h2){h0, h1});
+    lo[q] = __builtin_bit_cast(unsigned, (h2){l0, l1});
+  }
+#else
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned short h0 = p5_f2h_bits(f[2 * q]), h1 = p5_f2h_bits(f[2 * q + 1]);
+    const unsigned short l0 = p5_f2h_bits((f[2 * q] - p5_h2f_bits(h0)) * 4096.f), l1 = p5_f2h_bits((f[2 * q + 1] - p5_h2f_bits(h1)) * 4096.f);
+    hi[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+#endif
+}
+// acc += A B^T over the 32 K-values of a K-step; a / b: 8 fp16 per lane (lane group g supplies K-values 8g .. 8g+7 of its row)
+#ifdef P5_EMU
+static inline void mma32_f16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  emu::Wave& w = emu::wave();
+  const int l = (int)emu::lane();
+  memcpy(w.slot[l], &a, 16);
+  memcpy(w.slot[l] + 16, &b, 16);
+  emu::wave_barrier();
+  const int col = l & 15, rg = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = rg * 4 + r;
+    float s = acc[r];
+    for (int g = 0; g < 4; ++g) {
+      const unsigned short* pa = (const unsigned short*)(w.slot[g * 16 + row]);
+      const unsigned short* pb = (const unsigned short*)(w.slot[g * 16 + col] + 16);
+      for (int j = 0; j < 8; ++j) s += p5_h2f_bits(pa[j]) * p5_h2f_bits(pb[j]);
+    }
+    acc[r] = s;
+  }
+  emu::wave_barrier();
+}
+#else
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ static __forceinline__ void mma32_f16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+#endif
+// both chunks of a K-step of a K-contiguous fp32 operand tile, split on the way into LDS (chunk 0 image <- hi, chunk 1 image <- lo)
+template <int R>
+__device__ static __forceinline__ void stage_store_split(const u32x4* r0, const u32x4* r1, char* lds0, char* lds1, int tid) {
+  constexpr int NCH = R * 4 / 256;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256;
+    u32x4 hi, lo;
+    p5_split8(r0[i], r1[i], hi, lo);
+    st16(lds0 + kc_off(c >> 2, c & 3), hi);
+    st16(lds1 + kc_off(c >> 2, c & 3), lo);
+  }
+}
+
+template <class T, int BM, int BN, bool AKS, bool BKS, int NCK, bool ADMA, bool BDMA, int MM = 0>
 __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
+  static_assert(MM == 0 || (sizeof(T) == 4 && !AKS && !BKS && NCK == 2 && !ADMA && !BDMA), "split products: fp32, K-contiguous, register-staged");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int KCH = TT<T>::KCH;
   // bytes of one 32-deep K-chunk of an operand tile in LDS (direct-to-LDS images are unpadded)
@@ -509,10 +625,22 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   const T* __restrict__ Bp = (const T*)g.B;
 
   f32x4 acc[TM][TN];
+  f32x4 acc2[MM ? TM : 1][MM ? TN : 1];       // split products: the cross terms (scaled by 4096)
+#if P5_SPLIT_TERMS >= 4
+  f32x4 acc3[MM ? TM : 1][MM ? TN : 1];       // ... and lo.lo (scaled by 4096^2)
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (MM != 0) {
+        acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if P5_SPLIT_TERMS >= 4
+        acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+      }
+    }
 
   static_assert(!(ADMA || BDMA) || NCK == 2, "direct-to-LDS staging copies whole K-steps = two K-chunks");
   u32x4 ra[NCK][ADMA ? 1 : NA], rb[NCK][BDMA ? 1 : NB];
@@ -526,10 +654,15 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
   if constexpr (ADMA && AKS) stage_dma_ks<T, BM>(lds, A, g.lda, m0, st_begin * NCK * KCH, g.M, tid);
   if constexpr (BDMA && !BKS) stage_dma128<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
   if constexpr (BDMA && BKS) stage_dma_ks<T, BN>(lds + NCK * ACH, Bp, g.ldb, n0, st_begin * NCK * KCH, g.N, tid);
+  if constexpr (MM != 0) {
+    stage_store_split<BM>(ra[0], ra[1], lds, lds + ACH, tid);
+    stage_store_split<BN>(rb[0], rb[1], lds + NCK * ACH, lds + NCK * ACH + BCH, tid);
+  } else {
 #pragma unroll
-  for (int c = 0; c < NCK; ++c) {
-    if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * ACH, tid);
-    if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], lds + NCK * ACH + c * BCH, tid);
+    for (int c = 0; c < NCK; ++c) {
+      if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], lds + c * ACH, tid);
+      if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], lds + NCK * ACH + c * BCH, tid);
+    }
   }
   __syncthreads();
 
@@ -550,6 +683,30 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
       if constexpr (BDMA && !BKS) stage_dma128<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
       if constexpr (BDMA && BKS) stage_dma_ks<T, BN>(nb + NCK * ACH, Bp, g.ldb, n0, (st + 1) * NCK * KCH, g.N, tid);
     }
+    if constexpr (MM != 0) {
+      u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fah[i] = frag_load<T, BM, false>(base, wm * (BM / 2) + i * 16, lane);
+        fal[i] = frag_load<T, BM, false>(base + ACH, wm * (BM / 2) + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fbh[j] = frag_load<T, BN, false>(base + NCK * ACH, wn * (BN / 2) + j * 16, lane);
+        fbl[j] = frag_load<T, BN, false>(base + NCK * ACH + BCH, wn * (BN / 2) + j * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          mma32_f16(acc[i][j], fah[i], fbh[j]);
+          mma32_f16(acc2[i][j], fah[i], fbl[j]);
+          mma32_f16(acc2[i][j], fal[i], fbh[j]);
+#if P5_SPLIT_TERMS >= 4
+          mma32_f16(acc3[i][j], fal[i], fbl[j]);
+#endif
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
       const char* la = base + c * ACH;
@@ -570,18 +727,38 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
     }
+    }
     if (more) {
       char* nb = lds + (cur ^ 1) * STAGE;
+      if constexpr (MM != 0) {
+        stage_store_split<BM>(ra[0], ra[1], nb, nb + ACH, tid);
+        stage_store_split<BN>(rb[0], rb[1], nb + NCK * ACH, nb + NCK * ACH + BCH, tid);
+      } else {
 #pragma unroll
-      for (int c = 0; c < NCK; ++c) {
-        if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], nb + c * ACH, tid);
-        if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], nb + NCK * ACH + c * BCH, tid);
+        for (int c = 0; c < NCK; ++c) {
+          if constexpr (!ADMA) stage_store<T, BM, AKS>(ra[c], nb + c * ACH, tid);
+          if constexpr (!BDMA) stage_store<T, BN, BKS>(rb[c], nb + NCK * ACH + c * BCH, tid);
+        }
       }
     }
     P5_SCHED_FENCE();     // the copies issued at the top of the step stay in flight under the MFMAs above
     __syncthreads();
   }
 
+  if constexpr (MM != 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#if P5_SPLIT_TERMS >= 4
+          acc[i][j][r] += (acc2[i][j][r] + acc3[i][j][r] * (1.f / 4096.f)) * (1.f / 4096.f);
+#else
+          acc[i][j][r] += acc2[i][j][r] * (1.f / 4096.f);
+#endif
+        }
+  }
   gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
 }
 

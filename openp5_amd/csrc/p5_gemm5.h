@@ -378,81 +378,119 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         const int rowss_nt = cx.rowss_nt;
         const float invd = cx.invd, eps = cx.eps;
         const int gl = le >> 4;
-        int row = u.m0 + wm * WTM + (le & 15);
+        const int row = u.m0 + wm * WTM + (le & 15);
         const int col0 = u.n0 + wn * WTN + gl * 8;
-        T* cp = (T*)cx.C + (size_t)row * ldc + col0;
+        T* const cp = (T*)cx.C + (size_t)row * ldc + col0;
         const T* ap = cx.aux ? (const T*)cx.aux + (size_t)row * ldaux + col0 : nullptr;
         // EK: the epilogue kind as a compile-time constant (0 store, 1 ReLU, 2 ReLU + dropout, 3 + residual, 4 dropout + residual,
         // 5 ReLU' mask) -- chosen ONCE per tile below: a per-element `if (epi == ...)` chain compiles to scalar branches (the
         // dropout hash keeps hipcc from if-converting it), ~5 per element, 640 per tile.
-        auto rows = [&](auto ek, const f32x4(&a)[TN]) {
-          constexpr int EK = decltype(ek)::value;
-          float sc = alpha;
-          if (rowss) {
-            float ss;
-            if (rowss_nt > 0) {
-              const float* p = rowss + (size_t)row * rowss_nt;
-              ss = 0.f;
-              if ((rowss_nt & 3) == 0) {
-                for (int t = 0; t < rowss_nt; t += 4) {
-                  const f32x4 v = *(const f32x4*)(p + t);
-                  ss = (((ss + v[0]) + v[1]) + v[2]) + v[3];
-                }
-              } else {
-                for (int t = 0; t < rowss_nt; ++t) ss += p[t];
-              }
-            } else {
-              ss = rowss[row];
+        //
+        // Round 5: EVERY load of the tile goes out before its first store.  The in-step ablation (profiles/r05_ablations_in_step.txt) put
+        // 16 us of the 41 us of an 8192x2048x512 launch into "epilogue arithmetic": the eight row blocks each loaded their row statistics
+        // and aux rows, waited, computed and stored -- and because vmcnt counts stores as well as loads on this part, the wait for row
+        // block i+1's loads was also a wait for row block i's stores to be acknowledged: eight dependent memory round trips per tile.
+        // Now: lane group gl fetches the statistics of row blocks 2gl, 2gl+1 (16-byte loads, summed in index order as everywhere else)
+        // and the scale reaches the other lane groups by a shuffle; the aux rows run through a four-block ring (below).
+        float sc2[2] = {alpha, alpha};
+        if (rowss) {
+          const int rb = row + gl * 32;                       // row of block 2gl for this lane
+          if (rowss_nt > 0 && (rowss_nt & 3) == 0 && rowss_nt <= 16) {
+            f32x4 pv[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const float* p = rowss + (size_t)(rb + q * 16) * rowss_nt;
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (t * 4 < rowss_nt) pv[q][t] = *(const f32x4*)(p + t * 4);
             }
-            sc *= rsqrtf(ss * invd + eps);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float ss = 0.f;
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (t * 4 < rowss_nt) ss = (((ss + pv[q][t][0]) + pv[q][t][1]) + pv[q][t][2]) + pv[q][t][3];
+              sc2[q] = alpha * rsqrtf(ss * invd + eps);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float ss = 0.f;
+              if (rowss_nt > 0) {
+                const float* p = rowss + (size_t)(rb + q * 16) * rowss_nt;
+                for (int t = 0; t < rowss_nt; ++t) ss += p[t];
+              } else {
+                ss = rowss[rb + q * 16];
+              }
+              sc2[q] = alpha * rsqrtf(ss * invd + eps);
+            }
           }
-          u32x4 auxv[TN / 2];
+        }
+        auto all_rows = [&](auto ek) {
+          constexpr int EK = decltype(ek)::value;
+          // aux rows (residual / saved hidden): a ring of four row blocks' loads in flight.  Program order per block: use block i's aux ->
+          // request block i+4's into the same registers -> store block i.  A later wait for block i+4's loads then never includes block
+          // i's stores (they were issued after it); the stores it does include are four blocks old.
+          constexpr int AD = 4;
+          u32x4 auxv[AD][TN / 2];
+          auto aux_load = [&](int i) {
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h)
+              auxv[i % AD][h] = (ap && (ABL & 64) == 0) ? ld16(ap + (size_t)i * 16 * ldaux + h * 32) : (u32x4){0u, 0u, 0u, 0u};      // (ABL 64, lab: no residual / saved-hidden read)
+          };
           if constexpr (EK >= 3) {
 #pragma unroll
-            for (int h = 0; h < TN / 2; ++h) auxv[h] = (ap && (ABL & 64) == 0) ? ld16(ap + h * 32) : (u32x4){0u, 0u, 0u, 0u};      // (ABL 64, lab: no residual / saved-hidden read)
+            for (int i = 0; i < AD; ++i) aux_load(i);
           }
-          float sq = 0.f;
 #pragma unroll
-          for (int h = 0; h < TN / 2; ++h) {
-            float v[8];
+          for (int i = 0; i < TM; ++i) {
+            // scale of row block i: held by lane group i / 2 (same row-in-block)
+            const float sc = rowss ? __shfl((i & 1) ? sc2[1] : sc2[0], (le & 15) + 16 * (i >> 1)) : alpha;
+            float sq = 0.f;
+            u32x4 packed[TN / 2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = a[2 * h][r] * sc; v[4 + r] = a[2 * h + 1][r] * sc; }
-            if constexpr (EK != 0) {
-              float av[8];
-              if constexpr (EK >= 3) unpack16<T>(auxv[h], av);
-              const uint32_t idx0 = (uint32_t)(row * N + col0 + h * 32);
+            for (int h = 0; h < TN / 2; ++h) {
+              float v[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                float x = v[e];
-                if constexpr (EK == 1 || EK == 2) x = x > 0.f ? x : 0.f;
-                if constexpr ((EK == 2 || EK == 4) && (ABL & 32) == 0) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? x * dscale : 0.f;      // (ABL 32, lab: no dropout hash)
-                if constexpr (EK == 3 || EK == 4) x += av[e];
-                if constexpr (EK == 5) x = av[e] > 0.f ? x : 0.f;
-                v[e] = x;
+              for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * h][r] * sc; v[4 + r] = acc[i][2 * h + 1][r] * sc; }
+              if constexpr (EK != 0) {
+                float av[8];
+                if constexpr (EK >= 3) unpack16<T>(auxv[i % AD][h], av);
+                const uint32_t idx0 = (uint32_t)((row + i * 16) * N + col0 + h * 32);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  float x = v[e];
+                  if constexpr (EK == 1 || EK == 2) x = x > 0.f ? x : 0.f;
+                  if constexpr ((EK == 2 || EK == 4) && (ABL & 32) == 0) x = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? x * dscale : 0.f;      // (ABL 32, lab: no dropout hash)
+                  if constexpr (EK == 3 || EK == 4) x += av[e];
+                  if constexpr (EK == 5) x = av[e] > 0.f ? x : 0.f;
+                  v[e] = x;
+                }
+              }
+              packed[h] = pack16<T>(v);
+              if (ssq) {
+                float w[8];
+                unpack16<T>(packed[h], w);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sq += w[e] * w[e];
               }
             }
-            const u32x4 packed = pack16<T>(v);
-            if constexpr ((ABL & 16) != 0) { if (packed[0] == 0x12345678u) st16(cp + h * 32, packed); }      // (lab: epilogue math without the stores)
-            else st16(cp + h * 32, packed);
-            if (ssq) {
-              float w[8];
-              unpack16<T>(packed, w);
+            if constexpr (EK >= 3) {
+              if (i + AD < TM) aux_load(i + AD);
+            }
 #pragma unroll
-              for (int e = 0; e < 8; ++e) sq += w[e] * w[e];
+            for (int h = 0; h < TN / 2; ++h) {
+              T* const cpi = cp + (size_t)i * 16 * ldc + h * 32;
+              if constexpr ((ABL & 16) != 0) { if (packed[h][0] == 0x12345678u) st16(cpi, packed[h]); }      // (lab: epilogue math without the stores)
+              else st16(cpi, packed[h]);
+            }
+            if (ssq) {
+              sq += __shfl_xor(sq, 16);
+              sq += __shfl_xor(sq, 32);
+              const int cg = (u.n0 + wn * WTN) >> 6;
+              if (gl == 0 && cg < ssq_nt) ssq[(size_t)(row + i * 16) * ssq_nt + cg] = sq;
             }
           }
-          if (ssq) {
-            sq += __shfl_xor(sq, 16);
-            sq += __shfl_xor(sq, 32);
-            const int cg = (u.n0 + wn * WTN) >> 6;
-            if (gl == 0 && cg < ssq_nt) ssq[(size_t)row * ssq_nt + cg] = sq;
-          }
-          cp += (size_t)16 * ldc;
-          if (ap) ap += (size_t)16 * ldaux;
-          row += 16;
-        };
-        auto all_rows = [&](auto ek) {
-          rows(ek, acc[0]); rows(ek, acc[1]); rows(ek, acc[2]); rows(ek, acc[3]); rows(ek, acc[4]); rows(ek, acc[5]); rows(ek, acc[6]); rows(ek, acc[7]);
         };
         if (epi == P5_EPI_RELU_DROP) { if (cx.do_drop) all_rows(P5EpiTag<2>{}); else all_rows(P5EpiTag<1>{}); }
         else if (epi == P5_EPI_RESID_DROP) { if (cx.do_drop) all_rows(P5EpiTag<4>{}); else all_rows(P5EpiTag<3>{}); }

@@ -23,6 +23,7 @@ int g_opt_gemm_ring128_min_tiles = getenv("P5_GEMM_RING128_MIN_TILES") ? atoi(ge
 int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RING_N512")) : 1;   // ring kernel for N = d_model, K >= 1024
 int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
+int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 160;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -75,6 +76,13 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
       if (mode == 0) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, false>), grid, block, 0, s, g); return P5_KCHECK(); }
       if (mode == 1) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, false, true>), grid, block, 0, s, g); return P5_KCHECK(); }
       if (mode == 3) { P5_LAUNCH((p5_gemm2_kernel<BM, BN, 8, true, true>), grid, block, 0, s, g); return P5_KCHECK(); }
+    }
+  }
+  if constexpr (sizeof(T) == 4 && BM <= 128) {
+    if (mode == 0 && g.mm_split) {       // fp32 operands, products on the f16 matrix cores (p5_gemm.h, two-term split)
+      P5_PROF_TAG(BM == 128 ? "f32 128x128 split-f16" : "f32 64x64 split-f16");
+      P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false, 1>), grid, block, 0, s, g);
+      return P5_KCHECK();
     }
   }
   if (mode == 0 && dma) P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, sizeof(T) == 2, sizeof(T) == 2>), grid, block, 0, s, g);
@@ -208,6 +216,7 @@ static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
   static const int split_target = getenv("P5_GEMM_SPLIT_TARGET") ? atoi(getenv("P5_GEMM_SPLIT_TARGET")) : 768;
   // measured on MI355X (tools/gemm_bench2.py): 128x128 tiles win once there are >= 2 full rounds of them, 64x64 below
   bool big = force_tile ? force_tile == 128 : (t128 >= 512 || (g.epi == P5_EPI_ATOMIC && g.K >= 16384));
+  if (sizeof(T) == 4 && g.mm_split && !force_tile && g_opt_split_big_tiles > 0 && t128 >= g_opt_split_big_tiles) big = true;   // (split products: the wider wave tile halves the conversions per MFMA)
   // weight gradients (both operands K-strided, long K, few tiles): the four-slot-ring kernel, one 128x128 workgroup per CU,
   // split-K so that tiles x splits ~ 160: in isolation ~256 (every CU) is fastest, inside the step fewer, longer workgroups leave
   // CUs to the main stream (tools/wgrad_bench.py: 8192-deep 512x2048 50.9 -> 34.4 us, 2048x512 39.6 -> 32.6 us;

@@ -17,6 +17,7 @@
 #include "p5_embed.h"
 #include "p5_decode.h"
 #include "p5_decode2.h"
+#include "p5_verify.h"
 #include "../../include/p5hip.h"
 
 thread_local std::string g_p5_err;
@@ -83,7 +84,7 @@ struct Bump {
   }
 };
 
-struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S, *fold; int sz, fused; };
+struct GraphKey { int B, L, K, max_len, max_c, excl_words; const void *ws, *trie, *trie_tok, *trie_node, *roots, *P, *S, *fold, *hist; int sz, fused; };
 
 struct GenWs {
   void* kv_cross[64];   // per decoder layer: T [B*L, ldkv] -- column slices of ONE [B*L, n_dec*2*inner] block in the latency-shaped path
@@ -160,6 +161,8 @@ struct P5Engine {
   std::vector<int64_t> fold_qkv, fold_q, fold_wi;
   int64_t fold_E = 0, fold_count = 0;
   GenCtx gen;
+  int* gen_hist_next = nullptr;    // p5_generate_draft: history buffer of the NEXT search (one-shot)
+  struct VerifyCtx* ver = nullptr;  // state of a verification pass between p5_verify_plan and p5_verify_run (p5_verify.h)
   // transposed bf16 copies of the 2-D layer weights (same arena offsets): the data gradients dx = dy W then read W^T as a
   // K-contiguous operand, i.e. run on the forward kernel (p5_engine_bind_transposed; optional)
   void* St = nullptr;
@@ -363,6 +366,12 @@ static P5Drop mk_drop(const P5Engine* e, int stack, int layer, int which) {
 }
 static P5Drop no_drop() { P5Drop d; d.state = nullptr; d.site_key = 0; d.thr = 0; d.scale = 1.f; return d; }
 
+// fp32 engine: products of the K-contiguous forward GEMMs on the f16 matrix cores from a two-term split (p5_gemm.h); switched on by the
+// verification pass for the duration of its calls (option "verify_split"), off everywhere else: the fp32 parity engine stays exact
+static thread_local int g_f32_split = 0;
+static int g_opt_verify_split = getenv("P5_VERIFY_SPLIT") ? atoi(getenv("P5_VERIFY_SPLIT")) : 1;
+struct SplitScope { int prev; explicit SplitScope(int on) : prev(g_f32_split) { g_f32_split = on; } ~SplitScope() { g_f32_split = prev; } };
+
 template <class T>
 static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, int ldb, int bks, void* C, int ldc, int M, int N,
                 int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop, const float* rowss = nullptr,
@@ -372,6 +381,7 @@ static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, 
   g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
   g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = rowss_eps; g.ssq_out = ssq_out;
   g.rowss_nt = 0; g.ssq_nt = 0; g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0; g.c_split_stride = 0;
+  g.mm_split = (sizeof(T) == 4 && !aks && !bks && epi != P5_EPI_ATOMIC && epi != P5_EPI_ACCUM) ? g_f32_split : 0;
   return launch_gemm<T>(g, s);
 }
 // TRAINING forward with T5LayerNorm folded in (bf16 engine): y = rstd(x) * (x Wf^T), Wf = W diag(ln) from the folded
@@ -1166,6 +1176,7 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   st.x32 = g_opt_decode_v2 ? w.x32 : nullptr;
   st.E32 = e->P ? e->P + e->off_E : nullptr;
   st.d = d;
+  st.hist = nullptr;
   return (int64_t)((b.off + 255) & ~(size_t)255);
 }
 
@@ -1312,6 +1323,25 @@ static int head_nv(const P5Engine* e) {
   return 0;
 }
 
+// streaming tied head over R rows: per vocabulary tile (max, sum exp) only; the logits the search needs are recomputed by p5_dec_score2_kernel
+template <class T>
+static int launch_head_lse(P5Engine* e, float* part_m, float* part_s, const void* hn, int R, const int* done, hipStream_t s) {
+  const P5Config& c = e->c;
+  const int d = c.d_model;
+  const float alpha = 1.0f / sqrtf((float)d);
+  const int nv = head_nv(e), V = c.vocab_size, nt = (V + nv - 1) / nv;
+  const size_t bytes = (size_t)nv * d * sizeof(T);
+#define P5_HEAD(NV, KB) P5_LAUNCH((p5_head_lse_kernel<T, NV, KB>), dim3(nt), dim3(256), 0, s, part_m, part_s, (const T*)hn, Wc<T>(e, e->off_E), R, d, V, alpha, done)
+  if (nv == 128) P5_HEAD(128, 128);
+  else if (nv == 64 && bytes <= 64 * 1024) P5_HEAD(64, 64);
+  else if (nv == 64) P5_HEAD(64, 128);
+  else if (nv == 32 && bytes <= 64 * 1024) P5_HEAD(32, 64);
+  else if (nv == 32) P5_HEAD(32, 128);
+  else P5_HEAD(16, 64);
+#undef P5_HEAD
+  return P5_KCHECK();
+}
+
 template <class T>
 static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len, hipStream_t s) {
   const P5Config& c = e->c;
@@ -1368,20 +1398,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
   P5_LAUNCH((p5_rmsnorm_f32in_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, s, (T*)w.hn, (const float*)x, (const float*)(e->P + e->off_dec_fln), R, d, c.eps, done);
   P5_TRY(P5_KCHECK());
   const float alpha = 1.0f / sqrtf((float)d);
-  if (head_nv(e) > 0) {
-    // streaming head: per-tile (max, sum exp) only; the children's logits are recomputed by p5_beam_step2_kernel
-    const int nv = head_nv(e), V = c.vocab_size, nt = (V + nv - 1) / nv;
-    const size_t bytes = (size_t)nv * d * sizeof(T);
-#define P5_HEAD(NV, KB) P5_LAUNCH((p5_head_lse_kernel<T, NV, KB>), dim3(nt), dim3(256), 0, s, w.part_m, w.part_s, (const T*)w.hn, Wc<T>(e, e->off_E), R, d, V, alpha, done)
-    if (nv == 128) P5_HEAD(128, 128);
-    else if (nv == 64 && bytes <= 64 * 1024) P5_HEAD(64, 64);
-    else if (nv == 64) P5_HEAD(64, 128);
-    else if (nv == 32 && bytes <= 64 * 1024) P5_HEAD(32, 64);
-    else if (nv == 32) P5_HEAD(32, 128);
-    else P5_HEAD(16, 64);
-#undef P5_HEAD
-    return P5_KCHECK();
-  }
+  if (head_nv(e) > 0) return launch_head_lse<T>(e, w.part_m, w.part_s, w.hn, R, done, s);
   return linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, R, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, alpha, 1);
 }
 
@@ -1395,6 +1412,8 @@ static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, cons
   g.active = false;
   layout_gen(e, ws, B, L, K, max_len, max_c, excl_words, &g.w);
   GenWs& w = g.w;
+  w.st.hist = e->gen_hist_next;       // (p5_generate_draft) one-shot
+  e->gen_hist_next = nullptr;
   if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
   P5_TRY(encoder_fwd<T>(e, s));
@@ -1458,7 +1477,7 @@ static int decode_step_impl(P5Engine* e, hipStream_t s) {
   memset(&key, 0, sizeof(key));
   key.B = g.B; key.L = g.L; key.K = g.K; key.max_len = g.max_len; key.max_c = g.max_c; key.excl_words = g.excl_words; key.ws = g.ws;
   key.trie = g.child_off; key.trie_tok = g.child_tok; key.trie_node = g.child_node; key.roots = g.roots;
-  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold;
+  key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.hist = g.w.st.hist;
   key.fused = g_opt_decode_fused + 2 * g_opt_decode_v2 + 4 * g_opt_dec_fuseq + 8 * g_opt_dec_nb + 4096 * g_opt_dec_kw + (g_opt_dec_cross << 20) +
               (g_opt_dec_head << 23) + (g_opt_dec_head_nv << 24);
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
@@ -1499,6 +1518,190 @@ static int decode_finish_impl(P5Engine* e, int* out_seq, float* out_score, int* 
   P5_LAUNCH(p5_beam_finalize_kernel, dim3((R * g.max_len + 255) / 256), dim3(256), 0, s, out_seq, out_score, out_len, g.w.st, R, g.max_len);
   P5_TRY(P5_KCHECK());
   g.active = false;
+  return 0;
+}
+
+// ---- verified generation (p5_verify.h): plan -> encode -> run on an fp32 engine bound to the same master parameters ----
+struct VerifyWs {
+  P5VerifyPlan pl;
+  int64_t* ids; int *node_flat, *depth_flat;
+  void *x, *y, *n, *qkv, *q, *o, *h, *hn, *kv_all;
+  float *lse, *part_m, *part_s, *logits, *cand, *row_top_score, *zeros;
+  int *row_top_c, *n_top, *vrow_a, *vrow_b, *missing;
+  P5BeamState st;
+};
+struct VerifyCtx {
+  int stage = 0;       // 1 = planned, 2 = encoded
+  VerifyWs w;
+  int B = 0, L = 0, K = 0, Kw = 0, max_len = 0, max_c = 0, excl_words = 0;
+  const int *child_off = nullptr, *child_tok = nullptr, *child_node = nullptr, *roots = nullptr;
+  char* ws = nullptr;
+};
+static int verify_cap(int Kw, int max_len) { return (Kw * (max_len - 1) + 1 + 15) / 16 * 16; }
+
+static int64_t layout_verify(P5Engine* e, char* base, int B, int L, int K, int Kw, int max_len, int max_c, int excl_words, VerifyWs* out) {
+  const P5Config& c = e->c;
+  const size_t sz = c.dtype == 1 ? 2 : 4;
+  const int d = c.d_model, in = e->inner, F = c.d_ff, H = c.n_heads;
+  const int cap = verify_cap(Kw, max_len);
+  const size_t rows = (size_t)B * cap, R = (size_t)B * K;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  const int64_t enc_bytes = layout_ws(e, base, B, L, 0, false);
+  Bump b{base, (size_t)enc_bytes};
+  VerifyWs tmp;
+  VerifyWs& w = out ? *out : tmp;
+  w.kv_all = b.take((size_t)B * L * c.n_dec_layers * 2 * in * sz);
+  P5VerifyPlan& pl = w.pl;
+  pl.cap = cap; pl.max_len = max_len;
+  pl.hdr = (int*)b.take(64);
+  pl.n_rows = (int*)b.take((size_t)B * 4);
+  pl.row_tok = (int*)b.take(rows * 4); pl.row_parent = (int*)b.take(rows * 4); pl.row_depth = (int*)b.take(rows * 4); pl.row_node = (int*)b.take(rows * 4);
+  pl.first = (int*)b.take((size_t)B * (max_len + 1) * 4);
+  pl.anc = (int*)b.take(rows * max_len * 4);
+  w.ids = (int64_t*)b.take(rows * 8); w.node_flat = (int*)b.take(rows * 4); w.depth_flat = (int*)b.take(rows * 4);
+  w.x = b.take(rows * d * sz); w.y = b.take(rows * d * sz); w.n = b.take(rows * d * sz);
+  w.qkv = b.take(rows * 3 * in * sz); w.q = b.take(rows * in * sz); w.o = b.take(rows * in * sz);
+  w.h = b.take(rows * (c.gated_gelu ? 3 : 1) * F * sz); w.hn = b.take(rows * d * sz);
+  w.lse = (float*)b.take((size_t)B * H * cap * 4);
+  const int nv = head_nv(e);
+  const size_t nt = nv > 0 ? (size_t)(c.vocab_size + nv - 1) / nv : 1;
+  w.part_m = (float*)b.take(rows * nt * 4); w.part_s = (float*)b.take(rows * nt * 4);
+  w.logits = (float*)b.take(rows * Vp * 4);        // (materialised logits: toy widths, and the split-product head -- one throughput GEMM)
+  w.cand = (float*)b.take(rows * (size_t)max_c * 4);
+  w.row_top_score = (float*)b.take(rows * (size_t)(2 * K) * 4); w.row_top_c = (int*)b.take(rows * (size_t)(2 * K) * 4);
+  w.n_top = (int*)b.take(rows * 4); w.zeros = (float*)b.take(rows * 4);
+  w.vrow_a = (int*)b.take(R * 4); w.vrow_b = (int*)b.take(R * 4); w.missing = (int*)b.take((size_t)B * 4);
+  P5BeamState& st = w.st;
+  st.run_seq = (int*)b.take(R * max_len * 4); st.run_seq_next = (int*)b.take(R * max_len * 4);
+  st.fin_seq = (int*)b.take(R * max_len * 4); st.fin_seq_next = (int*)b.take(R * max_len * 4);
+  st.anc = (int*)b.take(R * max_len * 4); st.anc_next = (int*)b.take(R * max_len * 4);
+  st.run_score = (float*)b.take(R * 4); st.run_node = (int*)b.take(R * 4);
+  st.fin_score = (float*)b.take(R * 4); st.fin_flag = (int*)b.take(R * 4); st.fin_len = (int*)b.take(R * 4);
+  st.unsat = (int*)b.take((size_t)B * 4);
+  st.last_tok = (int64_t*)b.take(R * 8);
+  st.flags = (int*)b.take(64);
+  st.x32 = nullptr; st.E32 = nullptr; st.d = d; st.hist = nullptr;
+  (void)excl_words;
+  return (int64_t)((b.off + 255) & ~(size_t)255);
+}
+
+static int verify_plan_impl(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
+                            const int* child_node, const int* roots, int max_c, int excl_words, char* ws, hipStream_t s) {
+  if (!e->ver) e->ver = new VerifyCtx();
+  VerifyCtx& v = *e->ver;
+  v.stage = 0;
+  layout_verify(e, ws, B, L, K, Kw, max_len, max_c, excl_words, &v.w);
+  v.B = B; v.L = L; v.K = K; v.Kw = Kw; v.max_len = max_len; v.max_c = max_c; v.excl_words = excl_words; v.ws = ws;
+  v.child_off = child_off; v.child_tok = child_tok; v.child_node = child_node; v.roots = roots;
+  hipMemsetAsync(v.w.pl.hdr, 0, 64, s);
+  P5_LAUNCH(p5_verify_plan_kernel, dim3(B), dim3(256), 0, s, v.w.pl, hist, child_off, child_tok, child_node, roots, B, Kw, e->c.pad_id);
+  P5_TRY(P5_KCHECK());
+  v.stage = 1;
+  return 0;
+}
+
+// the fp32 encoder pass + the cross-attention K/V of every decoder layer (one GEMM over the contiguous weight block); independent of the plan
+template <class T>
+static int verify_encode_impl(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, hipStream_t s) {
+  VerifyCtx& v = *e->ver;
+  const P5Config& c = e->c;
+  SplitScope split(sizeof(T) == 4 ? g_opt_verify_split : 0);
+  layout_ws(e, v.ws, v.B, v.L, 0, false);          // (the encoder's buffers: the head of the verification workspace)
+  e->B = v.B; e->L = v.L; e->T = 0; e->M = v.B * v.L; e->Md = 0; e->training = 0;
+  e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
+  P5_TRY(encoder_fwd<T>(e, s));
+  P5_TRY(linear_fwd<T>(s, e->enc_out, c.d_model, Wc<T>(e, e->dec[0].ca.k), v.w.kv_all, c.n_dec_layers * 2 * e->inner, v.B * v.L, c.n_dec_layers * 2 * e->inner, c.d_model));
+  v.stage = 2;
+  return 0;
+}
+
+// SCORE + REPLAY.  PU: rows per user of this pass (>= the plan's largest row count, a multiple of 16, <= cap): the decoder runs on
+// [B x PU] rows -- self-attention sees them as B*PU single positions with ancestor lists, cross-attention as B sequences of PU queries.
+template <class T>
+static int verify_run_impl(P5Engine* e, int PU, const uint32_t* excluded, int* out_seq, float* out_score, int* out_len, int* out_missing, hipStream_t s) {
+  VerifyCtx& v = *e->ver;
+  VerifyWs& w = v.w;
+  const P5Config& c = e->c;
+  SplitScope split(sizeof(T) == 4 ? g_opt_verify_split : 0);
+  const int d = c.d_model, in = e->inner, H = c.n_heads, F = c.d_ff, B = v.B, K = v.K, max_len = v.max_len;
+  const int rows = B * PU, R = B * K, ldkv = c.n_dec_layers * 2 * in;
+  const int Vp = (c.vocab_size + 63) / 64 * 64;
+  P5_LAUNCH(p5_verify_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, w.ids, w.node_flat, w.depth_flat, w.pl, B, PU, c.pad_id);
+  P5_TRY(P5_KCHECK());
+  void* x = w.x; void* y = w.y;
+  P5_LAUNCH((p5_embed_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (T*)x, Wc<T>(e, e->off_E), (const T*)nullptr, (const int64_t*)w.ids,
+            (const int64_t*)nullptr, rows, d, no_drop(), (float*)nullptr);
+  P5_TRY(P5_KCHECK());
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    const LayerOff& lo = e->dec[i];
+    // self-attention over the row's own prefix
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.sa.ln, rows, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.sa.q), w.qkv, 3 * in, rows, 3 * in, d));
+    P5_LAUNCH((p5_tree_attn_kernel<T>), dim3((rows * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, w.pl, (const int*)w.depth_flat,
+              (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, B, PU, H);
+    P5_TRY(P5_KCHECK());
+    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.sa.o), y, d, rows, d, in, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+    // cross-attention: the user's PU rows are PU queries against the user's encoder keys (zero position bias, padding mask)
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ca.ln, rows, d, c.eps, no_drop()));
+    P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.ca.q), w.q, in, rows, in, d));
+    P5AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = w.q; a.K = (const T*)w.kv_all + (size_t)i * 2 * in; a.V = (const T*)w.kv_all + (size_t)i * 2 * in + in; a.O = w.o; a.lse = w.lse;
+    a.rel_table = nullptr; a.bucket_lut = nullptr; a.kmask = e->mask;
+    a.B = B; a.H = H; a.Lq = PU; a.Lk = v.L; a.ldq = in; a.ldk = a.ldv = ldkv; a.ldo = in; a.causal = 0;
+    a.drop = no_drop();
+    P5_TRY(launch_attn_fwd<T>(a, s));
+    P5_TRY(linear_fwd<T>(s, w.o, in, Wc<T>(e, lo.ca.o), y, d, rows, d, in, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+    // feed-forward
+    P5_TRY(rmsnorm_fwd<T>(s, w.n, nullptr, x, e->P + lo.ff_ln, rows, d, c.eps, no_drop()));
+    if (c.gated_gelu) {
+      T* u = (T*)w.h + (size_t)rows * F;
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), u, 2 * F, rows, 2 * F, d));
+      const size_t n = (size_t)rows * F;
+      P5_LAUNCH((p5_gated_gelu_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, (T*)w.h, (const T*)u, rows, F, no_drop());
+      P5_TRY(P5_KCHECK());
+    } else {
+      P5_TRY(linear_fwd<T>(s, w.n, d, Wc<T>(e, lo.wi), w.h, F, rows, F, d, P5_EPI_RELU_DROP));
+    }
+    P5_TRY(linear_fwd<T>(s, w.h, F, Wc<T>(e, lo.wo), y, d, rows, d, F, P5_EPI_RESID_DROP, x, d));
+    std::swap(x, y);
+  }
+  P5_TRY(rmsnorm_fwd<T>(s, w.hn, nullptr, x, e->P + e->off_dec_fln, rows, d, c.eps, no_drop()));
+  // log-sum-exp over the full vocabulary per row + the log-probabilities of the row's trie children (running score 0)
+  hipMemsetAsync(w.zeros, 0, (size_t)rows * 4, s);
+  const float alpha = 1.0f / sqrtf((float)d);
+  const uint32_t* excl = v.excl_words > 0 ? excluded : nullptr;
+  // (with split products the tied head is one throughput GEMM into materialised logits: the streaming head multiplies on exact-fp32 MFMAs)
+  if (head_nv(e) > 0 && !(sizeof(T) == 4 && g_opt_verify_split)) {
+    P5_TRY(launch_head_lse<T>(e, w.part_m, w.part_s, w.hn, rows, nullptr, s));
+    const int nv = head_nv(e), nt = (c.vocab_size + nv - 1) / nv;
+    P5_LAUNCH((p5_dec_score2_kernel<T>), dim3(rows), dim3(256), 0, s, w.row_top_score, w.row_top_c, w.n_top, w.cand, (const float*)w.part_m,
+              (const float*)w.part_s, nt, (const T*)w.hn, Wc<T>(e, e->off_E), d, alpha, (const int*)w.node_flat, (const float*)w.zeros, v.child_off,
+              v.child_tok, v.child_node, excl, v.excl_words, PU, v.max_c, 2 * K, (const int*)nullptr);
+  } else {
+    P5_TRY(linear_fwd<T>(s, w.hn, d, Wc<T>(e, e->off_E), w.logits, Vp, rows, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, alpha, 1));
+    P5_LAUNCH(p5_dec_score_kernel, dim3(rows), dim3(256), 0, s, w.cand, w.row_top_score, w.row_top_c, w.n_top, (const float*)w.logits, Vp, c.vocab_size,
+              (const int*)w.node_flat, (const float*)w.zeros, v.child_off, v.child_tok, v.child_node, excl, v.excl_words, PU, v.max_c, 2 * K,
+              (const int*)nullptr);
+  }
+  P5_TRY(P5_KCHECK());
+  // REPLAY with the real beam width
+  P5_LAUNCH(p5_beam_init_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, v.child_off, v.child_tok, v.child_node, v.roots, B, K, max_len,
+            c.pad_id);
+  P5_TRY(P5_KCHECK());
+  hipMemsetAsync(w.vrow_a, 0, (size_t)R * 4, s);        // every beam starts on row 0 (the start prefix)
+  hipMemsetAsync(w.missing, 0, (size_t)B * 4, s);
+  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
+    P5_LAUNCH(p5_verify_step_kernel, dim3(B), dim3(256), 0, s, w.st, w.pl, (const float*)w.row_top_score, (const int*)w.row_top_c, (const int*)w.n_top, PU,
+              v.child_off, v.child_tok, v.child_node, excl, v.excl_words, v.max_c, K, max_len, c.eos_id, R, w.vrow_a, w.vrow_b, w.missing);
+    P5_TRY(P5_KCHECK());
+  }
+  P5_LAUNCH(p5_beam_finalize_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, out_seq, out_score, out_len, w.st, R, max_len);
+  P5_TRY(P5_KCHECK());
+  hipMemcpyAsync(out_missing, w.missing, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
+  v.stage = 0;
   return 0;
 }
 
@@ -1616,6 +1819,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_cross")) g_opt_dec_cross = value;
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
+  else if (!strcmp(name, "verify_split")) g_opt_verify_split = value;
   else if (!strcmp(name, "wgrad_group")) g_opt_wgrad_group = value;
   else if (!strcmp(name, "norm_fuse")) g_opt_norm_fuse = value;
   else if (!strcmp(name, "wgrad_wgs")) g_opt_wgrad_wgs = value;
@@ -1636,7 +1840,7 @@ int p5_set_option(const char* name, int value) {
   else return fail("p5_set_option: unknown option");
   return 0;
 }
-int p5_abi_version(void) { return 1; }
+int p5_abi_version(void) { return 3; }    // 2: p5_op_attn_bwd gained d_rel_scratch / rel_buckets (round 4); 3: p5_generate_verified, p5_backward_staged (round 5)
 // ---- in-run kernel profiler (p5_device.h P5Prof) ----
 int p5_profile_begin(void) {
 #ifndef P5_EMU
@@ -1651,12 +1855,15 @@ int p5_profile_end(char* report, int cap) {
   P5Prof& p = p5_prof();
   p.on = 0;
   if (p.recs.empty()) return 0;
-  if (hipEventSynchronize(p.recs.back().b) != hipSuccess) return fail("profile: event sync failed");
+  // records are made on every stream the library launches on (main, side, weight-gradient): wait for all of them, and refuse to report
+  // a table with holes in it
+  if (hipDeviceSynchronize() != hipSuccess) return fail("profile: device sync failed");
+  int dropped = 0;
   struct Agg { std::string key; int n; double us, flops; };
   std::vector<Agg> agg;
   for (const P5Prof::Rec& r : p.recs) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { ++dropped; continue; }
     char k[512];
     char shp[64] = "";
     if (r.m > 0) snprintf(shp, sizeof(shp), " %dx%dx%d", r.m, r.n, r.k);
@@ -1675,6 +1882,7 @@ int p5_profile_end(char* report, int cap) {
     out += b;
   }
   out += "]";
+  if (dropped) { p.recs.clear(); (void)hipGetLastError(); return fail("profile: " + std::to_string(dropped) + " launch records could not be read"); }
   if (report && cap > 0) {
     if ((int)out.size() + 1 > cap) return fail("profile: report buffer too small");
     memcpy(report, out.c_str(), out.size() + 1);
@@ -1706,7 +1914,7 @@ int p5_engine_create(const P5Config* cfg, P5Engine** out) {
   *out = e;
   return 0;
 }
-int p5_engine_destroy(P5Engine* e) { delete e; return 0; }
+int p5_engine_destroy(P5Engine* e) { if (e) delete e->ver; delete e; return 0; }
 int64_t p5_param_count(const P5Engine* e) { return e->n_params; }
 int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols) {
   if (idx < 0 || idx >= (int)e->table.size()) return 1;
@@ -1997,6 +2205,49 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
 #endif
   return p5_decode_finish(e, out_seq, out_score, out_len, stream);
 }
+int64_t p5_generate_history_count(int B, int K, int max_len) { return 4 + (int64_t)max_len * P5_HIST_FIELDS * B * K; }
+int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,
+                      int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
+                      const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, int* hist,
+                      void* ws, int64_t ws_bytes, void* stream) {
+  P5_REQUIRE(hist, "p5_generate_draft: history buffer");
+  e->gen_hist_next = hist;
+  const int rc = p5_generate(e, input_ids, whole_word_ids, attention_mask, B, L, K, max_len, child_off, child_tok, child_node, roots, excluded_nodes,
+                             excluded_words, max_children, out_seq, out_score, out_len, ws, ws_bytes, stream);
+  e->gen_hist_next = nullptr;
+  return rc;
+}
+int64_t p5_verify_workspace_bytes(const P5Engine* e, int B, int L, int K, int Kw, int max_len, int max_children, int excluded_words) {
+  return layout_verify(const_cast<P5Engine*>(e), nullptr, B, L, K, Kw, max_len, max_children, excluded_words, nullptr);
+}
+int p5_verify_plan(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
+                   const int* child_node, const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes, void* stream) {
+  P5_REQUIRE(e->P, "engine not bound");
+  P5_REQUIRE(hist, "p5_verify_plan: history of the draft search");
+  P5_REQUIRE(K >= 1 && 2 * K * K <= P5_VERIFY_POOL, "verified generation: 1 <= num_beams <= 22");
+  P5_REQUIRE(Kw >= K && Kw <= P5_MAX_K, "draft beam width: num_beams <= Kw <= 64");
+  P5_REQUIRE(max_len >= 2 && max_len <= P5_MAX_LEN, "2 <= max_length <= 128 (P5_MAX_LEN)");
+  P5_REQUIRE(L >= 1 && L <= 512, "1 <= L <= 512");
+  P5_REQUIRE(max_children >= 1 && excluded_words >= 0, "max_children / excluded_words");
+  P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");
+  const int64_t need = layout_verify(e, nullptr, B, L, K, Kw, max_len, max_children, excluded_words, nullptr);
+  P5_REQUIRE(ws_bytes >= need, "workspace too small");
+  return verify_plan_impl(e, hist, B, L, K, Kw, max_len, child_off, child_tok, child_node, roots, max_children, excluded_words, (char*)ws, (hipStream_t)stream);
+}
+const int* p5_verify_plan_header(const P5Engine* e) { return (e->ver && e->ver->stage >= 1) ? e->ver->w.pl.hdr : nullptr; }
+int p5_verify_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, void* stream) {
+  P5_REQUIRE(e->ver && e->ver->stage == 1, "p5_verify_encode without p5_verify_plan");
+  return e->c.dtype == 1 ? verify_encode_impl<bf16>(e, input_ids, whole_word_ids, attention_mask, (hipStream_t)stream)
+                         : verify_encode_impl<float>(e, input_ids, whole_word_ids, attention_mask, (hipStream_t)stream);
+}
+int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len, int* out_missing,
+                  void* stream) {
+  P5_REQUIRE(e->ver && e->ver->stage == 2, "p5_verify_run without p5_verify_plan + p5_verify_encode");
+  P5_REQUIRE(rows_per_user >= 1 && rows_per_user <= e->ver->w.pl.cap, "rows_per_user: 1 .. capacity of the plan");
+  P5_REQUIRE(e->ver->excl_words == 0 || excluded_nodes, "excluded_nodes");
+  return e->c.dtype == 1 ? verify_run_impl<bf16>(e, rows_per_user, excluded_nodes, out_seq, out_score, out_len, out_missing, (hipStream_t)stream)
+                         : verify_run_impl<float>(e, rows_per_user, excluded_nodes, out_seq, out_score, out_len, out_missing, (hipStream_t)stream);
+}
 int p5_generate_timing(P5Engine* e, int enable, float* encode_ms, float* decode_ms) {
 #ifndef P5_EMU
   if (encode_ms || decode_ms) {
@@ -2041,6 +2292,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
   P5GemmArgs g;
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = a_ks; g.b_ks = b_ks; g.epi = epi; g.c_f32 = c_f32; g.splitk = splitk; g.ring = 0; g.alpha = alpha; g.drop = op_drop(rng_state, site, drop_p);
+  g.mm_split = (dtype == 2) ? 1 : 0;      // dtype 2 (tests): fp32 operands, split-f16 products
   g.rowss = nullptr; g.rowss_invd = 0.f; g.rowss_eps = 0.f; g.ssq_out = nullptr; g.rowss_nt = 0; g.ssq_nt = 0; g.c_split_stride = 0;
   g.g4_tiles_n = 0; g.g4_nk = 0; g.xcd_bm = g.xcd_bn = 0;
   return dtype == 1 ? launch_gemm<bf16>(g, (hipStream_t)stream) : launch_gemm<float>(g, (hipStream_t)stream);
@@ -2057,6 +2309,7 @@ int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs
     g.A = q.A; g.B = q.B; g.C = q.C; g.aux = q.aux; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldaux = q.ldaux;
     g.a_ks = ks; g.b_ks = ks; g.epi = q.epi; g.c_f32 = q.c_f32; g.splitk = q.splitk; g.alpha = q.alpha; g.drop = op_drop(rng_state, site, drop_p);
     g.rowss = q.rowss; g.rowss_invd = q.rowss ? 1.0f / (float)q.K : 0.f; g.rowss_eps = q.rowss_eps; g.ssq_out = q.ssq_out;
+    g.rowss_nt = q.rowss_nt; g.ssq_nt = q.ssq_nt;
   }
   return launch_gemm4(tile_cfg, ks != 0, grp, (hipStream_t)stream);
 }

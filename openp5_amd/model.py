@@ -126,6 +126,11 @@ class P5T5Native(nn.Module):
     use_side_stream = False
     use_transposed_weights = True     # bf16: keep W^T of the layer weights for the data gradients (p5_engine_bind_transposed)
     fuse_decode_norms = True      # generate(): fold the decoder RMSNorms into the GEMMs around them
+    # generate() of a bf16 model: "verified" = the bf16 search (with `verify_extra_beams` more beams) proposes, one fp32 pass decides -- the
+    # returned lists and scores are the fp32 search's (include/p5hip.h, csrc/p5_verify.h); "draft" = the plain bf16 search.  An fp32 model
+    # always runs the plain (fp32) search.
+    generation_mode = "verified"
+    verify_extra_beams = 6
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
         super().__init__()
@@ -155,7 +160,10 @@ class P5T5Native(nn.Module):
         self._side = None
         self._comm = None
         self._fold = None
-        self._fold_dirty = True
+        self._fold_dirty = self._fold_v_dirty = True
+        self._engine_v = None       # fp32 engine over the same master arena (verified generation)
+        self._fold_v, self._fold_v_dirty, self._ver_ws, self._gen_ws_v, self._ver_hdr, self._ver_ev = None, True, None, None, None, None
+        self.verify_stats = {"calls": 0, "users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0}
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
         self._grads_dead = False    # zero_grad(set_to_none=True) was called and no backward has run since: `.grad` holds stale values
         self._tr_dirty = True
@@ -179,6 +187,9 @@ class P5T5Native(nn.Module):
             self._lib.p5_engine_destroy(self._engine)
         self._engine = ctypes.c_void_p()
         self._fold, self._fold_dirty = None, True       # sized by (and bound to) the engine
+        if getattr(self, "_engine_v", None):            # the verification engine is bound to the old arena: rebuilt on demand
+            self._lib.p5_engine_destroy(self._engine_v)
+        self._engine_v, self._fold_v, self._fold_v_dirty = None, None, True
         cfg = self._cfg_struct()
         self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine)), "p5_engine_create")
         table = []
@@ -217,7 +228,7 @@ class P5T5Native(nn.Module):
             self._copy_in(old_state, strict=False)
         self._bind()
         self._shadow_dirty = True
-        self._fold_dirty = True
+        self._fold_dirty = self._fold_v_dirty = True
 
     def _register_dotted(self, name, p):
         parts = name.split(".")
@@ -282,7 +293,7 @@ class P5T5Native(nn.Module):
             n = int(self._lib.p5_decode_fold_count(self._engine))
             self._fold = torch.empty(n, dtype=torch.bfloat16 if self.compute_dtype == 1 else torch.float32, device=self._flat.device)
             self._be.check(self._lib.p5_engine_bind_decode_fold(self._engine, _ptr(self._fold)), "p5_engine_bind_decode_fold")
-            self._fold_dirty = True
+            self._fold_dirty = self._fold_v_dirty = True
         if self._fold_dirty:
             self._be.check(self._lib.p5_refresh_decode_fold(self._engine, self._be.stream_ptr()), "p5_refresh_decode_fold")
             self._fold_dirty = False
@@ -290,7 +301,7 @@ class P5T5Native(nn.Module):
     def mark_params_updated(self, shadow_fresh: bool = False):
         """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
         self._shadow_dirty = not shadow_fresh
-        self._fold_dirty = True
+        self._fold_dirty = self._fold_v_dirty = True
         self._tr_dirty = True
 
     def _sync_transposed(self):
@@ -348,7 +359,7 @@ class P5T5Native(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing={missing} unexpected={unexpected}")
         self._shadow_dirty = True
-        self._fold_dirty = True
+        self._fold_dirty = self._fold_v_dirty = True
         self._tr_dirty = True
         return missing, unexpected
 
@@ -399,7 +410,7 @@ class P5T5Native(nn.Module):
         n = min(old, new_num_tokens)
         self.shared.weight[:n].copy_(old_E[:n])
         self._shadow_dirty = True
-        self._fold_dirty = True
+        self._fold_dirty = self._fold_v_dirty = True
         return self.shared
 
     def get_input_embeddings(self):
@@ -417,9 +428,10 @@ class P5T5Native(nn.Module):
         backward, where torch would show None.  set_to_none=False: the arena is cleared now."""
         if set_to_none:
             self._be.check(self._lib.p5_engine_discard_grads(self._engine), "discard_grads")
-            self._grads_dead = True         # (FusedAdamW.step refuses to apply them again before a backward has rewritten them)
+            self._grads_dead = True         # (FusedAdamW.step skips the update until a backward has rewritten them, as torch skips grad=None)
         else:
             self._be.check(self._lib.p5_engine_clear_grads(self._engine, self._be.stream_ptr()), "clear_grads")
+            self._grads_dead = False        # real zeros: a step would apply them (weight decay only), as torch does
 
     def tie_weights(self):
         return None
@@ -636,19 +648,110 @@ class P5T5Native(nn.Module):
         # enqueue exactly as many decode steps as can do work.  (With max_length == depth the forced finish at max_length
         # coincides with the leaves' </s>, so results are those of the unbounded call.)
         max_length = max(2, min(int(max_length), int(trie.max_depth)))
-        ws = self._workspace(self._lib.p5_generate_workspace_bytes(self._engine, B, L, K, max_length, maxc, excl_words), "_gen_ws")
-        seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
-        score = torch.zeros(B, K, dtype=torch.float32, device=dev)
-        ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
-        self._be.check(self._lib.p5_generate(self._engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), B, L, K, max_length,
-                                             _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), _ptr(excl_t), excl_words, maxc, _ptr(seq), _ptr(score), _ptr(ln), _ptr(ws),
-                                             ws.numel(), self._be.stream_ptr()), "p5_generate")
+        mode = unused.get("generation_mode", self.generation_mode)
+        if mode not in ("verified", "draft"):
+            raise ValueError(f"generation_mode={mode!r} (verified | draft)")
+        args = (input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc)
+        if self.compute_dtype == 1 and mode == "verified" and 2 * K * K <= 1024:
+            seq, score, ln = self._generate_verified(*args)
+        else:
+            seq, score, ln = self._search(self._engine, "_gen_ws", *args)
         out_len = 1 + int(ln[:, :nret].max().item())
         sequences = seq[:, :nret, :out_len].reshape(B * nret, out_len).to(torch.int64)
         scores = score[:, :nret].reshape(B * nret)
         if return_dict_in_generate:
             return {"sequences": sequences, "sequences_scores": scores if output_scores else None}
         return sequences
+
+    def _search(self, engine, ws_attr, input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words,
+                maxc, hist=None):
+        """One device beam search on `engine` (p5_generate; with `hist`, p5_generate_draft records what the search kept alive)."""
+        dev = self._be.device
+        ws = self._workspace(self._lib.p5_generate_workspace_bytes(engine, B, L, K, max_length, maxc, excl_words), ws_attr)
+        seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
+        score = torch.zeros(B, K, dtype=torch.float32, device=dev)
+        ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        if hist is None:
+            self._be.check(self._lib.p5_generate(engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), B, L, K, max_length,
+                                                 _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), _ptr(excl_t), excl_words, maxc, _ptr(seq), _ptr(score), _ptr(ln),
+                                                 _ptr(ws), ws.numel(), self._be.stream_ptr()), "p5_generate")
+        else:
+            self._be.check(self._lib.p5_generate_draft(engine, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), B, L, K, max_length,
+                                                       _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), _ptr(excl_t), excl_words, maxc, _ptr(seq), _ptr(score),
+                                                       _ptr(ln), _ptr(hist), _ptr(ws), ws.numel(), self._be.stream_ptr()), "p5_generate_draft")
+        return seq, score, ln
+
+    # ------------------------------------------------------------------ verified generation (bf16 drafts, fp32 decides)
+    def _verify_engine(self):
+        """fp32 engine over the SAME master parameter arena (no copy of the weights; its kernels read `_flat` directly)."""
+        if not self._engine_v:
+            cfg = self._cfg_struct()
+            cfg.dtype = 0
+            self._engine_v = ctypes.c_void_p()
+            self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine_v)), "p5_engine_create (verify)")
+            self._be.check(self._lib.p5_engine_bind(self._engine_v, _ptr(self._flat), _ptr(self._grads), None, _ptr(self._lut_enc), _ptr(self._lut_dec),
+                                                     self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind (verify)")
+        return self._engine_v
+
+    def _generate_verified(self, input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc):
+        """include/p5hip.h "verified generation": the bf16 search with `verify_extra_beams` more beams proposes, ONE teacher-forced fp32
+        pass over the distinct prefixes it kept alive scores them, and HF's beam search of the real width is replayed on those fp32 numbers.
+        Users whose replay needed a prefix the draft had dropped are re-run through the plain fp32 search (counted in `verify_stats`)."""
+        lib, dev, sp = self._lib, self._be.device, self._be.stream_ptr()
+        Kw = min(64, K + max(0, int(self.verify_extra_beams)))
+        ev = self._verify_engine()
+        common = (input_ids, whole_word_ids, attention_mask, B, L)
+        trie_args = (off, tok, nxt, roots_t, excl_t, excl_words, maxc)
+        hist = torch.zeros(int(lib.p5_generate_history_count(B, Kw, max_length)), dtype=torch.int32, device=dev)
+        self._search(self._engine, "_gen_ws", *common, Kw, max_length, *trie_args, hist=hist)
+        ws = self._workspace(lib.p5_verify_workspace_bytes(ev, B, L, K, Kw, max_length, maxc, excl_words), "_ver_ws")
+        self._be.check(lib.p5_verify_plan(ev, _ptr(hist), B, L, K, Kw, max_length, _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, excl_words,
+                                          _ptr(ws), ws.numel(), sp), "p5_verify_plan")
+        hdr_off = int(lib.p5_verify_plan_header(ev)) - ws.data_ptr()
+        hdr_dev = ws[hdr_off:hdr_off + 16].view(torch.int32)
+        if ws.is_cuda:
+            # the ONE number the host needs (rows per user) travels while the fp32 encoder pass runs
+            if self._ver_hdr is None:
+                self._ver_hdr = torch.zeros(4, dtype=torch.int32).pin_memory()
+                self._ver_ev = torch.cuda.Event()
+            self._ver_hdr.copy_(hdr_dev, non_blocking=True)
+            self._ver_ev.record()
+        self._be.check(lib.p5_verify_encode(ev, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), sp), "p5_verify_encode")
+        if ws.is_cuda:
+            self._ver_ev.synchronize()
+            hdr = self._ver_hdr.tolist()
+        else:
+            hdr = hdr_dev.cpu().tolist()
+        if hdr[3]:
+            raise RuntimeError("p5_verify_plan: row capacity exceeded")
+        PU = max(16, (int(hdr[0]) + 15) // 16 * 16)
+        seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
+        score = torch.zeros(B, K, dtype=torch.float32, device=dev)
+        ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        missing = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._be.check(lib.p5_verify_run(ev, PU, _ptr(excl_t), _ptr(seq), _ptr(score), _ptr(ln), _ptr(missing), sp), "p5_verify_run")
+        st = self.verify_stats
+        st["calls"] += 1; st["users"] += B; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
+        st["draft_beams"] = Kw
+        miss = missing.nonzero().flatten()
+        if miss.numel():
+            # the fp32 search itself for these users (rare: a prefix the fp32 search ranks among its K was not among the draft's Kw)
+            st["fallback_users"] += int(miss.numel())
+            if self.fuse_decode_norms:
+                if self._fold_v is None:
+                    n = int(lib.p5_decode_fold_count(ev))
+                    self._fold_v = torch.empty(n, dtype=torch.float32, device=dev)
+                    self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(self._fold_v)), "p5_engine_bind_decode_fold (verify)")
+                    self._fold_v_dirty = True
+                if self._fold_v_dirty:
+                    self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
+                    self._fold_v_dirty = False
+            sub = lambda t: None if t is None else t[miss].contiguous()     # noqa: E731
+            nb = int(miss.numel())
+            s2, sc2, l2 = self._search(ev, "_gen_ws_v", sub(input_ids), sub(whole_word_ids), sub(attention_mask), nb, L, K, max_length, off, tok, nxt,
+                                       sub(roots_t), sub(excl_t), excl_words, maxc)
+            seq[miss] = s2; score[miss] = sc2; ln[miss] = l2
+        return seq, score, ln
 
     def time_generate(self, enable: bool = True):
         """Benchmark aid: arm (or disarm) the engine's device-time brackets around the next `generate` calls (two event records per
@@ -694,5 +797,7 @@ class P5T5Native(nn.Module):
         try:
             if self._engine:
                 self._lib.p5_engine_destroy(self._engine)
+            if getattr(self, "_engine_v", None):
+                self._lib.p5_engine_destroy(self._engine_v)
         except Exception:
             pass

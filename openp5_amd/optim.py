@@ -43,9 +43,11 @@ class FusedAdamW:
         mean is taken by the update kernel's gradient scale."""
         mdl = self.model
         if getattr(mdl, "_grads_dead", False):
-            # zero_grad() only marks the gradient arena dead (model.zero_grad docstring); torch would hold p.grad = None here and skip
-            # every parameter -- re-applying the previous step's gradients instead would be a silent error
-            raise RuntimeError("FusedAdamW.step(): the gradients were discarded by zero_grad() and no backward has run since")
+            # zero_grad() only marks the gradient arena dead (model.zero_grad docstring).  torch holds p.grad = None here and its AdamW
+            # skips every such parameter (no update, no moment change, no per-parameter step count); the reference loop still calls
+            # scheduler.step() (DistributedRunner.py:85-86).  Same here: the dead arena is never re-applied.
+            self.sched_steps += 1
+            return
         be, lib = mdl._be, mdl._lib
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         sp = be.stream_ptr()

@@ -76,9 +76,40 @@ def gemm_case(be, dtype, M, N, K, a_ks, b_ks, epi=0, c_f32=0, splitk=1, seed=0):
     return err
 
 
-def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0):
+def gemm_split_case(be, M, N, K, epi=0, seed=0, scale_a=1.0, scale_b=0.05):
+    """fp32 operands with the products on the f16 matrix cores (p5_gemm.h, two-term split; dtype code 2 of p5_op_gemm) against an fp64
+    product: the error must be of the order of an fp32 GEMM's own (a few 2^-22 relative per product), nowhere near fp16's or bf16's."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g) * scale_a
+    Bm = torch.randn(N, K, generator=g) * scale_b
+    A[0, :4] = torch.tensor([3.0e-6, -7.0e-5, 1.0e3, -2.5e4][:min(4, K)])      # tiny (lo becomes subnormal) and large magnitudes
+    ref = (A.double() @ Bm.double().t())
+    aux = None
+    if epi == 1:
+        ref = torch.relu(ref)
+    elif epi == 2:
+        aux = torch.randn(M, N, generator=g)
+        ref = ref + aux.double()
+    Ad, Bd, Cd = dev(be, A), dev(be, Bm), dev(be, torch.zeros(M, N))
+    auxd = dev(be, aux) if aux is not None else None
+    out = {}
+    for dtype in (0, 2):
+        be.check(be.lib.p5_op_gemm(dtype, P(Ad), P(Bd), P(Cd), P(auxd), M, N, K, K, K, N, N, 0, 0, epi, 1, 1, 1.0, None, 0, 0.0, be.stream_ptr()), "gemm")
+        sync(be)
+        out[dtype] = Cd.cpu().double()
+    scale = (A.double().abs() @ Bm.double().abs().t()).clamp(min=1e-30)          # sum of |products|: the natural error scale of a dot product
+    e32 = ((out[0] - ref).abs() / scale).max().item()
+    esp = ((out[2] - ref).abs() / scale).max().item()
+    # (both accumulate in fp32: ~sqrt(K) 2^-24 of the sum of |products|; the split adds ~2^-22 per product for the dropped lo.lo term)
+    assert esp <= 2 * e32 + 3e-7, f"split-f16 GEMM {M}x{N}x{K}: error {esp:.2e} of the sum of |products| (exact-fp32 kernel: {e32:.2e})"
+    return e32, esp
+
+
+def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0, stats_nt=0):
     """persistent ring GEMM (p5_gemm4.h): a GROUP of bf16 problems in one launch.  probs: list of (M, N, K, epi, c_f32, splitk).
-    Every epilogue against plain torch; accumulate epilogues (4 atomic, 6 C +=) start from a random C."""
+    Every epilogue against plain torch; accumulate epilogues (4 atomic, 6 C +=) start from a random C.
+    stats_nt > 0 (K-contiguous, bf16 outputs): the training step's folded T5LayerNorm -- A rows are scaled by rsqrt(mean(x^2) + eps)
+    from `stats_nt` partial sums of squares per row, and the output rows leave their own partial sums per 64 columns."""
     from openp5_amd._abi import P5GemmProblem
     g = torch.Generator().manual_seed(seed)
     tt = torch.bfloat16
@@ -122,7 +153,34 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0)
         q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux = M, N, K, A_.shape[1], B_.shape[1], N, N
         q.epi, q.c_f32, q.splitk, q.alpha = epi, c_f32, splitk, alpha
         q.rowss, q.rowss_eps, q.ssq_out = None, 0.0, None
-        checks.append((Cd, ref, c_f32, K, (M, N, K, epi)))
+        q.rowss_nt = q.ssq_nt = 0
+        ssq_d = None
+        if stats_nt > 0 and not ks and not c_f32 and epi in (0, 1, 2, 3):
+            part = (torch.rand(M, stats_nt, generator=g) * (2.0 * K / stats_nt)).float()
+            eps = 1e-6
+            ssum = torch.zeros(M)
+            for t in range(stats_nt):            # index order, as the kernels sum them
+                ssum = ssum + part[:, t]
+            rstd = torch.rsqrt(ssum / K + eps)
+            pre = (A.float() @ Bm.float().t()) * rstd[:, None] * alpha
+            if epi == 1:
+                pre = torch.relu(pre)
+                if keepm is not None:
+                    pre = torch.where(keepm, pre / (1 - drop_p), torch.zeros_like(pre))
+            elif epi == 2:
+                if keepm is not None:
+                    pre = torch.where(keepm, pre / (1 - drop_p), torch.zeros_like(pre))
+                pre = pre + aux.float()
+            elif epi == 3:
+                pre = torch.where(aux.float() > 0, pre, torch.zeros_like(pre))
+            ref = pre
+            partd = dev(be, part)
+            nt_out = (N + 63) // 64
+            ssq_d = dev(be, torch.full((M, nt_out), float("nan")))
+            keep += [partd, ssq_d]
+            q.rowss, q.rowss_eps, q.rowss_nt = partd.data_ptr(), eps, stats_nt
+            q.ssq_out, q.ssq_nt = ssq_d.data_ptr(), nt_out
+        checks.append((Cd, ref, c_f32, K, (M, N, K, epi), ssq_d))
     lib = be.lib
     try:
         be.check(lib.p5_set_option(b"g4_nst", nst), "opt")
@@ -133,12 +191,17 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0)
         lib.p5_set_option(b"g4_nst", 3)
         lib.p5_set_option(b"g4_wgs", 256)
     worst = 0.0
-    for Cd, ref, c_f32, K, tag in checks:
+    for Cd, ref, c_f32, K, tag, ssq_d in checks:
         got = Cd.cpu().float()
         tol = 1e-3 * max(1.0, K ** 0.5) if c_f32 else 2e-2 * max(1.0, float(ref.abs().max()))
         err = (got - ref).abs().max().item()
         assert err <= tol, f"gemm_group cfg={tile_cfg} ks={ks} {tag}: err {err} > {tol}"
         worst = max(worst, err / tol)
+        if ssq_d is not None:            # the output rows' partial sums of squares: of the bf16 values actually stored, per 64 columns
+            N = got.shape[1]
+            want = torch.stack([(got[:, c:c + 64] ** 2).sum(1) for c in range(0, N, 64)], 1)
+            e2 = ((ssq_d.cpu() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+            assert e2 <= 1e-4, f"gemm_group {tag}: output row statistics off by {e2}"
     return worst
 
 
@@ -525,10 +588,27 @@ def make_items(n_items, seed, lo=7, hi=40, prefix=(0, 5, 6), minlen=2, maxlen=4)
     return sorted(list(x) for x in items)
 
 
-def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours", id_len=(2, 4)):
+def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours", id_len=(2, 4), mode=None, extra_beams=None,
+                  sabotage=None):
+    """mode (bf16 models): "verified" = the bf16 search proposes, the fp32 pass decides (csrc/p5_verify.h) -- held to the fp32 tolerances;
+    "draft" = the plain bf16 search; None = the model's default.  sabotage(hist): test hook, edits the draft's recorded history before the
+    verification pass reads it (to force the flagged-user fallback)."""
     params = O.init_params(ocfg, 7)
     m = build_model(be, ocfg, params, dtype)
     m.eval()
+    if mode is not None:
+        m.generation_mode = mode
+    if extra_beams is not None:
+        m.verify_extra_beams = extra_beams
+    if sabotage is not None:
+        plain = m._search
+        def _search(engine, ws_attr, *a, hist=None):
+            r = plain(engine, ws_attr, *a, hist=hist)
+            if hist is not None:
+                sabotage(hist, a[3], a[5])      # (B, K of the draft)
+            return r
+        m._search = _search
+    verified = dtype == "bf16" and m.generation_mode == "verified"
     ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
     items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1), minlen=id_len[0], maxlen=id_len[1])
     trie = Trie(items)
@@ -552,17 +632,21 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
                      num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True)
     with torch.no_grad():
         s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, max_len)
-    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol, tie_tol=0.05 if dtype == "bf16" else 0.0, K=K)
+    compare_generation(out["sequences"].cpu(), out["sequences_scores"].cpu(), s_ref, sc_ref, score_tol,
+                       tie_tol=0.05 if (dtype == "bf16" and not verified) else 0.0, K=K)
+    out["verify_stats"] = dict(m.verify_stats)
     return out
 
 
-def generate_excluded_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, frac=0.4):
+def generate_excluded_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, frac=0.4, mode=None):
     """Per-user history exclusion (DistributedRunner.py:286-297): the shared device trie + one excluded-node bitmap per user
     must rank exactly like the reference protocol's per-user Trie(all_items - positive)."""
     from openp5_amd.trie import CompiledTrie
     params = O.init_params(ocfg, 7)
     m = build_model(be, ocfg, params, dtype)
     m.eval()
+    if mode is not None:
+        m.generation_mode = mode
     ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
     items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
     ct = CompiledTrie.from_sequences(items)

@@ -68,6 +68,13 @@ def test_gemm_persistent_ring_wgrad_256x128(emu):
     cases.gemm_group_case(emu, 1, 1, probs, wgs=8)
 
 
+@pytest.mark.parametrize("shape", [(70, 100, 96, 0), (130, 64, 40, 1), (64, 200, 512, 2)])
+def test_gemm_fp32_split_products(emu, shape):
+    """fp32 GEMM with its products on the f16 matrix cores (verification pass): ragged shapes, K not a multiple of 32, every fp32 epilogue."""
+    M, N, K, epi = shape
+    cases.gemm_split_case(emu, M, N, K, epi)
+
+
 @pytest.mark.parametrize("wgs", [8, 256])
 def test_gemm_wave_specialised(emu, wgs):
     """p5_gemm5.h (four loader waves + four compute waves on 128x64 wave tiles), K-contiguous: grouped problems, units crossing
@@ -78,6 +85,10 @@ def test_gemm_wave_specialised(emu, wgs):
     whole_tiles = [(512, 256, 128, 1, 0, 1), (256, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (512, 128, 128, 0, 0, 1), (300, 256, 64, 2, 0, 1),
                    (512, 300, 128, 0, 1, 1)]        # (fp32 store: whole tiles straight from the accumulators -- the tied head's logits -- next to a ragged one)
     cases.gemm_group_case(emu, 3, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=1)      # (the descriptor-hoisted epilogue of whole tiles)
+    # the folded T5LayerNorm of the training step: row scales from 8 / 12 partial sums (every load of a tile issued before its first
+    # store, round 5), output partial sums per 64 columns; whole tiles next to a ragged one
+    for nt in (8, 12, 3):
+        cases.gemm_group_case(emu, 3, 0, whole_tiles[:4] + [(300, 200, 64, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=2, stats_nt=nt)
 
 
 def test_gemm_wave_specialised_wgrad(emu):
@@ -212,6 +223,42 @@ def test_generate_excluded_history(emu):
 def test_generate_few_items(emu):
     """fewer items than beams: junk (-1e9) hypotheses appear exactly as in HF."""
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 11, 6, 9, 7, seed=9, score_tol=1e4)
+
+
+@pytest.mark.parametrize("via", ["ours", "append"])
+def test_generate_verified(emu, via):
+    """bf16 model, generation_mode "verified" (csrc/p5_verify.h): the bf16 search with extra beams proposes, one teacher-forced fp32 pass over
+    the distinct prefixes decides -- ranked lists and scores are held to the FP32 tolerances against the oracle (token-exact, 2e-5), not to
+    the bf16 tie tolerance.  "append": a grafted (DAG) trie -- rows are keyed by path, not by node."""
+    out = cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="verified", via=via)
+    st = out["verify_stats"]
+    assert st["calls"] == 1 and st["users"] == 3 and st["draft_beams"] == 11 and 3 <= st["rows"] <= 3 * (11 * 11 + 1), st
+
+
+def test_generate_verified_gated_and_excluded(emu):
+    cases.generate_case(emu, O.T5Cfg.named("tiny", ff_act="gated-gelu"), 2, 12, 4, 10, 30, seed=11, dtype="bf16", mode="verified")
+    cases.generate_excluded_case(emu, O.T5Cfg.named("tiny"), 3, 14, 5, 12, 40, dtype="bf16", mode="verified")
+
+
+def test_generate_verified_few_items(emu):
+    """fewer items than beams: the dead (-1e9) hypotheses of HF come out of the replay exactly as out of the search (child-order ties)."""
+    cases.generate_case(emu, O.T5Cfg.named("tiny"), 2, 11, 6, 9, 7, seed=9, score_tol=1e4, dtype="bf16", mode="verified")
+
+
+def test_generate_verified_fallback(emu):
+    """A draft that dropped prefixes the fp32 search needs (here: sabotaged -- only its two best beams are reported alive) must be NOTICED:
+    the replay flags the users, they are re-run through the plain fp32 search, and the results are still the oracle's."""
+    def sabotage(hist, B, Kw):
+        R = B * Kw
+        h = hist[4:].view(-1, 4, R)
+        live = h[:, 3, :].view(-1, B, Kw)
+        live[:, :, 2:] = 0
+    out = cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="verified", sabotage=sabotage)
+    assert out["verify_stats"]["fallback_users"] >= 1, out["verify_stats"]
+
+
+def test_generate_draft_mode_is_the_plain_bf16_search(emu):
+    cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="draft", score_tol=0.05)
 
 
 def test_train_trajectory_fp32(emu):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_native_library_loaded(hip):
     assert hip.lib.p5_is_emulator() == 0
-    assert hip.lib.p5_abi_version() == 1
+    assert hip.lib.p5_abi_version() == 3
 
 
 def test_tr_probe(hip):
@@ -155,6 +155,36 @@ def test_generate_excluded_history(hip):
     cases.generate_excluded_case(hip, O.T5Cfg.named("t5-small"), 4, 48, 10, 12, 300, score_tol=1e-4, frac=0.7)
 
 
+@pytest.mark.parametrize("via", ["ours", "append"])
+def test_generate_verified(hip, via):
+    """bf16 model in its default generation mode (bf16 search with extra beams proposes, ONE teacher-forced fp32 pass decides,
+    csrc/p5_verify.h): token-exact ranked lists and fp32-tolerance scores against the oracle -- not the bf16 tie tolerance."""
+    out = cases.generate_case(hip, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="verified", via=via)
+    print("[verified tiny]", out["verify_stats"])      # (a toy model's bf16 and fp32 searches disagree often enough for an occasional flagged user)
+
+
+def test_generate_verified_t5_small(hip):
+    """T5-small dims (streaming tied head + per-row child scoring in the verification pass), beam 10, 300-item trie, incl. per-user history
+    exclusion: ranked item sequences identical to the CPU oracle, scores within 1e-4."""
+    out = cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4, dtype="bf16", mode="verified")
+    print("[verified t5-small]", out["verify_stats"])
+    cases.generate_excluded_case(hip, O.T5Cfg.named("t5-small"), 4, 48, 10, 12, 300, score_tol=1e-4, frac=0.7, dtype="bf16", mode="verified")
+
+
+def test_generate_verified_edge_cases(hip):
+    """fewer items than beams (dead -1e9 hypotheses replayed in HF's tie order), gated-gelu FFN, a sabotaged draft (flagged users fall back to
+    the fp32 search), no extra beams at all."""
+    cases.generate_case(hip, O.T5Cfg.named("tiny"), 2, 11, 6, 9, 7, seed=9, score_tol=1e4, dtype="bf16", mode="verified")
+    cases.generate_case(hip, O.T5Cfg.named("tiny", ff_act="gated-gelu"), 2, 12, 4, 10, 30, seed=11, dtype="bf16", mode="verified")
+
+    def sabotage(hist, B, Kw):
+        live = hist[4:].view(-1, 4, B * Kw)[:, 3, :].view(-1, B, Kw)
+        live[:, :, 2:] = 0
+    out = cases.generate_case(hip, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="verified", sabotage=sabotage)
+    assert out["verify_stats"]["fallback_users"] >= 1, out["verify_stats"]
+    cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4, dtype="bf16", mode="verified", extra_beams=0)
+
+
 def test_train_trajectory_fp32(hip):
     cases.train_trajectory_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6)
 
@@ -172,6 +202,7 @@ def test_generate_bf16_ranked_set(hip):
     params = O.init_params(ocfg, 7)
     m = cases.build_model(hip, ocfg, params, "bf16")
     m.eval()
+    m.generation_mode = "draft"          # the plain bf16 search (the default mode of a bf16 model is the fp32-verified one)
     ids, ww, mask, _, _ = cases.synth_batch(ocfg, 8, 64, 4, 5)
     items = cases.make_items(300, 5, hi=60)
     trie = Trie(items)
