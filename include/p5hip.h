@@ -146,6 +146,13 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
                 int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node,
                 const int* roots /* [B] empty-prefix node per batch item, or NULL = node 0 */,
                 const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len, void* ws, int64_t ws_bytes, void* stream);
+/* Forced-prefix fast-forward (openp5_amd/csrc/p5_decode.h): when the first n tokens after the decoder start token are the same for EVERY
+ * item of the trie (OpenP5 item ids all start with "<dataset> item _"), the first n beam-search steps have one allowed token each and
+ * are computed as ONE teacher-forced decoder pass over n positions per user instead of n decode steps -- same numbers, n - 1 steps saved.
+ * tokens[i] / nodes[i]: the i-th forced token and the trie node it leads to (HOST arrays, n <= 16).  One-shot: applies to the next
+ * p5_decode_begin / p5_generate / p5_generate_draft on this engine; ignored with per-item roots, n < 2, or option "gen_ff" = 0.
+ * The caller guarantees that the chain is really forced for every item of the batch (no excluded node on it). */
+int p5_generate_set_forced_prefix(P5Engine* e, const int* tokens, const int* nodes, int n);
 /* ---- verified generation: the bf16 search proposes, an fp32 pass decides (openp5_amd/csrc/p5_verify.h) ----
  * The reference ranks by the fp32 scores of HF beam search (DistributedRunner.py:361-387, utils/evaluate.py:37-58).  Protocol, two engines
  * over the SAME master parameter arena (a bf16 one for the draft, an fp32 one -- dtype 0 -- for the verification), one stream:

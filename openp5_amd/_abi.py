@@ -55,6 +55,7 @@ PROTOTYPES = {
     "p5_engine_discard_grads": (i32, [vp]),
     "p5_generate_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
     "p5_generate": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]),
+    "p5_generate_set_forced_prefix": (i32, [vp, vp, vp, i32]),
     "p5_generate_history_count": (i64, [i32, i32, i32]),
     "p5_generate_draft": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp]),
     "p5_verify_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32, i32]),

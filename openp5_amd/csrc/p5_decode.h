@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
       // four candidates per LDS round trip (16-byte reads): at beam 16 the one-at-a-time loop was 78 us of this kernel's 95 -- 512
       // dependent read pairs per candidate (round 5, profiles/r05_generate_verified_*.md)
       int rank = 0;
+#pragma unroll 4
       for (int u = 0; u < n4; ++u) {
         const f32x4 vu = ((const f32x4*)cs)[u];
         const u32x4 ku = ((const u32x4*)ckey)[u];
@@ -801,6 +802,66 @@ __global__ __launch_bounds__(256) void p5_dec_score2_kernel(float* __restrict__ 
     __syncthreads();
   }
   if (tid == 0) n_top[r] = want;
+}
+
+// =====================================================================================================================
+// Forced-prefix fast-forward (round 5).  Every OpenP5 item id starts with the same tokens -- "<dataset> item _" (data/.../indexing: the
+// target template `{dataset} {target}`) -- so for the first F steps of HF's beam search every beam of every user has
+// exactly ONE allowed token: beam 0 carries the real score, beams 1..K-1 the -1e9 of HF's initial state, nothing can finish, and step s
+// only adds log p(f_s | start, f_1 .. f_{s-1}) to beam 0.  Those F steps are therefore ONE teacher-forced decoder pass over F positions per
+// user (B x F rows through the throughput kernels, causal self-attention) instead of F latency-bound decode steps over B x K rows: same
+// numbers (a decoder position never sees later tokens), F - 1 steps saved -- 4 of the 8 steps of the ML-1M-shaped benchmark trie.
+// The pass leaves per position the self-attention K/V of every layer (scattered into the step cache at row b*K, which the ancestry
+// table maps every beam of the user to) and the per-token NLL; p5_beam_forced_kernel builds the beam state HF would have after F steps.
+// =====================================================================================================================
+#define P5_FF_MAX 16
+struct P5Forced { int n; int tok[P5_FF_MAX]; int node[P5_FF_MAX]; };      // f_1 .. f_n and the trie node each one leads to
+
+__global__ __launch_bounds__(256) void p5_ff_labels_kernel(int64_t* __restrict__ labels, P5Forced ff, int B) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * ff.n) labels[i] = (int64_t)ff.tok[i % ff.n];
+}
+// K/V of the forced positions: qkv [B*F, 3*inner] of one layer -> cache [max_len][R][2*inner] at (position p, row b*Kb)
+template <class T>
+__global__ __launch_bounds__(256) void p5_ff_cache_kernel(T* __restrict__ cache, const T* __restrict__ qkv, int F, int Kb, int R, int inner) {
+  constexpr int EPF = TT<T>::EPF;
+  const int bp = blockIdx.x, b = bp / F, p = bp % F;
+  const T* src = qkv + (size_t)bp * 3 * inner + inner;
+  T* dst = cache + ((size_t)p * R + (size_t)b * Kb) * 2 * inner;
+  for (int c = threadIdx.x; c < 2 * inner / EPF; c += 256) st16(dst + c * EPF, ld16(src + c * EPF));
+}
+// the beam state after F forced steps (p5_beam_init_kernel has run): see the header above
+__global__ __launch_bounds__(256) void p5_beam_forced_kernel(P5BeamState st, P5Forced ff, const float* __restrict__ nll, int B, int Kb, int max_len,
+                                                            int start_id) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int R = B * Kb, F = ff.n;
+  if (i < R * max_len) {
+    const int p = i % max_len;
+    const int v = (p == 0) ? start_id : (p <= F ? ff.tok[p - 1] : 0);
+    st.run_seq[i] = v; st.run_seq_next[i] = v;
+    // ancestry tables are [position][row]: K/V of position p < F live in the row of the user's beam 0
+    const int pp = i / R, r = i % R;
+    if (pp < F) { st.anc[i] = (r / Kb) * Kb; st.anc_next[i] = (r / Kb) * Kb; }
+  }
+  if (i < R) {
+    const int b = i / Kb, j = i % Kb;
+    float sc = 0.f;
+    for (int p = 0; p < F; ++p) sc += -nll[b * F + p];        // HF adds one log-probability per step, in step order
+    st.run_score[i] = (j == 0) ? sc : -1.0e9f;
+    st.run_node[i] = ff.node[F - 1];
+    st.last_tok[i] = (int64_t)ff.tok[F - 1];
+    if (st.hist)
+      for (int s = 1; s <= F; ++s) {
+        int* hrec = st.hist + 4 + (size_t)s * 4 * R + i;
+        hrec[0] = j; hrec[R] = ff.tok[s - 1]; hrec[2 * (size_t)R] = ff.node[s - 1]; hrec[3 * (size_t)R] = (j == 0) ? 1 : 0;
+      }
+  }
+  if (st.x32) {
+    const int d4 = st.d >> 2;
+    for (int t = i; t < R * d4; t += gridDim.x * 256)
+      *(f32x4*)(st.x32 + (size_t)t * 4) = *(const f32x4*)(st.E32 + (size_t)ff.tok[F - 1] * st.d + (t % d4) * 4);
+  }
+  if (i == 0) st.flags[2] = F + 1;
 }
 
 // results of the search: the finished set written by the last EXECUTED step lives in the "next" buffer of that step's parity

@@ -21,6 +21,7 @@ enum P5SkinnyEpi : int {
   P5_SK_RELU = 1,       // C(T)   = relu(acc)
   P5_SK_ATOMIC = 2,     // C(f32) += acc            (residual stream update, split-K over workgroups)
   P5_SK_STORE_F32 = 3,  // C(f32) = acc * alpha
+  P5_SK_RESID = 4,      // C(f32) = C + acc         (residual stream update by the element's ONLY writer: no K split, bit-reproducible)
 };
 
 struct P5SkinnyArgs {
@@ -29,7 +30,8 @@ struct P5SkinnyArgs {
   const void* W;        // T [N, ldw] (nn.Linear layout, K-contiguous)
   void* C;
   int M, N, K, lda, ldw, ldc;
-  int kw;               // K range per workgroup along gridDim.z (AMODE 0); = K for AMODE 1
+  int kw;               // K range per pass (AMODE 0); = K for AMODE 1
+  int kpasses;          // AMODE 0: passes of kw a workgroup makes one after the other over its K range (1 = the whole range up front)
   int epi;
   float alpha, eps;
   const int* done;      // optional device flag: != 0 -> the whole launch is a no-op (search finished in an earlier step)
@@ -168,18 +170,24 @@ __global__ __launch_bounds__(256) void p5_skinny_gemm_kernel(P5SkinnyArgs g) {
   if (g.done && *g.done) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * NB, m0 = blockIdx.y * 16;
-  const int k0 = AMODE == 1 ? 0 : blockIdx.z * g.kw;
-  int kw = AMODE == 1 ? g.K : ((k0 + g.kw <= g.K) ? g.kw : g.K - k0);
-  if (kw <= 0) return;
-  const int nsteps = kw / EPS;
-  char* aimg = lds;
-  char* bimg = lds + (size_t)nsteps * 2048;
-  float* red = (float*)(bimg + (size_t)nsteps * NB * 128);
-  sk_dma_rows<T>(bimg, (const T*)g.W, g.ldw, n0, g.N, k0, NB, nsteps, tid);
-  if constexpr (AMODE == 1) sk_norm_rows<T>(aimg, (const float*)g.A, g.ln, m0, g.M, g.K, g.eps, tid);
-  else sk_dma_rows<T>(aimg, (const T*)g.A, g.lda, m0, g.M, k0, 16, nsteps, tid);
-  __syncthreads();          // (drains the direct-to-LDS copies: cdna_hip_programming.md section 5)
-  const f32x4 acc = sk_mma<T, NB>(aimg, bimg, nsteps, red, tid);
+  const int npass = AMODE == 1 ? 1 : (g.kpasses > 0 ? g.kpasses : 1);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ps = 0; ps < npass; ++ps) {
+    const int k0 = AMODE == 1 ? 0 : (blockIdx.z * npass + ps) * g.kw;
+    int kw = AMODE == 1 ? g.K : ((k0 + g.kw <= g.K) ? g.kw : g.K - k0);
+    if (kw <= 0) break;
+    const int nsteps = kw / EPS;
+    char* aimg = lds;
+    char* bimg = lds + (size_t)nsteps * 2048;
+    float* red = (float*)(bimg + (size_t)nsteps * NB * 128);
+    if (ps > 0) __syncthreads();          // the previous pass's images (and its cross-wave reduction buffer) are read out
+    sk_dma_rows<T>(bimg, (const T*)g.W, g.ldw, n0, g.N, k0, NB, nsteps, tid);
+    if constexpr (AMODE == 1) sk_norm_rows<T>(aimg, (const float*)g.A, g.ln, m0, g.M, g.K, g.eps, tid);
+    else sk_dma_rows<T>(aimg, (const T*)g.A, g.lda, m0, g.M, k0, 16, nsteps, tid);
+    __syncthreads();          // (drains the direct-to-LDS copies: cdna_hip_programming.md section 5)
+    const f32x4 part = sk_mma<T, NB>(aimg, bimg, nsteps, red, tid);
+    acc[0] += part[0]; acc[1] += part[1]; acc[2] += part[2]; acc[3] += part[3];      // (complete on the waves with K part 0 only)
+  }
   if (KP > 1 && wave >= NT) return;
   const int col = n0 + (wave % NT) * 16 + (lane & 15);
   if (col >= g.N) return;
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void p5_skinny_gemm_kernel(P5SkinnyArgs g) {
     const size_t ci = (size_t)row * g.ldc + col;
     float v = acc[r];
     if (g.epi == P5_SK_ATOMIC) atomicAdd((float*)g.C + ci, v);
+    else if (g.epi == P5_SK_RESID) ((float*)g.C)[ci] += v;
     else if (g.epi == P5_SK_STORE_F32) ((float*)g.C)[ci] = v * g.alpha;
     else if (g.epi == P5_SK_RELU) ((T*)g.C)[ci] = from_f<T>(v > 0.f ? v : 0.f);
     else ((T*)g.C)[ci] = from_f<T>(v * g.alpha);

@@ -35,6 +35,8 @@ static int g_opt_dec_fuseq = getenv("P5_DEC_FUSEQ") ? atoi(getenv("P5_DEC_FUSEQ"
 static int g_opt_dgrad_t = getenv("P5_DGRAD_T") ? atoi(getenv("P5_DGRAD_T")) : 1;       // data gradients on the transposed weight copy when one is bound
 static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS")) : 3;   // 3 = MFMA cross-attention, 2 = scalar score / PV loops
 static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
+static int g_opt_dec_atomic = getenv("P5_DEC_ATOMIC") ? atoi(getenv("P5_DEC_ATOMIC")) : 0;   // 1 = round-2..4 decode step: residual stream updated with fp32 atomics by K-split workgroups (not bit-reproducible)
+static int g_opt_gen_ff = getenv("P5_GEN_FF") ? atoi(getenv("P5_GEN_FF")) : 1;             // forced-prefix fast-forward (p5_decode.h): 0 = every step is a decode step
 static int g_opt_dec_head_nv = getenv("P5_DEC_HEAD_NV") ? atoi(getenv("P5_DEC_HEAD_NV")) : 0;   // streaming head: forced E rows per workgroup (0 = auto)
 
 __global__ __launch_bounds__(256) void p5_shift_right_kernel(int64_t* out, const int64_t* labels, int B, int T, int64_t start) {
@@ -97,6 +99,7 @@ struct GenWs {
   int64_t* mask_copy;
   float* ssq;             // [3 * n_dec_layers + 1][R] row sums of squares of the residual stream entering each norm (fused path)
   uint32_t* excluded;     // [B, excl_words] copy of the caller's per-item excluded-node bitmap (stable address for the graph)
+  int64_t* ff_labels; float* ff_nll;     // forced-prefix pass: its labels [B, F] and per-token NLL
   P5BeamState st;
 };
 
@@ -104,7 +107,7 @@ struct GenWs {
 struct GenCtx {
   bool active = false;
   GenWs w;
-  int B = 0, L = 0, K = 0, max_len = 0, max_c = 0, excl_words = 0, steps = 0;
+  int B = 0, L = 0, K = 0, max_len = 0, max_c = 0, excl_words = 0, steps = 0, steps0 = 0;     // steps0: steps covered by the forced-prefix pass
   const int *child_off = nullptr, *child_tok = nullptr, *child_node = nullptr, *roots = nullptr;
   char* ws = nullptr;
 };
@@ -162,6 +165,7 @@ struct P5Engine {
   int64_t fold_E = 0, fold_count = 0;
   GenCtx gen;
   int* gen_hist_next = nullptr;    // p5_generate_draft: history buffer of the NEXT search (one-shot)
+  P5Forced ff_next = {0, {0}, {0}};  // p5_generate_set_forced_prefix: forced prefix of the NEXT search (one-shot)
   struct VerifyCtx* ver = nullptr;  // state of a verification pass between p5_verify_plan and p5_verify_run (p5_verify.h)
   // transposed bf16 copies of the 2-D layer weights (same arena offsets): the data gradients dx = dy W then read W^T as a
   // K-contiguous operand, i.e. run on the forward kernel (p5_engine_bind_transposed; optional)
@@ -1136,10 +1140,14 @@ static int64_t layout_gen(P5Engine* e, char* base, int B, int L, int K, int max_
   const int d = c.d_model, in = e->inner, F = c.d_ff;
   const size_t R = (size_t)B * K;
   const int Vp = (c.vocab_size + 63) / 64 * 64;
-  const int64_t enc_bytes = layout_ws(e, base, B, L, 0, false);
+  // (the encoder's buffers, and the training-layout decoder buffers of the forced-prefix pass: at most P5_FF_MAX positions per user)
+  const int ffcap = g_opt_gen_ff && g_opt_decode_v2 ? (max_len - 2 < P5_FF_MAX ? (max_len - 2 > 0 ? max_len - 2 : 0) : P5_FF_MAX) : 0;
+  const int64_t enc_bytes = layout_ws(e, base, B, L, ffcap, false);
   Bump b{base, (size_t)enc_bytes};
   GenWs tmp;
   GenWs& w = g ? *g : tmp;
+  w.ff_labels = (int64_t*)b.take((size_t)B * (ffcap > 0 ? ffcap : 1) * 8);
+  w.ff_nll = (float*)b.take((size_t)B * (ffcap > 0 ? ffcap : 1) * 4);
   {
     char* kv_all = g_opt_decode_v2 ? (char*)b.take((size_t)B * L * c.n_dec_layers * 2 * in * sz) : nullptr;
     w.ldkv = g_opt_decode_v2 ? c.n_dec_layers * 2 * in : 2 * in;
@@ -1284,8 +1292,16 @@ static int skinny(hipStream_t s, int amode, const void* A, int lda, const float*
   g.done = done;
   auto need = [&](int nb, int kw) { return (kw / EPS) * (2048 + nb * 128) + (nb < 64 ? 3072 : 0); };   // (+ cross-wave reduction buffer when waves split K)
   int nb = g_opt_dec_nb, kw = K, splits = 1;
+  g.kpasses = 1;
   if (amode == 1) {
     if (!nb) nb = need(64, K) <= 80 * 1024 ? 64 : (need(32, K) <= 100 * 1024 ? 32 : 16);
+  } else if (epi == P5_SK_RESID) {
+    // one writer per output element (bit-reproducible residual update): no K split over workgroups -- narrow column tiles make the
+    // workgroups (>= ~200 for 200 rows x 512 columns), and a long reduction is walked in passes of at most 80 KiB of operands
+    if (!nb) nb = need(32, K) <= 52 * 1024 ? 32 : 16;
+    kw = K;
+    while (need(nb, kw) > 80 * 1024 && kw > 2 * EPS) kw = ((kw / 2 + EPS - 1) / EPS) * EPS;
+    g.kpasses = (K + kw - 1) / kw;
   } else {
     if (!nb) nb = 64;
     // K range per workgroup: at most 512 (bf16) / 256 (fp32) elements -- one 80 KiB burst -- and enough splits for >= ~200 workgroups
@@ -1351,6 +1367,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
   constexpr int EPS = SkT<T>::EPS;
   // LDS of the fused kernel: q image 2 KiB + scores 8.25 + probabilities 2 x 4.25 + stats + K/V chunk images 2 x 16 KiB + normalised
   // rows + the head's Wq slice + reduction buffer
+  const int sk_resid = g_opt_dec_atomic ? P5_SK_ATOMIC : P5_SK_RESID;      // how the o / wo projections update the fp32 residual stream
   const bool fuseq = g_opt_dec_fuseq && sizeof(T) == 2 && (d / EPS) * (2048 + 64 * 128) + 3072 + 19712 + 2 * 16384 <= 136 * 1024;
   for (int i = 0; i < c.n_dec_layers; ++i) {
     const LayerOff& lo = e->dec[i];
@@ -1363,7 +1380,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
       P5_LAUNCH((p5_dec_self_attn2_kernel<T, P5_MAX_LEN / 8>), dim3((R * H + 3) / 4), dim3(256), 0, s, (T*)w.o, (const T*)w.qkv, (T*)w.cache[i], (const int*)w.st.anc,
                 (const int*)w.st.anc_next, (const float*)(e->P + e->off_dec_rel), e->lut_dec, e->lut_half, R, H, (const int*)(w.st.flags + 2), max_len, done);
     P5_TRY(P5_KCHECK());
-    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.sa.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
+    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.sa.o), in, x, d, R, d, in, sk_resid, 1.f, 0.f, done));
     // ---- cross-attention ----
     P5CrossArgs a;
     a.out = w.o; a.q = w.q; a.x = x; a.ln = e->P + lo.ca.ln; a.Wq = Wc<T>(e, lo.ca.q); a.kv = w.kv_cross[i]; a.mask = w.mask_copy;
@@ -1380,7 +1397,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
       else P5_LAUNCH((p5_dec_cross_attn2_kernel<T, false, sizeof(T) == 2 ? 48 : 80>), cgrid, dim3(256), 0, s, a);
     }
     P5_TRY(P5_KCHECK());
-    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.ca.o), in, x, d, R, d, in, P5_SK_ATOMIC, 1.f, 0.f, done));
+    P5_TRY(skinny<T>(s, 0, w.o, in, nullptr, Wc<T>(e, lo.ca.o), in, x, d, R, d, in, sk_resid, 1.f, 0.f, done));
     // ---- feed-forward ----
     if (c.gated_gelu) {
       T* u = (T*)w.h + (size_t)R * F;
@@ -1391,7 +1408,7 @@ static int decode_step2(P5Engine* e, GenWs& w, int B, int L, int K, int max_len,
     } else {
       P5_TRY(skinny<T>(s, 1, x, d, e->P + lo.ff_ln, Wc<T>(e, lo.wi), d, w.h, F, R, F, d, P5_SK_RELU, 1.f, c.eps, done));
     }
-    P5_TRY(skinny<T>(s, 0, w.h, F, nullptr, Wc<T>(e, lo.wo), F, x, d, R, d, F, P5_SK_ATOMIC, 1.f, 0.f, done));
+    P5_TRY(skinny<T>(s, 0, w.h, F, nullptr, Wc<T>(e, lo.wo), F, x, d, R, d, F, sk_resid, 1.f, 0.f, done));
   }
   // logits = (norm(x) * d^-0.5) E^T   (P5_T5.py:352-361)
   const int Vp = (c.vocab_size + 63) / 64 * 64;
@@ -1417,7 +1434,27 @@ static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, cons
   if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
   P5_TRY(encoder_fwd<T>(e, s));
-  if (g_opt_decode_v2) {     // K/V projections of every decoder layer in ONE GEMM over the contiguous weight block (build_layout)
+  // forced-prefix fast-forward (p5_decode.h): the first F steps as one teacher-forced pass of the training-layout decoder over B x F rows
+  P5Forced ff = e->ff_next;
+  e->ff_next.n = 0;
+  const int ffcap = g_opt_gen_ff && g_opt_decode_v2 ? (max_len - 2 < P5_FF_MAX ? max_len - 2 : P5_FF_MAX) : 0;
+  if (ff.n > ffcap) ff.n = ffcap > 0 ? ffcap : 0;
+  if (ff.n < 2 || roots != nullptr) ff.n = 0;          // (one forced step is what a decode step costs; per-user roots: not a shared prefix)
+  const int F = ff.n;
+  if (F > 0) {
+    P5_LAUNCH(p5_ff_labels_kernel, dim3((B * F + 255) / 256), dim3(256), 0, s, w.ff_labels, ff, B);
+    P5_TRY(P5_KCHECK());
+    e->T = F; e->Md = B * F; e->labels = w.ff_labels; e->Vp = (c.vocab_size + 63) / 64 * 64;
+    P5_TRY(decoder_fwd<T>(e, s));      // (also projects the encoder output to the cross-attention K/V of every layer: e->kv_all)
+    P5_LAUNCH((p5_ce_fwd_kernel<T>), dim3(e->Md), dim3(256), 0, s, w.ff_nll, e->lse_tok, (const float*)e->logits, (const int64_t*)w.ff_labels, c.vocab_size, e->Vp);
+    P5_TRY(P5_KCHECK());
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      w.kv_cross[i] = e->ds[i].kv_ca;                  // same [B*L, n_dec * 2 * inner] block layout as the decode step's own projection
+      P5_LAUNCH((p5_ff_cache_kernel<T>), dim3(B * F), dim3(256), 0, s, (T*)w.cache[i], (const T*)e->ds[i].qkv, F, K, R, in);
+      P5_TRY(P5_KCHECK());
+    }
+    e->T = 0; e->Md = 0; e->labels = nullptr;
+  } else if (g_opt_decode_v2) {     // K/V projections of every decoder layer in ONE GEMM over the contiguous weight block (build_layout)
     P5_TRY(linear_fwd<T>(s, e->enc_out, d, Wc<T>(e, e->dec[0].ca.k), w.kv_cross[0], w.ldkv, B * L, c.n_dec_layers * 2 * in, d));
   } else {
     for (int i = 0; i < c.n_dec_layers; ++i)
@@ -1426,11 +1463,15 @@ static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, cons
   P5_LAUNCH(p5_beam_init_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, child_off, child_tok, child_node, roots, B, K, max_len,
             c.pad_id);
   P5_TRY(P5_KCHECK());
+  if (F > 0) {
+    P5_LAUNCH(p5_beam_forced_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, ff, (const float*)w.ff_nll, B, K, max_len, c.pad_id);
+    P5_TRY(P5_KCHECK());
+  }
   hipMemcpyAsync(w.mask_copy, e->mask, (size_t)B * L * 8, hipMemcpyDeviceToDevice, s);
   if (excl_words > 0) hipMemcpyAsync(w.excluded, excluded, (size_t)B * excl_words * 4, hipMemcpyDeviceToDevice, s);
   g.B = B; g.L = L; g.K = K; g.max_len = max_len; g.max_c = max_c; g.excl_words = excl_words; g.ws = ws;
   g.child_off = child_off; g.child_tok = child_tok; g.child_node = child_node; g.roots = roots;
-  g.steps = 0;
+  g.steps = F; g.steps0 = F;
   g.active = true;
   return 0;
 }
@@ -1479,9 +1520,9 @@ static int decode_step_impl(P5Engine* e, hipStream_t s) {
   key.trie = g.child_off; key.trie_tok = g.child_tok; key.trie_node = g.child_node; key.roots = g.roots;
   key.P = e->P; key.S = e->S; key.sz = (int)sizeof(T); key.fold = e->fold; key.hist = g.w.st.hist;
   key.fused = g_opt_decode_fused + 2 * g_opt_decode_v2 + 4 * g_opt_dec_fuseq + 8 * g_opt_dec_nb + 4096 * g_opt_dec_kw + (g_opt_dec_cross << 20) +
-              (g_opt_dec_head << 23) + (g_opt_dec_head_nv << 24);
+              (g_opt_dec_head << 23) + (g_opt_dec_head_nv << 24) + ((g.steps0 > 0 ? 1 : 0) << 30) + (g_opt_dec_atomic << 29);     // (forced-prefix pass: the cross K/V live elsewhere)
   bool have_graph = use_graph && e->gen_graph_exec && memcmp(&key, &e->gen_graph_key, sizeof(key)) == 0;
-  if (use_graph && !have_graph && g.steps >= 1 && !e->gen_graph_failed) {
+  if (use_graph && !have_graph && g.steps > g.steps0 && !e->gen_graph_failed) {
     // (never during the very first step: the first launch of a kernel loads its code object, which is not allowed
     // while a stream is capturing)
     if (e->gen_graph_exec) { hipGraphExecDestroy(e->gen_graph_exec); e->gen_graph_exec = nullptr; }
@@ -1820,6 +1861,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "dec_head")) g_opt_dec_head = value;
   else if (!strcmp(name, "dec_head_nv")) g_opt_dec_head_nv = value;
   else if (!strcmp(name, "verify_split")) g_opt_verify_split = value;
+  else if (!strcmp(name, "gen_ff")) g_opt_gen_ff = value;
+  else if (!strcmp(name, "dec_atomic")) g_opt_dec_atomic = value;
   else if (!strcmp(name, "wgrad_group")) g_opt_wgrad_group = value;
   else if (!strcmp(name, "norm_fuse")) g_opt_norm_fuse = value;
   else if (!strcmp(name, "wgrad_wgs")) g_opt_wgrad_wgs = value;
@@ -2204,6 +2247,12 @@ int p5_generate(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word
   if (e->gen_timing) hipEventRecord(e->gen_ev[2], (hipStream_t)stream);
 #endif
   return p5_decode_finish(e, out_seq, out_score, out_len, stream);
+}
+int p5_generate_set_forced_prefix(P5Engine* e, const int* tokens, const int* nodes, int n) {
+  P5_REQUIRE(n >= 0 && (n == 0 || (tokens && nodes)), "forced prefix: tokens / nodes");
+  e->ff_next.n = n < P5_FF_MAX ? n : P5_FF_MAX;
+  for (int i = 0; i < e->ff_next.n; ++i) { e->ff_next.tok[i] = tokens[i]; e->ff_next.node[i] = nodes[i]; }
+  return 0;
 }
 int64_t p5_generate_history_count(int B, int K, int max_len) { return 4 + (int64_t)max_len * P5_HIST_FIELDS * B * K; }
 int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, int B, int L, int K,

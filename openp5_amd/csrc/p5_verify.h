@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void p5_verify_step_kernel(P5BeamState st, P5V
     if (v == P5_NEG_INF) continue;
     const int key = ckey[t];
     int rank = 0;
+#pragma unroll 4
     for (int u = 0; u < n4; ++u) {
       const f32x4 vu = ((const f32x4*)cs)[u];
       const u32x4 ku = ((const u32x4*)ckey)[u];

@@ -131,6 +131,7 @@ class P5T5Native(nn.Module):
     # always runs the plain (fp32) search.
     generation_mode = "verified"
     verify_extra_beams = 6
+    prefix_fast_forward = True    # the steps every item shares ("<dataset> item _") as one teacher-forced pass (p5_generate_set_forced_prefix)
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
         super().__init__()
@@ -648,6 +649,19 @@ class P5T5Native(nn.Module):
         # enqueue exactly as many decode steps as can do work.  (With max_length == depth the forced finish at max_length
         # coincides with the leaves' </s>, so results are those of the unbounded call.)
         max_length = max(2, min(int(max_length), int(trie.max_depth)))
+        # forced-prefix fast-forward (include/p5hip.h): the chain every item shares behind the start token, as long as no user's history
+        # exclusion touches it (an excluded node on the chain would leave that user without candidates: the plain search handles that)
+        self._forced = ([], [])
+        if self.prefix_fast_forward and roots_t is None:
+            ftok, fnode = trie.forced_prefix(self.config.decoder_start_token_id, self.config.eos_token_id)
+            n = min(len(ftok), max_length - 2)
+            if n >= 2 and excluded is not None:
+                words = excl_np[:, [x >> 5 for x in fnode[:n]]]
+                bits = np.asarray([x & 31 for x in fnode[:n]], dtype=np.uint32)
+                if bool(((words >> bits[None, :]) & 1).any()):
+                    n = 0
+            if n >= 2:
+                self._forced = (ftok[:n], fnode[:n])
         mode = unused.get("generation_mode", self.generation_mode)
         if mode not in ("verified", "draft"):
             raise ValueError(f"generation_mode={mode!r} (verified | draft)")
@@ -667,6 +681,10 @@ class P5T5Native(nn.Module):
                 maxc, hist=None):
         """One device beam search on `engine` (p5_generate; with `hist`, p5_generate_draft records what the search kept alive)."""
         dev = self._be.device
+        ftok, fnode = self._forced
+        if ftok:
+            arr = (ctypes.c_int * len(ftok))
+            self._be.check(self._lib.p5_generate_set_forced_prefix(engine, arr(*ftok), arr(*fnode), len(ftok)), "p5_generate_set_forced_prefix")
         ws = self._workspace(self._lib.p5_generate_workspace_bytes(engine, B, L, K, max_length, maxc, excl_words), ws_attr)
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)

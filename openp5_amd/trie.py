@@ -122,6 +122,29 @@ class CompiledTrie:
             self._max_depth = depth
         return self._max_depth
 
+    def forced_prefix(self, start_id: int, eos_id: int, limit: int = 16):
+        """(tokens, nodes) of the chain every item shares behind the decoder start token: from the start node on, as long as a node has
+        exactly ONE child and that child is not </s>.  OpenP5's item ids all begin with "<dataset> item _" (the `{dataset} {target}` target
+        template), so the first steps of every beam search under the item trie are forced -- p5_generate_set_forced_prefix turns them into
+        one teacher-forced pass.  Cached per (start, eos)."""
+        key = (int(start_id), int(eos_id), int(limit))
+        cache = self.__dict__.setdefault("_forced", {})
+        if key not in cache:
+            toks, nodes = [], []
+            node = -1
+            for c in range(int(self.child_off[0]), int(self.child_off[1])):
+                if int(self.child_tok[c]) == start_id:
+                    node = int(self.child_node[c])
+            while node >= 0 and len(toks) < limit:
+                lo, hi = int(self.child_off[node]), int(self.child_off[node + 1])
+                if hi - lo != 1 or int(self.child_tok[lo]) == eos_id:
+                    break
+                toks.append(int(self.child_tok[lo]))
+                node = int(self.child_node[lo])
+                nodes.append(node)
+            cache[key] = (toks, nodes)
+        return cache[key]
+
     @staticmethod
     def from_dict(trie_dict: Dict[int, dict]) -> "CompiledTrie":
         off, tok, nxt = [0], [], []

@@ -589,7 +589,7 @@ def make_items(n_items, seed, lo=7, hi=40, prefix=(0, 5, 6), minlen=2, maxlen=4)
 
 
 def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, score_tol=2e-5, via="ours", id_len=(2, 4), mode=None, extra_beams=None,
-                  sabotage=None):
+                  sabotage=None, prefix=(0, 5, 6)):
     """mode (bf16 models): "verified" = the bf16 search proposes, the fp32 pass decides (csrc/p5_verify.h) -- held to the fp32 tolerances;
     "draft" = the plain bf16 search; None = the model's default.  sabotage(hist): test hook, edits the draft's recorded history before the
     verification pass reads it (to force the flagged-user fallback)."""
@@ -610,7 +610,7 @@ def generate_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", seed=5, sco
         m._search = _search
     verified = dtype == "bf16" and m.generation_mode == "verified"
     ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
-    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1), minlen=id_len[0], maxlen=id_len[1])
+    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1), minlen=id_len[0], maxlen=id_len[1], prefix=prefix)
     trie = Trie(items)
     if via == "append":             # generation_trie.py:19-21: a second trie takes over where the first one reaches `bos_token_id`
         bos = min(61, ocfg.vocab_size - 2)
@@ -1278,10 +1278,10 @@ def skinny_gemm_case(be, dtype, amode, M, N, K, epi, seed=0):
     base = torch.randn(M, N, generator=g)
     if epi == 1:
         ref = torch.relu(ref)
-    if epi == 2:
+    if epi in (2, 4):            # 2: fp32 atomics over K-split workgroups; 4: one writer per element, K walked in passes (bit-reproducible)
         ref = base + ref
-    out_f32 = epi in (2, 3)
-    C = base.clone() if epi == 2 else torch.zeros(M, N, dtype=torch.float32 if out_f32 else tt)
+    out_f32 = epi in (2, 3, 4)
+    C = base.clone() if epi in (2, 4) else torch.zeros(M, N, dtype=torch.float32 if out_f32 else tt)
     Ad, Wd, Cd = dev(be, A_dev), dev(be, W), dev(be, C)
     lnd = dev(be, ln) if ln is not None else None
     be.check(be.lib.p5_op_skinny_gemm(dtype, amode, P(Ad), lda, P(lnd), P(Wd), K, P(Cd), N, M, N, K, epi, 1.0, 1e-6, be.stream_ptr()), "skinny")
@@ -1400,24 +1400,47 @@ def generate_wide_fanout_case(be, ocfg, B, L, K, n_wide, dtype="fp32", seed=3, s
 
 
 # ---- the dataset-level gate (tests/test_gpu_dataset.py on the GPU; tests/test_runner_emu.py runs the same body on the host emulation)
-FP32_TIE_TOL = 1e-4   # fp32 engine vs oracle: two items whose oracle scores differ by less than the fp32 score tolerance of the
-                      # generation tests (1e-4) may swap places (measured: 2 of 240 users, score gaps <= 1.2e-5)
-BF16_SCORE_TOL = 0.02   # bf16 engine: ceiling on the largest |score - oracle score| of an item both list (measured 0.003 .. 0.016,
-                        # depending on the weights the few training epochs produce)
-TIE_TOL = 2.0 * BF16_SCORE_TOL   # FIXED decision margin of the ORACLE below which the bf16 engine may decide differently: score errors
-                                 # below BF16_SCORE_TOL per score can flip decisions whose margin is at most twice that.  (Round 2
-                                 # scaled this with the error measured in the same run, so a regression widened its own excuse.)
+FP32_TIE_TOL = 1e-4   # fp32 arithmetic vs the oracle: two items whose oracle scores differ by less than the fp32 score tolerance of the
+                      # generation tests (1e-4) may swap places (measured: 2 of 240 users, score gaps <= 1.2e-5).  The HEADLINE generation
+                      # mode (bf16 model, generation_mode "verified") and the fp32 engine are both held to this and to nothing looser.
+# the plain bf16 search ("draft" mode: a leg of bench.py, and what proposes prefixes to the verification pass) -- round 5, tightened:
+BF16_SCORE_TOL = 0.016   # ceiling on |returned score - oracle score of the same sequence| (measured 0.003 .. 0.0141)
+TIE_TOL = 0.01           # oracle-score margin below which the bf16 search may decide differently: 4 x the largest gap observed between an
+                         # item it dropped and the weakest it kept (0.0024 per token); was 0.04
+BF16_SET_DIFF_MAX = 0.05  # share of users whose top-K SET may differ from the oracle's (measured 10 of 240)
 
 
-def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, **pipeline):
-    """The dataset-level evaluation gate of tests/test_gpu_dataset.py (its docstring says what is compared); `be` is the backend (the HIP
-    library on the GPU box; the host emulation runs the same body on a tiny model in tests/test_runner_emu.py), `pipeline` the
-    make_pipeline arguments, `ocfg_of(vocab_size)` the oracle's configuration of the same model."""
+def dropped_gap_first(x, x_lp, ranked, ranked_lp):
+    """dropped_gap judged at ONE step only: the first step t at which x[:t] is no prefix of any returned item (the earliest step at which
+    the search can have dropped x; it may have carried the prefix further -- then this is a lower bound of its excuse and the test says so
+    in what it prints).  Per token; 0.0 = consistent with an exact search."""
+    for t in range(1, len(x) + 1):
+        if any(tuple(y[:t]) == tuple(x[:t]) for y in ranked):
+            continue
+        peers = [sum(lp[:t]) for y, lp in zip(ranked, ranked_lp) if len(y) >= t]
+        if not peers:
+            continue
+        return max(0.0, (sum(x_lp[:t]) - min(peers)) / t)
+    return float("inf")
+
+
+def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, **pipeline):
+    """The dataset-level evaluation gate of tests/test_gpu_dataset.py: a model trained through the real pipeline (bf16 engine), then every
+    test user of both tasks ranked FOUR ways with the same weights -- fp32 CPU oracle (HF beam search restated + Python trie callbacks), the
+    bf16 model in its default "verified" mode (bf16 search with extra beams proposes, one fp32 pass decides: csrc/p5_verify.h), the fp32
+    engine, and the plain bf16 search ("draft").  `be` is the backend (the HIP library on the GPU box; the host emulation runs the same
+    body on a tiny model in tests/test_runner_emu.py), `pipeline` the make_pipeline arguments, `ocfg_of(vocab_size)` the oracle's
+    configuration of the same model.  north_star: "ranked Hit@k identical" -- asserted for the verified mode and the fp32 engine."""
     runner, model, tok, args = make_pipeline(be, tmp, "bf16", **pipeline)
     losses = runner.train()
     assert losses[-1] < 0.7 * losses[0], losses
     model.eval()
+    model.generation_mode = "verified"
+    r_ver = collect_rankings(runner, engine_gen_fn(model), K)
+    vstats = dict(model.verify_stats)
+    model.generation_mode = "draft"
     r_bf16 = collect_rankings(runner, engine_gen_fn(model), K)
+    model.generation_mode = "verified"
     sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
     from openp5_amd.model import P5T5Native
     m32 = P5T5Native(model.config, dtype="fp32", backend=be, seed=1)
@@ -1426,112 +1449,65 @@ def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, **pipeline):
     r_fp32 = collect_rankings(runner, engine_gen_fn(m32), K)
     ocfg = ocfg_of(model.config.vocab_size)
     margins = []
-    r_or = collect_rankings(runner, oracle_gen_fn({k: sd[k] for k in O.param_shapes(ocfg)}, ocfg, margins), K)
-    m_bf16, m_fp32, m_or = rankings_metrics(r_bf16), rankings_metrics(r_fp32), rankings_metrics(r_or)
+    params_o = {k: sd[k] for k in O.param_shapes(ocfg)}
+    r_or = collect_rankings(runner, oracle_gen_fn(params_o, ocfg, margins), K)
+    m_ver, m_bf16, m_fp32, m_or = rankings_metrics(r_ver), rankings_metrics(r_bf16), rankings_metrics(r_fp32), rankings_metrics(r_or)
+    cver = compare_rankings(r_ver, r_or, tie_tol=FP32_TIE_TOL)
     c32 = compare_rankings(r_fp32, r_or, tie_tol=FP32_TIE_TOL)
     c16 = compare_rankings(r_bf16, r_or, tie_tol=TIE_TOL)
-    print("[dataset] oracle metrics", m_or)
-    print("[dataset] bf16 metrics  ", m_bf16)
+    n_users = cver["users"]
+    depth = sorted({len(it) for users in r_or for _, ranked, _ in users for it in ranked})
+    # token positions at which the items of one user's oracle list differ: the steps at which the search had something to decide
+    levels = sorted({p for users in r_or for _, ranked, _ in users for p in range(min(len(it) for it in ranked)) if len({it[p] for it in ranked}) > 1})
+    print("[dataset] oracle metrics  ", m_or)
+    print("[dataset] verified metrics", m_ver, "verification pass:", vstats)
+    print("[dataset] plain bf16 metrics", m_bf16)
+    print("[dataset] item lengths (tokens incl. </s>):", depth, "positions at which a user's top-K items differ:", levels)
+    print("[dataset] verified vs oracle   ", {k: v for k, v in cver.items()})
     print("[dataset] fp32 engine vs oracle", {k: v for k, v in c32.items()})
-    print("[dataset] bf16 engine vs oracle", {k: v for k, v in c16.items()})
+    print("[dataset] plain bf16 vs oracle ", {k: v for k, v in c16.items()})
     assert sum(len(u) for u in r_or) >= min_users and any(v > 0 for m in m_or for v in m.values())
-    # fp32 engine: every user's ranked list identical to the oracle's up to swaps of items the ORACLE scores within 1e-4 of each
-    # other, the gold item at the same rank for every user, hence every Hit@k / NDCG@k identical
-    assert c32["identical_up_to_ties"] == c32["users"] and c32["max_score_diff"] <= 1e-4, c32
-    assert c32["identical_lists"] >= 0.98 * c32["users"], c32
-    assert c32["same_gold_rank"] == c32["users"] and m_fp32 == m_or
-    # ---- teacher-forced check, EVERY user, EVERY returned hypothesis (teacher_forced_check): the oracle scores the very token
-    # sequences an engine returned (O.sequence_scores).  This does not depend on the two searches having decided alike, so it is not
-    # vacuous on a model whose own decision margins are small: (a) each returned score equals the oracle's score of that sequence
-    # within the mode's tolerance, (b) the returned order is the oracle's order of those sequences up to the tie tolerance.
-    params_o = {k: sd[k] for k in O.param_shapes(ocfg)}
-    tf32 = teacher_forced_check(runner, params_o, ocfg, r_fp32, K, 1e-4, FP32_TIE_TOL, r_or)
+    # ---- headline mode and fp32 engine: every user's ranked list identical to the oracle's up to swaps of items the ORACLE scores within
+    # 1e-4 of each other, the gold item at the same rank for every user, every Hit@k / NDCG@k EQUAL, scores within 1e-4; and every returned
+    # hypothesis, re-scored by the oracle on the same token sequence (teacher-forced, O.sequence_scores), within 1e-4 and in order
+    for name, c, r, m in (("verified", cver, r_ver, m_ver), ("fp32 engine", c32, r_fp32, m_fp32)):
+        assert c["identical_up_to_ties"] == c["users"] and c["max_score_diff"] <= 1e-4, (name, c)
+        assert c["identical_lists"] >= 0.98 * c["users"], (name, c)
+        assert c["same_gold_rank"] == c["users"] and m == m_or, (name, m, m_or)
+        tf = teacher_forced_check(runner, params_o, ocfg, r, K, 1e-4, FP32_TIE_TOL, r_or)
+        print(f"[dataset] teacher-forced, {name}:", {k: v for k, v in tf.items() if not isinstance(v, list)}, "max dropped", max(tf["dropped"]))
+        assert tf["users"] == c["users"] and tf["score_viol"] == 0 and tf["order_viol"] == 0 and max(tf["dropped"]) <= FP32_TIE_TOL, (name, tf["max_score_err"])
+    # (the verification pass may hand a user to the fp32 search when the draft dropped a prefix the fp32 search needs: correct either way,
+    #  but it is the slow path -- it must stay the exception)
+    assert vstats["fallback_users"] <= max_fallback_frac * max(1, vstats["users"]), vstats
+    # ---- the plain bf16 search: (a) every returned score within BF16_SCORE_TOL of the oracle's score of that sequence, (b) the returned
+    # order is the oracle's order of those sequences up to TIE_TOL, (c) the top-K set differs from the oracle's for at most 5 % of the
+    # users, and (d) every item the oracle lists and the bf16 search does not was one it was entitled to drop AT THE FIRST STEP its prefix
+    # is no prefix of a returned item: its running score there within TIE_TOL per token of -- or below -- the weakest kept prefix
     tf16 = teacher_forced_check(runner, params_o, ocfg, r_bf16, K, BF16_SCORE_TOL, TIE_TOL, r_or)
-    print("[dataset] teacher-forced, fp32 engine:", {k: v for k, v in tf32.items() if not isinstance(v, list)}, "max missed", max(tf32["missed"]))
-    print("[dataset] teacher-forced, bf16 engine:", {k: v for k, v in tf16.items() if not isinstance(v, list)}, "missed > TIE_TOL:",
-          sum(1 for x in tf16["missed"] if x > TIE_TOL), "max", max(tf16["missed"]))
-    assert tf32["users"] == c32["users"] and tf32["score_viol"] == 0 and tf32["order_viol"] == 0 and max(tf32["missed"]) <= FP32_TIE_TOL, tf32
-    assert tf16["score_viol"] == 0 and tf16["order_viol"] == 0, {k: v for k, v in tf16.items() if not isinstance(v, list)}
-    # (c) EVERY difference between the bf16 list and the oracle's list must be explained by a tie in ORACLE scores:
-    #   * the lists are equal up to swaps of items the oracle scores within TIE_TOL of each other, or
-    #   * every item the oracle lists and the search does not could be dropped (dropped_gap): at some step of the search its running
-    #     score was within TIE_TOL (per token) of -- or below -- the lowest running score among the items the search kept to the end.  At
-    #     the last step that is a tie of final scores; at an earlier step a tie between two PREFIXES, whose completions may score
-    #     differently.
-    # Nothing may remain unexplained.  On this trie every item is 6 tokens with 4 distinct 4th tokens, so the whole search is ONE decision:
-    # the 10 best of 150 five-token prefixes, each followed by a forced </s>.  Seeded trajectory (`gpurun_out` dump analysed in
-    # profiles/r04_dataset_gate.txt): the top-10 set differs for 10 of 240 users, each time ONE item exchanged for another whose final
-    # score is within 0.002 (`exchange`) and whose prefix score is within 0.0024 per token (`dropped`).  `missed` says 0.60 for the same
-    # users: one popular prefix is in all 240 users' top 10 and its </s> costs -3.8, so the K-th item of BOTH lists is that item at
-    # -1.2 .. -1.3 and "above the K-th" measures nothing -- which is why the assertion is on `dropped`, the quantity a beam search decides by.
-    rob = robust_users(r_or, margins, TIE_TOL)
     flat16, flat_or = [u for us in r_bf16 for u in us], [u for us in r_or for u in us]
     dump = os.environ.get("P5_DATASET_DUMP")
     if dump:
-        torch.save({"r_bf16": r_bf16, "r_fp32": r_fp32, "r_or": r_or, "margins": margins, "tf16": tf16, "tf32": tf32, "c16": c16, "c32": c32,
-                    "m": (m_bf16, m_fp32, m_or), "rob": rob, "losses": losses}, dump)
-    unexplained, set_diff, prefix_only = [], 0, 0
+        torch.save({"r_bf16": r_bf16, "r_ver": r_ver, "r_fp32": r_fp32, "r_or": r_or, "margins": margins, "tf16": tf16, "c16": c16, "c32": c32, "cver": cver,
+                    "m": (m_bf16, m_fp32, m_or, m_ver), "losses": losses, "verify_stats": vstats}, dump)
+    unexplained, set_diff, first_gaps = [], 0, []
     for i, ((_, ra, _), (_, ro, so)) in enumerate(zip(flat16, flat_or)):
         set_diff += int(set(ra) != set(ro))
         if list(ra) == list(ro) or lists_equal_up_to_ties(list(ra), list(ro), list(so), TIE_TOL):
             continue
-        if tf16["dropped"][i] <= TIE_TOL:
-            prefix_only += int(tf16["exchange"][i] > TIE_TOL)
-            continue
-        unexplained.append((i, round(tf16["exchange"][i], 4), round(tf16["dropped"][i], 4)))
-    print(f"[dataset] bf16: differences not explained by ties: {len(unexplained)} of {len(flat16)} users {unexplained[:6]}; top-{K} set differs for "
-          f"{set_diff} users: largest final-score gap of what was exchanged {max(tf16['exchange']):.4f}, largest dropped_gap {max(tf16['dropped']):.4f} "
-          f"(fp32 engine {max(tf32['dropped']):.2e}), explained by a tie between prefixes only: {prefix_only}, largest 'missed above the K-th' "
-          f"{max(tf16['missed']):.3f}")
-    assert max(tf32["dropped"]) <= FP32_TIE_TOL, max(tf32["dropped"])
-    assert len(unexplained) == 0, unexplained
-    # bf16 engine.  Its scores are within BF16_SCORE_TOL of the oracle's; a beam search is a sequence of discrete decisions, so
-    # it must reproduce the oracle exactly wherever the oracle took every decision by a margin larger than TIE_TOL
-    # (fixed: 2 x the score-error ceiling) and may differ only where the oracle itself was that close to deciding otherwise:
-    #   * list-robust users   -> identical ranked lists;
-    #   * metric-robust users -> gold item at the same rank, i.e. identical Hit@5/10, NDCG@5/10 contributions;
-    #   * the rest is the tie report (printed), and the dataset-level metrics may move by at most those users.
+        r_lp, o_lp = tf16["detail"][i]
+        gaps = [dropped_gap_first(ro[j], o_lp[j], list(ra), r_lp) for j in range(len(ro)) if ro[j] not in ra]
+        g = max(gaps + [0.0])
+        first_gaps.append(g)
+        if g > TIE_TOL:
+            unexplained.append((i, round(g, 4), round(tf16["dropped"][i], 4)))
+    print(f"[dataset] plain bf16: teacher-forced", {k: v for k, v in tf16.items() if not isinstance(v, list)})
+    print(f"[dataset] plain bf16: top-{K} set differs for {set_diff} of {n_users} users; largest first-step dropped gap {max(first_gaps + [0.0]):.4f} per token "
+          f"(any-step {max(tf16['dropped']):.4f}); not explained at TIE_TOL {TIE_TOL}: {unexplained[:8]}; {c16['identical_lists']} bit-identical lists, "
+          f"{c16['identical_up_to_ties']} identical up to oracle ties, same gold rank {c16['same_gold_rank']}")
+    assert tf16["score_viol"] == 0 and tf16["order_viol"] == 0, {k: v for k, v in tf16.items() if not isinstance(v, list)}
     assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
-    # Floors over ALL users (the raw counts of bit-identical lists, of lists identical up to tie swaps and of identical top-10 sets are
-    # printed, not gated: with the oracle's median gap between consecutive final scores at 0.006 they count near-ties at the tail of the
-    # list -- six training trajectories of this test gave 158 .. 203 identical lists, 227 .. 240 identical up to swaps, the top-10 set
-    # differing for 0 .. 13 users, always with the gold item at the same rank for >= 235 users and the top-5 SET identical for all 240;
-    # what every returned list must satisfy is the teacher-forced check and the "every difference is a tie" assertion above.  Those
-    # trajectories started from different embeddings -- `random_initialization` draws from torch's device generator, which make_pipeline
-    # did not seed; it does now, and the training itself is bit-reproducible, so a given build gives ONE trajectory):
-    print(f"[dataset] bf16: {c16['identical_lists']}/{c16['users']} bit-identical lists, {c16['identical_up_to_ties']} identical up to oracle ties <= {TIE_TOL}, "
-          f"same top-10 set {c16['same_topk_set'][10]}, same top-5 set {c16['same_topk_set'][5]}, same gold rank {c16['same_gold_rank']}")
-    assert c16["same_topk_set"][5] >= 0.95 * c16["users"], c16
-    assert c16["same_gold_rank"] >= 0.95 * c16["users"], c16
-    for mb, mo in zip(m_bf16, m_or):
-        assert abs(mb["hit@5"] - mo["hit@5"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)
-        assert abs(mb["hit@10"] - mo["hit@10"]) <= 2.0 / (c16["users"] / len(m_or)) + 1e-12, (mb, mo)
-    flat_b, flat_o = flat16, flat_or
-    n_list = n_metric = n_fragile_moved = 0
-    for (list_ok, metric_ok), (g, ra, sa), (_, ro, so), (set_m, gaps) in zip(rob, flat_b, flat_o, margins):
-        ka, ko = (ra.index(g) if g in ra else -1), (ro.index(g) if g in ro else -1)
-        if list_ok:
-            n_list += 1
-            assert ra == ro, ("list-robust user differs", set_m, gaps, ra, ro)
-        if metric_ok:
-            n_metric += 1
-            assert ka == ko, ("metric-robust user: gold rank moved", set_m, gaps, ka, ko)
-        elif ka != ko:
-            n_fragile_moved += 1
-            print(f"[dataset] tie report: gold rank {ko} (oracle) vs {ka} (bf16); oracle's smallest set margin {set_m:.4f}, "
-                  f"final-score gaps around the gold item {[round(x, 4) for x in gaps[max(0, ko - 1):ko + 1]] if ko >= 0 else '-'}")
-    n = len(rob)
-    print(f"[dataset] bf16: {n_list}/{n} users list-robust (all identical), {n_metric}/{n} metric-robust (gold rank identical), "
-          f"{n - n_metric} fragile of which {n_fragile_moved} moved")
-    sm = sorted(m[0] for m in margins)
-    print(f"[dataset] TIE_TOL {TIE_TOL:.4f}; oracle set-margin quantiles 10/50/90%: {sm[n // 10]:.4f} {sm[n // 2]:.4f} {sm[9 * n // 10]:.4f}")
-    # (the oracle's OWN decision margins on this barely-trained model are small -- median 0.025, 90 % below 0.06 -- so most users are
-    # fragile at any tolerance a bf16 score error of 0.005 .. 0.016 allows; the floors asserted above are what holds for ALL users)
-    # (how many users are robust at TIE_TOL depends on the trained weights: 18 of 240 on one trajectory of this test, 0 on another --
-    #  the per-user exactness above is asserted for whoever is robust; the floors over ALL users are the gate that always applies)
-    print(f"[dataset] robust population at TIE_TOL: {n_metric}/{n}")
-    for mb, mo in zip(m_bf16, m_or):      # dataset-level metrics: equal up to the fragile users that moved
-        for k in mo:
-            assert abs(mb[k] - mo[k]) <= n_fragile_moved / (n / len(m_or)) + 1e-12, (k, mb[k], mo[k])
-    if n_fragile_moved == 0:
-        assert m_bf16 == m_or, (m_bf16, m_or)
+    assert set_diff <= BF16_SET_DIFF_MAX * n_users, (set_diff, n_users)
+    assert len(unexplained) == 0, unexplained
+    assert c16["same_gold_rank"] >= 0.95 * n_users and c16["same_topk_set"][5] >= 0.95 * n_users, c16
+    return {"verify_stats": vstats, "cver": cver, "c16": c16, "set_diff": set_diff, "depth": depth, "levels": levels}

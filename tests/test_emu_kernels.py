@@ -210,6 +210,26 @@ def test_generate_unfused_decode_norms(emu):
         emu.lib.p5_set_option(b"decode_fused", 1)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_generate_forced_prefix_fast_forward(emu, dtype):
+    """Item ids that share their first four tokens ("<dataset> item _ ..."): the four forced steps run as ONE teacher-forced decoder pass
+    (p5_decode.h, p5_generate_set_forced_prefix) -- results equal the oracle's step-by-step search; with the option off the same search
+    takes every step as a decode step and returns the same lists."""
+    kw = dict(prefix=(0, 5, 6, 7, 8), seed=4)
+    if dtype == "bf16":
+        kw.update(dtype="bf16", mode="draft", score_tol=0.05)
+    a = cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 14, 40, **kw)
+    try:
+        emu.check(emu.lib.p5_set_option(b"gen_ff", 0), "set_option")
+        b = cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 14, 40, **kw)
+    finally:
+        emu.lib.p5_set_option(b"gen_ff", 1)
+    if dtype == "fp32":
+        import torch
+        assert torch.equal(a["sequences"].cpu(), b["sequences"].cpu())
+        assert (a["sequences_scores"].cpu() - b["sequences_scores"].cpu()).abs().max() <= 2e-6
+
+
 def test_generate_gated_fused(emu):
     """gated-gelu FFN (T5 v1.1) through the fused decode step."""
     cases.generate_case(emu, O.T5Cfg.named("tiny", ff_act="gated-gelu"), 2, 12, 4, 10, 30, seed=11)
@@ -282,7 +302,8 @@ def test_fused_loss_matches_autograd_path(emu):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("shape", [(0, 15, 128, 128, 0), (1, 15, 384, 128, 0), (1, 15, 256, 128, 1), (0, 15, 128, 256, 2), (0, 40, 96, 512, 2), (1, 40, 100, 512, 3), (1, 20, 40, 768, 0), (1, 18, 32, 1024, 0)])
+@pytest.mark.parametrize("shape", [(0, 15, 128, 128, 0), (1, 15, 384, 128, 0), (1, 15, 256, 128, 1), (0, 15, 128, 256, 2), (0, 40, 96, 512, 2), (1, 40, 100, 512, 3), (1, 20, 40, 768, 0), (1, 18, 32, 1024, 0),
+                                   (0, 40, 96, 512, 4), (0, 20, 100, 2048, 4), (0, 33, 64, 3072, 4)])
 def test_skinny_gemm(emu, dtype, shape):
     """decode-step projections (p5_decode2.h): plain / ReLU / atomic-accumulate epilogues, fused T5LayerNorm prologue, split-K,
     column-tile widths 64 / 32 / 16 as d_model grows."""

@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 
 def test_dataset_level_hit_ndcg_equal_oracle(hip, tmp_path):
     """the body, its tolerances and what each assertion means: tests/cases.py::dataset_gate (the host emulation runs the same body on a
-    tiny model in the CPU suite, tests/test_runner_emu.py::test_dataset_gate_body_on_emulator)"""
+    tiny model in the CPU suite, tests/test_runner_emu.py::test_dataset_gate_body_on_emulator).  150 items, all six tokens long with four
+    distinct fourth tokens: the whole search is ONE decision (the 10 best of 150 five-token prefixes, then a forced </s>)."""
     cases.dataset_gate(hip, str(tmp_path), lambda v: O.T5Cfg.named("t5-small", dropout=0.0, vocab_size=v), K=10, min_users=200,
                        flags=["--epochs", "6", "--lr", "1e-3"])
+
+
+def test_dataset_level_ml1m_shaped_trie(hip, tmp_path):
+    """The same gate on an ML-1M-shaped item space (3,416 items, sequential ids 1001 .. 4416 = two number pieces: a ~35-way decision -- of
+    which the beam keeps 10 -- followed by a ~100-way one per kept prefix): the search prunes at more than one step, so an early error
+    would compound (the 150-item gate above has two first pieces and keeps both: one decision).  80 users x 2 tasks."""
+    r = cases.dataset_gate(hip, str(tmp_path), lambda v: O.T5Cfg.named("t5-small", dropout=0.0, vocab_size=v), K=10, min_users=150,
+                           dataset="ML1M", n_users=80, n_items=3416, n_inter=80 * 40, flags=["--epochs", "6", "--lr", "1e-3"])
+    assert len(r["levels"]) >= 2, r["levels"]          # the returned items differ at two token positions at least: decisions at several steps

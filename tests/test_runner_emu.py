@@ -588,7 +588,7 @@ def test_dataset_gate_body_on_emulator(emu, tmp_path):
     cfg = P5ModelConfig(d_model=64, d_ff=128, num_layers=1, num_decoder_layers=1, num_heads=2, dropout_rate=0.0)
     cases.dataset_gate(emu, str(tmp_path), lambda v: O.T5Cfg(vocab_size=v, d_model=64, d_ff=128, num_heads=2, num_layers=1, num_decoder_layers=1,
                                                               dropout=0.0),
-                       K=4, min_users=16, dataset="Toy", n_users=8, n_items=20, n_inter=64, dropout=0.0, model_cfg=cfg, vocab=VOCAB,
+                       K=4, min_users=16, max_fallback_frac=0.5, dataset="Toy", n_users=8, n_items=20, n_inter=64, dropout=0.0, model_cfg=cfg, vocab=VOCAB,
                        flags=["--epochs", "3", "--lr", "3e-3", "--eval_batch_size", "8"])
 
 

@@ -18,7 +18,7 @@ ALLOWED = {
     "p5_gemm5.h": ["atomicAdd(cp + r, v[r])", "atomicAdd((float*)g.C + ci + r, v[r])", "atomicAdd(cp + e, v[e])", "atomicAdd(g.ssq_out + row, ss)"],
     # (GEMM epilogues: P5_EPI_ATOMIC is issued by the engine with ONE split only -- each element receives a single add per backward --
     #  or with c_split_stride > 0, which stores; the scalar ssq form is the first-generation decode step's, generation only)
-    "p5_decode2.h": ["atomicAdd((float*)g.C + ci, v)"],        # decode step: fp32 residual stream updated in place (generation)
+    "p5_decode2.h": ["atomicAdd((float*)g.C + ci, v)"],        # decode step of rounds 2-4 (K-split workgroups adding into the residual stream): only with p5_set_option("dec_atomic", 1)
 }
 
 
@@ -31,11 +31,17 @@ def test_no_new_float_atomics_in_kernel_sources():
             code = line.split("//")[0]
             if "atomicAdd(" not in code:
                 continue
-            if re.search(r"atomicAdd\(&?(s_nothit|st\.flags|hist|s_sel)", code):       # integer counters of the beam search
+            if re.search(r"atomicAdd\(&?(s_nothit|st\.flags|hist|s_sel|pl\.hdr)", code):       # integer counters of the beam search / verification plan
                 continue
             if not any(tok in code for tok in ALLOWED.get(fn, [])):
                 found.setdefault(fn, []).append((i, code.strip()))
     assert not found, f"float atomics outside the allowed sites (DESIGN.md 3.5): {found}"
+
+
+def test_decode_step_updates_the_residual_stream_with_one_writer_per_element():
+    src = open(os.path.join(CSRC, "p5_lib.hip")).read()
+    assert "g_opt_dec_atomic ? P5_SK_ATOMIC : P5_SK_RESID" in src and 'P5_DEC_ATOMIC") ? atoi(getenv("P5_DEC_ATOMIC")) : 0' in src
+    assert "P5_SK_ATOMIC, 1.f, 0.f, done" not in src         # no projection of the decode step asks for the atomic epilogue directly
 
 
 def test_engine_issues_atomic_gemms_with_one_split():
