@@ -174,22 +174,38 @@ def kernel_classes(rows):
     return sorted(cls.values(), key=lambda c: -c["us_per_step"])
 
 
-def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, seed, vocab=V):
+def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, seed, vocab=V, mode=None):
+    """`batches` generate() calls of `gB` users, beam `gK`, bracketed like the training step (barrier + synchronize).  mode (bf16 models):
+    "verified" = the bf16 search with extra beams proposes, one fp32 pass decides (lists and scores are the fp32 search's: csrc/p5_verify.h),
+    "draft" = the plain bf16 search.  Returns (seconds, decoded length, engine timing of the search kernels, per-call median ms, stats)."""
     from openp5_amd.trie import prefix_allowed_tokens_fn
     model.eval()
+    if mode is not None:
+        model.generation_mode = mode
     fn = prefix_allowed_tokens_fn(trie)
     gids, gww, gmask, _, _ = synth_batch(gB, L, 8, device, seed, vocab)
     kw = dict(input_ids=gids, attention_mask=gmask, whole_word_ids=gww, max_length=max_length, prefix_allowed_tokens_fn=fn,
               num_beams=gK, num_return_sequences=gK, output_scores=True, return_dict_in_generate=True)
-    for _ in range(2):
+    for _ in range(3):
         o = model.generate(**kw)
+    for k in model.verify_stats:
+        model.verify_stats[k] = 0
     barrier(world)
     g0 = time.perf_counter()
     for _ in range(batches):
         o = model.generate(**kw)
     barrier(world)
     gdt = max_over_ranks(time.perf_counter() - g0, world, device)
-    # device time of the decode loop alone (engine-side HIP events around it), taken on extra calls OUTSIDE the timed region
+    stats = dict(model.verify_stats)
+    # per-call wall times (each call ends with the read of the result lengths, i.e. is synchronous) and the device time of the search's
+    # decode loop alone (engine-side HIP events around it), both on extra calls OUTSIDE the timed region
+    per_call = []
+    for _ in range(max(5, min(20, batches))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(**kw)
+        torch.cuda.synchronize()
+        per_call.append((time.perf_counter() - t0) * 1e3)
     timing = None
     if hasattr(model, "time_generate"):
         model.time_generate(True)
@@ -200,8 +216,11 @@ def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, 
             enc.append(t["encode_ms"])
             dec.append(t["decode_ms"])
         model.time_generate(False)
-        timing = {"encode_ms": sorted(enc)[1], "decode_ms": sorted(dec)[1], "source": "HIP events recorded by p5_generate around its decode loop, median of 3 calls"}
-    return gdt, int(o["sequences"].shape[1]), timing
+        ff = len(getattr(model, "_forced", ([], []))[0])
+        timing = {"encode_ms": sorted(enc)[1], "decode_ms": sorted(dec)[1], "forced_prefix_steps": ff,
+                  "source": "HIP events recorded by p5_generate around its decode loop, median of 3 calls; encode_ms = encoder pass (or the cast of the "
+                            "verification pass's encoder output) + the forced-prefix pass + cross-attention K/V + beam state"}
+    return gdt, int(o["sequences"].shape[1]), timing, sorted(per_call)[len(per_call) // 2], stats
 
 
 def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
@@ -465,10 +484,15 @@ def config_legs(be, device, dtype):
         # C2 generation in the fp32 parity mode: the mode whose ranked lists are identical to the fp32 oracle's for every user
         # (tests/test_gpu_dataset.py); the bf16 headline number is the fast mode, whose lists may differ where the oracle's own
         # decision margins are below the bf16 score tolerance
-        cfg, model, _ = build_model("t5-small", "fp32", device, be, 1, 0)
-        gdt, dec_len, _ = time_generation(model, 20, 10, 128, synth_item_trie(3416, 7), 30, 5, 1, device, 500)
-        legs["c2_generation_fp32_parity_mode"] = {"items_per_s": 20 * 10 * 5 / gdt, "ms_per_batch": gdt / 5 * 1e3, "users_per_batch": 20, "num_beams": 10,
-                                                  "decoded_len": dec_len, "dtype": "f32"}
+        cfg, model, opt = build_model("t5-small", "fp32", device, be, 1, 0)
+        gdt, dec_len, timing, med, _ = time_generation(model, 20, 10, 128, synth_item_trie(3416, 7), 30, 20, 1, device, 500)
+        legs["c2_generation_fp32_parity_mode"] = {"items_per_s": 20 * 10 * 20 / gdt, "ms_per_batch": gdt / 20 * 1e3, "ms_per_batch_median_call": med,
+                                                  "batches": 20, "users_per_batch": 20, "num_beams": 10, "decoded_len": dec_len, "dtype": "f32", "timing_ms": timing}
+        # the fp32 parity engine's TRAINING step at C2 (the reference trains in fp32; exact-fp32 MFMA chain, no folded norms, ungrouped weight gradients)
+        batch = synth_batch(64, 128, 8, device, 100)
+        tdt, tloss = time_training(model, opt, batch, 5, 2, 1, device)
+        legs["c2_training_fp32_parity_mode"] = {"samples_per_s": 64 * 5 / tdt, "ms_per_step": tdt / 5 * 1e3, "steps": 5, "batch": 64, "dtype": "f32", "final_loss": tloss}
+        del opt
         del model
         torch.cuda.empty_cache()
     except Exception as ex:
@@ -478,12 +502,14 @@ def config_legs(be, device, dtype):
         cfg, model, _ = build_model("t5-base", dtype, device, be, 1, 0, vocab=Vc)
         trie = synth_item_trie(12101, 11, lo=V, hi=Vc - 1, pieces=(2, 3, 3, 4))       # Beauty: 12,101 items, <CIk> token paths
         gB, gK, L = 20, 20, 128
-        gdt, dec_len, timing = time_generation(model, gB, gK, L, trie, 30, 5, 1, device, 700, vocab=Vc)
+        gdt, dec_len, timing, _, vst = time_generation(model, gB, gK, L, trie, 30, 5, 1, device, 700, vocab=Vc, mode="verified")
+        gdt_d, _, timing_d, _, _ = time_generation(model, gB, gK, L, trie, 30, 5, 1, device, 700, vocab=Vc, mode="draft")
         d, F, H, NL = DIMS["t5-base"]
         S = dec_len - 1
         ms = gdt / 5 * 1e3
         legs["c4_t5base_beam20_b20"] = {"items_per_s": gB * gK * 5 / gdt, "ms_per_batch": ms, "users_per_batch": gB, "num_beams": gK, "vocab": Vc,
-                                        "trie_items": 12101, "decoded_len": dec_len, "timing_ms": timing,
+                                        "trie_items": 12101, "decoded_len": dec_len, "timing_ms": timing, "mode": "verified", "verify_stats": vst,
+                                        "plain_bf16": {"items_per_s": gB * gK * 5 / gdt_d, "ms_per_batch": gdt_d / 5 * 1e3, "timing_ms": timing_d},
                                         "hbm_bytes_per_step_min": gen_bytes_per_step(d, H * 64, F, NL, Vc, gB, gK, L, S // 2 + 1),
                                         "gflop_per_batch": gB * gen_flops_per_user(d, H * 64, F, H, NL, L, gK, S, Vc) / 1e9}
         del model
@@ -546,12 +572,21 @@ def main():
         model.ddp_timing = False
 
     # ---- beam-10 constrained generation: items/s (B=20 users/GPU, K=10, ML1M-sized trie of 3416 items) ----
-    gen = None
+    # HEADLINE = the bf16 model's default "verified" mode: ranked lists and scores are the fp32 search's (tests/test_gpu_dataset.py holds it to
+    # the fp32 criteria against the oracle); the plain bf16 search ("draft": lists may differ at near-ties) is reported next to it.
+    gen = gen_draft = None
     if not args.no_gen:
         gB, gK = 20, 10
-        gdt, dec_len, timing = time_generation(model, gB, gK, L, synth_item_trie(3416, 7), 30, args.gen_batches, world, device, 500 + rank)
-        gen = {"items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3,
-               "users_per_batch": gB, "num_beams": gK, "max_length": 30, "trie_items": 3416, "decoded_len": dec_len, "timing_ms": timing}
+        trie = synth_item_trie(3416, 7)
+        gdt, dec_len, timing, med, vst = time_generation(model, gB, gK, L, trie, 30, args.gen_batches, world, device, 500 + rank, mode="verified")
+        gen = {"mode": "verified (bf16 search with 6 extra beams proposes, one teacher-forced fp32 pass decides; csrc/p5_verify.h)",
+               "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3, "ms_per_batch_median_call": med,
+               "users_per_batch": gB, "num_beams": gK, "max_length": 30, "trie_items": 3416, "decoded_len": dec_len, "draft_timing_ms": timing,
+               "verify_stats": vst}
+        gdt, dec_len, timing, med, _ = time_generation(model, gB, gK, L, trie, 30, args.gen_batches, world, device, 500 + rank, mode="draft")
+        gen_draft = {"mode": "draft (plain bf16 search)", "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3,
+                     "ms_per_batch_median_call": med, "users_per_batch": gB, "num_beams": gK, "decoded_len": dec_len, "timing_ms": timing}
+        model.generation_mode = "verified"
 
     if rank == 0:
         c = cfg
@@ -584,6 +619,7 @@ def main():
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
             "generation": gen,
+            "generation_plain_bf16": gen_draft,
             "distributed": ddp,
             # `roofline` = the kernel with the largest share of the step's time IN THIS RUN (library profiler, HIP events around every
             # launch of 3 extra steps outside the timed region): aggregate algorithmic FLOPs of its launches / their summed in-step
@@ -609,6 +645,14 @@ def main():
                                 "share_of_kernel_time": top["us_per_step"] / max(1e-9, sum(c["us_per_step"] for c in cls)),
                                 "by_grid": top["grids"], "alone": wg_alone if is_ks else fwd_alone, "traffic": (wg_alone if is_ks else fwd_alone)["traffic"],
                                 "source": "p5_profile_begin/end in this run: HIP events around every launch of 3 steps (durations include the dispatch gap)"}
+            # which number to read: `frac` is computed from event-BRACKETED durations (each includes its launch's dispatch gap: an upper bound of
+            # the kernel time, so `frac` is a lower bound).  The smallest bracket of the step (a trivial kernel) bounds that gap from above;
+            # `frac_excl_dispatch` subtracts it per launch and is what a rocprofv3 kernel trace of the same step shows within a few per cent
+            # (profiles/r05_train_in_step.json holds the rocprofv3 durations of this build).
+            floor_us = min(r["total_us"] / max(1, r["launches"]) for r in prof_rows)
+            us_excl = max(1e-9, top["us_per_step"] - floor_us * top["launches_per_step"])
+            line["roofline"]["bracket_floor_us"] = floor_us
+            line["roofline"]["frac_excl_dispatch"] = top["flops_per_step"] / us_excl / 1e6 / BF16_PEAK_TFLOPS
             ks = [c for c in cls if "p5_gemm5_kernel" in c["kernel"] and "[KS" in c["kernel"]]
             if ks and not is_ks:
                 k0 = ks[0]
@@ -625,17 +669,20 @@ def main():
         else:
             line["roofline"] = dict(bound="mfma", kernel=k_wg, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **wg_alone)
         line["roofline_fwd"] = dict(bound="mfma", kernel=k_fwd, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", **fwd_alone)
-        if gen:
-            S = gen["decoded_len"] - 1
-            timed = (timing or {}).get("decode_ms")
-            step_ms = timed / max(1, S) if timed else gen["ms_per_batch"] / max(1, S)
-            byts = gen_bytes_per_step(c.d_model, inner, c.d_ff, c.num_decoder_layers, V, 20, 10, L, S // 2 + 1)
+        if gen_draft:
+            # the decode step of the plain bf16 search (K = 10): the steps the forced-prefix pass did not cover
+            timing = gen_draft["timing_ms"] or {}
+            S = gen_draft["decoded_len"] - 1 - int(timing.get("forced_prefix_steps", 0))
+            timed = timing.get("decode_ms")
+            step_ms = timed / max(1, S) if timed else gen_draft["ms_per_batch"] / max(1, S)
+            byts = gen_bytes_per_step(c.d_model, inner, c.d_ff, c.num_decoder_layers, V, 20, 10, L, (gen_draft["decoded_len"] - 1) // 2 + 1)
             gbs = byts / (step_ms * 1e-3) / 1e9
-            line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step), plain bf16 search", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": byts, "ms_per_step": step_ms,
-                                           "steps": S, "traffic": None,
-                                           "time_source": "device time of the decode loop (engine HIP events) / steps" if timed else "whole generate() / steps",
-                                           "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d))"}
+                                           "steps": S, "forced_prefix_steps": int(timing.get("forced_prefix_steps", 0)), "traffic": None,
+                                           "time_source": "device time of the decode loop (engine HIP events) / decode steps" if timed else "whole generate() / steps",
+                                           "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d)); the steps every item id shares "
+                                                   "run as ONE teacher-forced pass before the loop (p5_decode.h) and are not decode steps"}
         legs_on = [] if args.legs == "none" else (["configs", "task_mix"] if args.legs == "all" else args.legs.split(","))
         if world == 1:
             del model, opt

@@ -156,27 +156,38 @@ int p5_generate_set_forced_prefix(P5Engine* e, const int* tokens, const int* nod
 /* ---- verified generation: the bf16 search proposes, an fp32 pass decides (openp5_amd/csrc/p5_verify.h) ----
  * The reference ranks by the fp32 scores of HF beam search (DistributedRunner.py:361-387, utils/evaluate.py:37-58).  Protocol, two engines
  * over the SAME master parameter arena (a bf16 one for the draft, an fp32 one -- dtype 0 -- for the verification), one stream:
- *   p5_generate_draft (bf16 engine, beam width Kw = K + a few)   -> results ignored, `hist` = what the search kept alive at every step
+ *   p5_verify_begin   (fp32 engine)   -> lays out the verification workspace for this batch shape (host only)
+ *   p5_verify_encode  (fp32 engine)   -> fp32 encoder pass + cross-attention K/V; p5_verify_encoder_output() = its fp32 [B*L, d_model]
+ *   p5_generate_set_encoder_output + p5_generate_draft (bf16 engine, beam width Kw = K + a few): the draft starts from THAT encoder
+ *                                        output (rounded once) instead of running its own encoder; its results are ignored, `hist` = what
+ *                                        the search kept alive at every step
  *   p5_verify_plan    (fp32 engine)   -> the distinct live prefixes of every user ("rows"); p5_verify_plan_header()[0] = the largest
- *                                        row count of any user -- the ONE number the host reads (copy it asynchronously, then enqueue ...)
- *   p5_verify_encode  (fp32 engine)   -> fp32 encoder pass + cross-attention K/V (independent of the plan: runs while the host reads)
+ *                                        row count of any user -- the ONE number the host reads
  *   p5_verify_run     (fp32 engine, rows_per_user >= that number, multiple of 16 recommended)
  *                                     -> one teacher-forced fp32 decoder pass over all rows, full-vocabulary log-sum-exp and the trie
  *                                        children's log-probabilities per row, then HF's beam search of the REAL width K replayed on
  *                                        those numbers.  out_* as p5_generate; out_missing int32 [B]: 1 = the replay needed a prefix the
  *                                        draft had dropped -- that user's result is NOT the fp32 search's and the caller must re-run the
  *                                        user through p5_generate on the fp32 engine (openp5_amd/model.py does).
- * A returned, unflagged list is the fp32 search's list: no bf16 number takes part in any decision or score.  Limits: K <= 22, Kw <= 64. */
+ * A returned, unflagged list is the fp32 search's list: no bf16 number takes part in any decision or score.  The GEMMs of the fp32 passes
+ * multiply on the f16 matrix cores from an exact two-term split of every fp32 operand (csrc/p5_gemm.h; option "verify_split" 0 = fp32
+ * MFMAs).  Limits: K <= 22, Kw <= 64.  A forced prefix set on the fp32 engine (p5_generate_set_forced_prefix) before p5_verify_begin
+ * lets the replay skip the forced steps as the draft does. */
 int64_t p5_generate_history_count(int B, int K, int max_len);      /* ints in `hist` for a draft of beam width K */
 int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
                       int B, int L, int K, int max_len, const int* child_off, const int* child_tok, const int* child_node, const int* roots,
                       const uint32_t* excluded_nodes, int excluded_words, int max_children, int* out_seq, float* out_score, int* out_len,
                       int* hist, void* ws, int64_t ws_bytes, void* stream);
 int64_t p5_verify_workspace_bytes(const P5Engine* e, int B, int L, int K, int Kw, int max_len, int max_children, int excluded_words);
-int p5_verify_plan(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
-                   const int* child_node, const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes, void* stream);
-const int* p5_verify_plan_header(const P5Engine* e);     /* device int[4]: max rows per user, draft steps, total rows, overflow */
+int p5_verify_begin(P5Engine* e, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                    const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes);
 int p5_verify_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, void* stream);
+const void* p5_verify_encoder_output(const P5Engine* e);     /* device fp32 [B*L, d_model], valid after p5_verify_encode until the next p5_verify_begin */
+/* one-shot: the next p5_decode_begin / p5_generate / p5_generate_draft on `e` takes this fp32 encoder output [B*L, d_model] (cast to the
+ * engine's dtype) instead of running its encoder */
+int p5_generate_set_encoder_output(P5Engine* e, const float* enc_out_f32);
+int p5_verify_plan(P5Engine* e, const int* hist, void* stream);
+const int* p5_verify_plan_header(const P5Engine* e);     /* device int[4]: max rows per user, draft steps, total rows, overflow */
 int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len,
                   int* out_missing, void* stream);
 /* Device-time brackets of p5_generate for benchmarks: p5_generate_timing(e, 1, NULL, NULL) arms it; after a p5_generate call,

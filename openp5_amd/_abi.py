@@ -59,7 +59,10 @@ PROTOTYPES = {
     "p5_generate_history_count": (i64, [i32, i32, i32]),
     "p5_generate_draft": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp]),
     "p5_verify_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32, i32]),
-    "p5_verify_plan": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
+    "p5_verify_begin": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, i64]),
+    "p5_verify_encoder_output": (vp, [vp]),
+    "p5_generate_set_encoder_output": (i32, [vp, vp]),
+    "p5_verify_plan": (i32, [vp, vp, vp]),
     "p5_verify_plan_header": (vp, [vp]),
     "p5_verify_encode": (i32, [vp, vp, vp, vp, vp]),
     "p5_verify_run": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),

@@ -763,6 +763,98 @@ __global__ __launch_bounds__(256) void p5_gemm_kernel(P5GemmArgs g) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 x fp32 K-contiguous GEMM with split products (see p5_split8 above), pipelined three K-steps deep.  p5_gemm_kernel<.., MM = 1> is
+// correct but exposes a global-load latency per 32-wide K-step (one step of lookahead: 2 us per step on the verification pass's
+// 2560 x 1536 x 512 -- 127 TF/s where the three f16 MFMAs per step take 0.1 us).  Here the loads of K-step s+3 are issued before step s
+// is multiplied (three register stages: at 64 x 64 tiles that is 12 registers), the split + LDS store of step s+1 follows the MFMAs of
+// step s, one barrier per step.  Loads past K are predicated off and read as zeros, so the loop body has no tail variants.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void p5_gemm_split_kernel(P5GemmArgs g) {
+  using T = float;
+  constexpr int TM = BM / 32, TN = BN / 32, KCH = TT<T>::KCH;
+  constexpr int ACH = LdsChunk<T, BM, false>::BYTES, BCH = LdsChunk<T, BN, false>::BYTES;
+  constexpr int STAGE = 2 * (ACH + BCH);
+  constexpr int NA = BM * 4 / 256, NB = BN * 4 / 256;
+  constexpr int CST = BN * 2 + 16;
+  constexpr int LDS_BYTES = (2 * STAGE > BM * CST) ? 2 * STAGE : BM * CST;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  gemm_tile_origin<BM, BN>(g, m0, n0);
+  const int nst = (g.K + 2 * KCH - 1) / (2 * KCH);
+  const T* __restrict__ A = (const T*)g.A;
+  const T* __restrict__ Bp = (const T*)g.B;
+  f32x4 acc[TM][TN], acc2[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  u32x4 ra0[2][NA], ra1[2][NA], ra2[2][NA], rb0[2][NB], rb1[2][NB], rb2[2][NB];
+  auto load = [&](u32x4(&ra)[2][NA], u32x4(&rb)[2][NB], int st) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      stage_load<T, BM, false>(ra[c], A, g.lda, m0, (st * 2 + c) * KCH, g.M, g.K, tid);
+      stage_load<T, BN, false>(rb[c], Bp, g.ldb, n0, (st * 2 + c) * KCH, g.N, g.K, tid);
+    }
+  };
+  auto store = [&](const u32x4(&ra)[2][NA], const u32x4(&rb)[2][NB], char* stage) {
+    stage_store_split<BM>(ra[0], ra[1], stage, stage + ACH, tid);
+    stage_store_split<BN>(rb[0], rb[1], stage + 2 * ACH, stage + 2 * ACH + BCH, tid);
+  };
+  auto compute = [&](const char* base) {
+    u32x4 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      fah[i] = frag_load<T, BM, false>(base, wm * (BM / 2) + i * 16, lane);
+      fal[i] = frag_load<T, BM, false>(base + ACH, wm * (BM / 2) + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      fbh[j] = frag_load<T, BN, false>(base + 2 * ACH, wn * (BN / 2) + j * 16, lane);
+      fbl[j] = frag_load<T, BN, false>(base + 2 * ACH + BCH, wn * (BN / 2) + j * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        mma32_f16(acc[i][j], fah[i], fbh[j]);
+        mma32_f16(acc2[i][j], fah[i], fbl[j]);
+        mma32_f16(acc2[i][j], fal[i], fbh[j]);
+      }
+  };
+  load(ra0, rb0, 0);
+  load(ra1, rb1, 1);
+  load(ra2, rb2, 2);
+  store(ra0, rb0, lds);
+  __syncthreads();
+  // step s lives in register stage s % 3 until it is stored; LDS stage s & 1
+#define P5_SPLIT_STEP(RA_CUR, RB_CUR, RA_NEXT, RB_NEXT, OFF)                                  \
+  if (st + (OFF) < nst) {                                                                       \
+    load(RA_CUR, RB_CUR, st + (OFF) + 3);              /* (its own step was stored a step ago) */ \
+    compute(lds + ((st + (OFF)) & 1) * STAGE);                                                  \
+    if (st + (OFF) + 1 < nst) store(RA_NEXT, RB_NEXT, lds + ((st + (OFF) + 1) & 1) * STAGE);     \
+    P5_SCHED_FENCE();                                                                           \
+    __syncthreads();                                                                            \
+  }
+  for (int st = 0; st < nst; st += 3) {
+    P5_SPLIT_STEP(ra0, rb0, ra1, rb1, 0)
+    P5_SPLIT_STEP(ra1, rb1, ra2, rb2, 1)
+    P5_SPLIT_STEP(ra2, rb2, ra0, rb0, 2)
+  }
+#undef P5_SPLIT_STEP
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += acc2[i][j][r] * (1.f / 4096.f);
+  gemm_epilogue<T, BM, BN, LDS_BYTES>(g, acc, lds, m0, n0, tid);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------------------
 // v2 main loop for the bf16 K-contiguous x K-contiguous case (every forward Linear): same tile, same LDS image

@@ -165,6 +165,7 @@ struct P5Engine {
   int64_t fold_E = 0, fold_count = 0;
   GenCtx gen;
   int* gen_hist_next = nullptr;    // p5_generate_draft: history buffer of the NEXT search (one-shot)
+  const float* enc_ext_next = nullptr;   // p5_generate_set_encoder_output: fp32 encoder output the NEXT search starts from (one-shot)
   P5Forced ff_next = {0, {0}, {0}};  // p5_generate_set_forced_prefix: forced prefix of the NEXT search (one-shot)
   struct VerifyCtx* ver = nullptr;  // state of a verification pass between p5_verify_plan and p5_verify_run (p5_verify.h)
   // transposed bf16 copies of the 2-D layer weights (same arena offsets): the data gradients dx = dy W then read W^T as a
@@ -1433,7 +1434,20 @@ static int decode_begin_impl(P5Engine* e, int B, int L, int K, int max_len, cons
   e->gen_hist_next = nullptr;
   if (!excluded) excl_words = 0;
   e->B = B; e->L = L; e->T = 0; e->M = B * L; e->Md = 0; e->training = 0;
-  P5_TRY(encoder_fwd<T>(e, s));
+  if (e->enc_ext_next) {
+    // the encoder output of the verification pass (fp32, same weights), rounded once to this engine's dtype: one encoder pass per batch
+    // instead of two, and a draft that starts from the better numbers
+    const size_t n = (size_t)B * L * d;
+    if constexpr (sizeof(T) == 2) {
+      P5_LAUNCH((p5_cast_kernel<T>), dim3((unsigned)((n / 8 + 255) / 256 > 2048 ? 2048 : (n / 8 + 255) / 256)), dim3(256), 0, s, (T*)e->enc_out, e->enc_ext_next, n);
+      P5_TRY(P5_KCHECK());
+    } else {
+      hipMemcpyAsync(e->enc_out, e->enc_ext_next, n * 4, hipMemcpyDeviceToDevice, s);
+    }
+    e->enc_ext_next = nullptr;
+  } else {
+    P5_TRY(encoder_fwd<T>(e, s));
+  }
   // forced-prefix fast-forward (p5_decode.h): the first F steps as one teacher-forced pass of the training-layout decoder over B x F rows
   P5Forced ff = e->ff_next;
   e->ff_next.n = 0;
@@ -1572,7 +1586,8 @@ struct VerifyWs {
   P5BeamState st;
 };
 struct VerifyCtx {
-  int stage = 0;       // 1 = planned, 2 = encoded
+  bool begun = false, encoded = false, planned = false;
+  P5Forced ff = {0, {0}, {0}};     // forced prefix of the search being verified (p5_generate_set_forced_prefix on this engine before p5_verify_begin)
   VerifyWs w;
   int B = 0, L = 0, K = 0, Kw = 0, max_len = 0, max_c = 0, excl_words = 0;
   const int *child_off = nullptr, *child_tok = nullptr, *child_node = nullptr, *roots = nullptr;
@@ -1626,18 +1641,27 @@ static int64_t layout_verify(P5Engine* e, char* base, int B, int L, int K, int K
   return (int64_t)((b.off + 255) & ~(size_t)255);
 }
 
-static int verify_plan_impl(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
-                            const int* child_node, const int* roots, int max_c, int excl_words, char* ws, hipStream_t s) {
+static int verify_begin_impl(P5Engine* e, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
+                             const int* child_node, const int* roots, int max_c, int excl_words, char* ws) {
   if (!e->ver) e->ver = new VerifyCtx();
   VerifyCtx& v = *e->ver;
-  v.stage = 0;
+  v.begun = v.encoded = v.planned = false;
   layout_verify(e, ws, B, L, K, Kw, max_len, max_c, excl_words, &v.w);
   v.B = B; v.L = L; v.K = K; v.Kw = Kw; v.max_len = max_len; v.max_c = max_c; v.excl_words = excl_words; v.ws = ws;
   v.child_off = child_off; v.child_tok = child_tok; v.child_node = child_node; v.roots = roots;
+  v.ff = e->ff_next;
+  e->ff_next.n = 0;
+  if (v.ff.n < 2 || roots != nullptr || !g_opt_gen_ff) v.ff.n = 0;
+  if (v.ff.n > max_len - 2) v.ff.n = max_len - 2 > 0 ? max_len - 2 : 0;
+  v.begun = true;
+  return 0;
+}
+static int verify_plan_impl(P5Engine* e, const int* hist, hipStream_t s) {
+  VerifyCtx& v = *e->ver;
   hipMemsetAsync(v.w.pl.hdr, 0, 64, s);
-  P5_LAUNCH(p5_verify_plan_kernel, dim3(B), dim3(256), 0, s, v.w.pl, hist, child_off, child_tok, child_node, roots, B, Kw, e->c.pad_id);
+  P5_LAUNCH(p5_verify_plan_kernel, dim3(v.B), dim3(256), 0, s, v.w.pl, hist, v.child_off, v.child_tok, v.child_node, v.roots, v.B, v.Kw, e->c.pad_id);
   P5_TRY(P5_KCHECK());
-  v.stage = 1;
+  v.planned = true;
   return 0;
 }
 
@@ -1652,7 +1676,7 @@ static int verify_encode_impl(P5Engine* e, const int64_t* input_ids, const int64
   e->ids = input_ids; e->ww = whole_word_ids; e->mask = attention_mask; e->labels = nullptr;
   P5_TRY(encoder_fwd<T>(e, s));
   P5_TRY(linear_fwd<T>(s, e->enc_out, c.d_model, Wc<T>(e, e->dec[0].ca.k), v.w.kv_all, c.n_dec_layers * 2 * e->inner, v.B * v.L, c.n_dec_layers * 2 * e->inner, c.d_model));
-  v.stage = 2;
+  v.encoded = true;
   return 0;
 }
 
@@ -1733,8 +1757,19 @@ static int verify_run_impl(P5Engine* e, int PU, const uint32_t* excluded, int* o
             c.pad_id);
   P5_TRY(P5_KCHECK());
   hipMemsetAsync(w.vrow_a, 0, (size_t)R * 4, s);        // every beam starts on row 0 (the start prefix)
+  hipMemsetAsync(w.vrow_b, 0, (size_t)R * 4, s);
   hipMemsetAsync(w.missing, 0, (size_t)B * 4, s);
-  for (int cur_len = 1; cur_len < max_len; ++cur_len) {
+  int first = 1;
+  if (v.ff.n > 0) {
+    // the forced steps of the replay (p5_decode.h): rows 0 .. F-1 are the forced chain (one live prefix per depth), each with ONE child
+    P5_LAUNCH(p5_verify_forced_kernel, dim3((R + B * v.ff.n + 255) / 256), dim3(256), 0, s, w.zeros, w.vrow_a, w.vrow_b, (const float*)w.row_top_score, PU, 2 * K,
+              B, K, v.ff.n);
+    P5_TRY(P5_KCHECK());
+    P5_LAUNCH(p5_beam_forced_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, w.st, v.ff, (const float*)w.zeros, B, K, max_len, c.pad_id);
+    P5_TRY(P5_KCHECK());
+    first = v.ff.n + 1;
+  }
+  for (int cur_len = first; cur_len < max_len; ++cur_len) {
     P5_LAUNCH(p5_verify_step_kernel, dim3(B), dim3(256), 0, s, w.st, w.pl, (const float*)w.row_top_score, (const int*)w.row_top_c, (const int*)w.n_top, PU,
               v.child_off, v.child_tok, v.child_node, excl, v.excl_words, v.max_c, K, max_len, c.eos_id, R, w.vrow_a, w.vrow_b, w.missing);
     P5_TRY(P5_KCHECK());
@@ -1742,7 +1777,7 @@ static int verify_run_impl(P5Engine* e, int PU, const uint32_t* excluded, int* o
   P5_LAUNCH(p5_beam_finalize_kernel, dim3((R * max_len + 255) / 256), dim3(256), 0, s, out_seq, out_score, out_len, w.st, R, max_len);
   P5_TRY(P5_KCHECK());
   hipMemcpyAsync(out_missing, w.missing, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
-  v.stage = 0;
+  v.begun = v.encoded = v.planned = false;
   return 0;
 }
 
@@ -2269,10 +2304,9 @@ int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whol
 int64_t p5_verify_workspace_bytes(const P5Engine* e, int B, int L, int K, int Kw, int max_len, int max_children, int excluded_words) {
   return layout_verify(const_cast<P5Engine*>(e), nullptr, B, L, K, Kw, max_len, max_children, excluded_words, nullptr);
 }
-int p5_verify_plan(P5Engine* e, const int* hist, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok,
-                   const int* child_node, const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes, void* stream) {
+int p5_verify_begin(P5Engine* e, int B, int L, int K, int Kw, int max_len, const int* child_off, const int* child_tok, const int* child_node,
+                    const int* roots, int max_children, int excluded_words, void* ws, int64_t ws_bytes) {
   P5_REQUIRE(e->P, "engine not bound");
-  P5_REQUIRE(hist, "p5_verify_plan: history of the draft search");
   P5_REQUIRE(K >= 1 && 2 * K * K <= P5_VERIFY_POOL, "verified generation: 1 <= num_beams <= 22");
   P5_REQUIRE(Kw >= K && Kw <= P5_MAX_K, "draft beam width: num_beams <= Kw <= 64");
   P5_REQUIRE(max_len >= 2 && max_len <= P5_MAX_LEN, "2 <= max_length <= 128 (P5_MAX_LEN)");
@@ -2281,22 +2315,29 @@ int p5_verify_plan(P5Engine* e, const int* hist, int B, int L, int K, int Kw, in
   P5_REQUIRE(e->lut_half >= max_len, "bucket LUT too short");
   const int64_t need = layout_verify(e, nullptr, B, L, K, Kw, max_len, max_children, excluded_words, nullptr);
   P5_REQUIRE(ws_bytes >= need, "workspace too small");
-  return verify_plan_impl(e, hist, B, L, K, Kw, max_len, child_off, child_tok, child_node, roots, max_children, excluded_words, (char*)ws, (hipStream_t)stream);
+  return verify_begin_impl(e, B, L, K, Kw, max_len, child_off, child_tok, child_node, roots, max_children, excluded_words, (char*)ws);
 }
-const int* p5_verify_plan_header(const P5Engine* e) { return (e->ver && e->ver->stage >= 1) ? e->ver->w.pl.hdr : nullptr; }
 int p5_verify_encode(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask, void* stream) {
-  P5_REQUIRE(e->ver && e->ver->stage == 1, "p5_verify_encode without p5_verify_plan");
+  P5_REQUIRE(e->ver && e->ver->begun, "p5_verify_encode without p5_verify_begin");
   return e->c.dtype == 1 ? verify_encode_impl<bf16>(e, input_ids, whole_word_ids, attention_mask, (hipStream_t)stream)
                          : verify_encode_impl<float>(e, input_ids, whole_word_ids, attention_mask, (hipStream_t)stream);
 }
+const void* p5_verify_encoder_output(const P5Engine* e) { return (e->ver && e->ver->encoded) ? e->enc_out : nullptr; }
+int p5_verify_plan(P5Engine* e, const int* hist, void* stream) {
+  P5_REQUIRE(e->ver && e->ver->begun, "p5_verify_plan without p5_verify_begin");
+  P5_REQUIRE(hist, "p5_verify_plan: history of the draft search");
+  return verify_plan_impl(e, hist, (hipStream_t)stream);
+}
+const int* p5_verify_plan_header(const P5Engine* e) { return (e->ver && e->ver->begun) ? e->ver->w.pl.hdr : nullptr; }
 int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len, int* out_missing,
                   void* stream) {
-  P5_REQUIRE(e->ver && e->ver->stage == 2, "p5_verify_run without p5_verify_plan + p5_verify_encode");
+  P5_REQUIRE(e->ver && e->ver->begun && e->ver->encoded && e->ver->planned, "p5_verify_run needs p5_verify_begin + p5_verify_encode + p5_verify_plan");
   P5_REQUIRE(rows_per_user >= 1 && rows_per_user <= e->ver->w.pl.cap, "rows_per_user: 1 .. capacity of the plan");
   P5_REQUIRE(e->ver->excl_words == 0 || excluded_nodes, "excluded_nodes");
   return e->c.dtype == 1 ? verify_run_impl<bf16>(e, rows_per_user, excluded_nodes, out_seq, out_score, out_len, out_missing, (hipStream_t)stream)
                          : verify_run_impl<float>(e, rows_per_user, excluded_nodes, out_seq, out_score, out_len, out_missing, (hipStream_t)stream);
 }
+int p5_generate_set_encoder_output(P5Engine* e, const float* enc_out_f32) { e->enc_ext_next = enc_out_f32; return 0; }
 int p5_generate_timing(P5Engine* e, int enable, float* encode_ms, float* decode_ms) {
 #ifndef P5_EMU
   if (encode_ms || decode_ms) {

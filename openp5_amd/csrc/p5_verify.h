@@ -214,6 +214,16 @@ __global__ __launch_bounds__(256) void p5_tree_attn_kernel(T* __restrict__ out, 
 // row_top_*: the per-ROW candidate lists written by p5_dec_score2_kernel / p5_dec_score_kernel with a zero running score: entry i of row
 // r is (log p of the row's i-th best child, child index), sorted (score desc, child asc).  vrow_*: verification row of every running
 // beam (double-buffered by the parity of cur_len like the other beam state), -1 = none (dead beam, or a live prefix the draft never kept).
+// forced steps of the replay (p5_decode.h, forced-prefix fast-forward): rows 0 .. F-1 are the chain, each with exactly one candidate -- its
+// log-probability is what the step adds to beam 0; every beam then stands on row F
+__global__ __launch_bounds__(256) void p5_verify_forced_kernel(float* __restrict__ nll, int* __restrict__ vrow_a, int* __restrict__ vrow_b,
+                                                              const float* __restrict__ row_top_score, int PU, int K2, int B, int Kb, int F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * F) nll[i] = -row_top_score[((size_t)(i / F) * PU + (i % F)) * K2];
+  const int j = i - B * F;
+  if (j >= 0 && j < B * Kb) { vrow_a[j] = F; vrow_b[j] = F; }
+}
+
 #define P5_VERIFY_POOL 1024          // Kb x 2 Kb candidates of the replay: real beam widths up to 22 (the DRAFT may be as wide as P5_MAX_K)
 __global__ __launch_bounds__(256) void p5_verify_step_kernel(P5BeamState st, P5VerifyPlan pl, const float* __restrict__ row_top_score,
                                                             const int* __restrict__ row_top_c, const int* __restrict__ row_n_top, int PU,

@@ -131,6 +131,7 @@ class P5T5Native(nn.Module):
     # always runs the plain (fp32) search.
     generation_mode = "verified"
     verify_extra_beams = 6
+    verify_share_encoder = True   # verified mode: the draft starts from the verification pass's fp32 encoder output (one encoder pass per batch)
     prefix_fast_forward = True    # the steps every item shares ("<dataset> item _") as one teacher-forced pass (p5_generate_set_forced_prefix)
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
@@ -720,23 +721,27 @@ class P5T5Native(nn.Module):
         ev = self._verify_engine()
         common = (input_ids, whole_word_ids, attention_mask, B, L)
         trie_args = (off, tok, nxt, roots_t, excl_t, excl_words, maxc)
+        ftok, fnode = self._forced
+        if ftok:      # (the replay skips the forced steps as the draft does)
+            arr = (ctypes.c_int * len(ftok))
+            self._be.check(lib.p5_generate_set_forced_prefix(ev, arr(*ftok), arr(*fnode), len(ftok)), "p5_generate_set_forced_prefix (verify)")
+        ws = self._workspace(lib.p5_verify_workspace_bytes(ev, B, L, K, Kw, max_length, maxc, excl_words), "_ver_ws")
+        self._be.check(lib.p5_verify_begin(ev, B, L, K, Kw, max_length, _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, excl_words, _ptr(ws), ws.numel()),
+                       "p5_verify_begin")
+        # ONE encoder pass per batch: the fp32 one; the draft starts from its output
+        self._be.check(lib.p5_verify_encode(ev, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), sp), "p5_verify_encode")
+        if self.verify_share_encoder:
+            self._be.check(lib.p5_generate_set_encoder_output(self._engine, ctypes.c_void_p(lib.p5_verify_encoder_output(ev))), "p5_generate_set_encoder_output")
         hist = torch.zeros(int(lib.p5_generate_history_count(B, Kw, max_length)), dtype=torch.int32, device=dev)
         self._search(self._engine, "_gen_ws", *common, Kw, max_length, *trie_args, hist=hist)
-        ws = self._workspace(lib.p5_verify_workspace_bytes(ev, B, L, K, Kw, max_length, maxc, excl_words), "_ver_ws")
-        self._be.check(lib.p5_verify_plan(ev, _ptr(hist), B, L, K, Kw, max_length, _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, excl_words,
-                                          _ptr(ws), ws.numel(), sp), "p5_verify_plan")
+        self._be.check(lib.p5_verify_plan(ev, _ptr(hist), sp), "p5_verify_plan")
         hdr_off = int(lib.p5_verify_plan_header(ev)) - ws.data_ptr()
         hdr_dev = ws[hdr_off:hdr_off + 16].view(torch.int32)
         if ws.is_cuda:
-            # the ONE number the host needs (rows per user) travels while the fp32 encoder pass runs
             if self._ver_hdr is None:
                 self._ver_hdr = torch.zeros(4, dtype=torch.int32).pin_memory()
-                self._ver_ev = torch.cuda.Event()
-            self._ver_hdr.copy_(hdr_dev, non_blocking=True)
-            self._ver_ev.record()
-        self._be.check(lib.p5_verify_encode(ev, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), sp), "p5_verify_encode")
-        if ws.is_cuda:
-            self._ver_ev.synchronize()
+            self._ver_hdr.copy_(hdr_dev, non_blocking=True)      # the ONE number the host needs: rows per user of this batch
+            torch.cuda.current_stream().synchronize()
             hdr = self._ver_hdr.tolist()
         else:
             hdr = hdr_dev.cpu().tolist()

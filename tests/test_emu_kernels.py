@@ -281,6 +281,12 @@ def test_generate_draft_mode_is_the_plain_bf16_search(emu):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="draft", score_tol=0.05)
 
 
+def test_released_checkpoint_layout_loads(emu, tmp_path):
+    """utils.load_model on a file in the released checkpoints' layout (stock-HF keys with the duplicated tied tables + the whole-word
+    table, larger vocabulary) == stock HF on the same weights."""
+    cases.released_checkpoint_case(emu, str(tmp_path), O.T5Cfg.named("tiny"))
+
+
 def test_train_trajectory_fp32(emu):
     """3 fused optimizer steps == the oracle's clip + HF-AdamW + warmup trajectory."""
     cases.train_trajectory_case(emu, O.T5Cfg.named("tiny"), 2, 12, 5)

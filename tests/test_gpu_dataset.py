@@ -23,5 +23,5 @@ def test_dataset_level_ml1m_shaped_trie(hip, tmp_path):
     which the beam keeps 10 -- followed by a ~100-way one per kept prefix): the search prunes at more than one step, so an early error
     would compound (the 150-item gate above has two first pieces and keeps both: one decision).  80 users x 2 tasks."""
     r = cases.dataset_gate(hip, str(tmp_path), lambda v: O.T5Cfg.named("t5-small", dropout=0.0, vocab_size=v), K=10, min_users=150,
-                           dataset="ML1M", n_users=80, n_items=3416, n_inter=80 * 40, flags=["--epochs", "6", "--lr", "1e-3"])
+                           loss_drop=0.85, dataset="ML1M", n_users=80, n_items=3416, n_inter=80 * 40, flags=["--epochs", "6", "--lr", "5e-4"])
     assert len(r["levels"]) >= 2, r["levels"]          # the returned items differ at two token positions at least: decisions at several steps

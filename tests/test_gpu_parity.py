@@ -185,6 +185,11 @@ def test_generate_verified_edge_cases(hip):
     cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4, dtype="bf16", mode="verified", extra_beams=0)
 
 
+def test_released_checkpoint_layout_loads(hip, tmp_path):
+    cases.released_checkpoint_case(hip, str(tmp_path), O.T5Cfg.named("tiny"))
+    cases.released_checkpoint_case(hip, str(tmp_path), O.T5Cfg.named("t5-small", num_layers=1, num_decoder_layers=1, vocab_size=32100), nll_tol=1e-4)
+
+
 def test_train_trajectory_fp32(hip):
     cases.train_trajectory_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6)
 
