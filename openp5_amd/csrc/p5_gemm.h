@@ -793,11 +793,36 @@ __global__ __launch_bounds__(256) void p5_gemm_split_kernel(P5GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   u32x4 ra0[2][NA], ra1[2][NA], ra2[2][NA], rb0[2][NB], rb1[2][NB], rb2[2][NB];
+  // The loads are RAW (inline asm, p5_device.h gload16_raw): with compiler-tracked loads -- predicated per lane for the matrix edges --
+  // hipcc waits for EVERY load in flight at the loop header (`s_waitcnt vmcnt(0)`, ISA of the first version), i.e. the three-deep
+  // prefetch bought 10 %.  Rows past the edge are clamped (they only feed C rows / columns that are never stored), K is a multiple of
+  // 32 (launcher), steps past the last one re-fetch it (constant count of loads in flight), and the waits are counted by hand:
+  // LPS loads per step and thread, two later steps may still be in flight when a step is split into LDS.
+  constexpr int LPS = 2 * (NA + NB);
+  const T* pa[NA];
+  const T* pb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int c = tid + i * 256;
+    int gr = m0 + (c >> 2);
+    gr = gr < g.M ? gr : g.M - 1;
+    pa[i] = A + (size_t)gr * g.lda + (c & 3) * TT<T>::EPF;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int c = tid + i * 256;
+    int gr = n0 + (c >> 2);
+    gr = gr < g.N ? gr : g.N - 1;
+    pb[i] = Bp + (size_t)gr * g.ldb + (c & 3) * TT<T>::EPF;
+  }
   auto load = [&](u32x4(&ra)[2][NA], u32x4(&rb)[2][NB], int st) {
+    const int k0 = (st < nst ? st : nst - 1) * 2 * KCH;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      stage_load<T, BM, false>(ra[c], A, g.lda, m0, (st * 2 + c) * KCH, g.M, g.K, tid);
-      stage_load<T, BN, false>(rb[c], Bp, g.ldb, n0, (st * 2 + c) * KCH, g.N, g.K, tid);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) gload16_raw(ra[c][i], pa[i] + k0 + c * KCH);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) gload16_raw(rb[c][i], pb[i] + k0 + c * KCH);
     }
   };
   auto store = [&](const u32x4(&ra)[2][NA], const u32x4(&rb)[2][NB], char* stage) {
@@ -828,22 +853,29 @@ __global__ __launch_bounds__(256) void p5_gemm_split_kernel(P5GemmArgs g) {
   load(ra0, rb0, 0);
   load(ra1, rb1, 1);
   load(ra2, rb2, 2);
+  P5_WAIT_VM(2 * LPS);
+  P5_SCHED_FENCE();
   store(ra0, rb0, lds);
-  __syncthreads();
+  P5_BARRIER_LDS();
   // step s lives in register stage s % 3 until it is stored; LDS stage s & 1
 #define P5_SPLIT_STEP(RA_CUR, RB_CUR, RA_NEXT, RB_NEXT, OFF)                                  \
   if (st + (OFF) < nst) {                                                                       \
     load(RA_CUR, RB_CUR, st + (OFF) + 3);              /* (its own step was stored a step ago) */ \
     compute(lds + ((st + (OFF)) & 1) * STAGE);                                                  \
-    if (st + (OFF) + 1 < nst) store(RA_NEXT, RB_NEXT, lds + ((st + (OFF) + 1) & 1) * STAGE);     \
+    if (st + (OFF) + 1 < nst) {                                                                 \
+      P5_WAIT_VM(2 * LPS);                             /* step s+1 has landed; s+2, s+3 may fly */ \
+      P5_SCHED_FENCE();                                                                         \
+      store(RA_NEXT, RB_NEXT, lds + ((st + (OFF) + 1) & 1) * STAGE);                              \
+    }                                                                                           \
     P5_SCHED_FENCE();                                                                           \
-    __syncthreads();                                                                            \
+    P5_BARRIER_LDS();                                                                           \
   }
   for (int st = 0; st < nst; st += 3) {
     P5_SPLIT_STEP(ra0, rb0, ra1, rb1, 0)
     P5_SPLIT_STEP(ra1, rb1, ra2, rb2, 1)
     P5_SPLIT_STEP(ra2, rb2, ra0, rb0, 2)
   }
+  P5_WAIT_VM(0);            // (the re-fetches past the last step) before the epilogue's own memory traffic
 #undef P5_SPLIT_STEP
 #pragma unroll
   for (int i = 0; i < TM; ++i)

@@ -24,7 +24,7 @@ int g_opt_gemm_ring_n512 = getenv("P5_GEMM_RING_N512") ? atoi(getenv("P5_GEMM_RI
 int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;          // ring depth of the 128x128 configuration
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
 int g_opt_split_pipe = getenv("P5_SPLIT_PIPE") ? atoi(getenv("P5_SPLIT_PIPE")) : 1;    // split-f16 fp32 GEMMs: the three-deep pipelined kernel (0 = p5_gemm_kernel<MM = 1>)
-int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 160;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them
+int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 0;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them (0 = the fp32 rule: from 512; measured on the verification pass, 64x64 tiles win below that: 5.05 vs 5.30 ms per batch)
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -82,7 +82,7 @@ static int launch_gemm_tile(P5GemmArgs g, hipStream_t s) {
   if constexpr (sizeof(T) == 4 && BM <= 128) {
     if (mode == 0 && g.mm_split) {       // fp32 operands, products on the f16 matrix cores (p5_gemm.h, two-term split)
       P5_PROF_TAG(BM == 128 ? "f32 128x128 split-f16" : "f32 64x64 split-f16");
-      if (g_opt_split_pipe && g.splitk <= 1) P5_LAUNCH((p5_gemm_split_kernel<BM, BN>), grid, block, 0, s, g);      // three K-steps of lookahead
+      if (g_opt_split_pipe && g.splitk <= 1 && (g.K % 32) == 0) P5_LAUNCH((p5_gemm_split_kernel<BM, BN>), grid, block, 0, s, g);      // three K-steps of lookahead
       else P5_LAUNCH((p5_gemm_kernel<T, BM, BN, false, false, 2, false, false, 1>), grid, block, 0, s, g);
       return P5_KCHECK();
     }

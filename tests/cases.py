@@ -1473,7 +1473,7 @@ def dropped_gap_first(x, x_lp, ranked, ranked_lp):
     return float("inf")
 
 
-def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, loss_drop=0.7, **pipeline):
+def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, loss_drop=0.7, bf16_set_diff_max=BF16_SET_DIFF_MAX, **pipeline):
     """The dataset-level evaluation gate of tests/test_gpu_dataset.py: a model trained through the real pipeline (bf16 engine), then every
     test user of both tasks ranked FOUR ways with the same weights -- fp32 CPU oracle (HF beam search restated + Python trie callbacks), the
     bf16 model in its default "verified" mode (bf16 search with extra beams proposes, one fp32 pass decides: csrc/p5_verify.h), the fp32
@@ -1556,7 +1556,7 @@ def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, 
           f"{c16['identical_up_to_ties']} identical up to oracle ties, same gold rank {c16['same_gold_rank']}")
     assert tf16["score_viol"] == 0 and tf16["order_viol"] == 0, {k: v for k, v in tf16.items() if not isinstance(v, list)}
     assert c16["max_score_diff"] <= BF16_SCORE_TOL, c16
-    assert set_diff <= BF16_SET_DIFF_MAX * n_users, (set_diff, n_users)
+    assert set_diff <= bf16_set_diff_max * n_users, (set_diff, n_users)
     assert len(unexplained) == 0, unexplained
     assert c16["same_gold_rank"] >= 0.95 * n_users and c16["same_topk_set"][5] >= 0.95 * n_users, c16
     return {"verify_stats": vstats, "cver": cver, "c16": c16, "set_diff": set_diff, "depth": depth, "levels": levels}
