@@ -578,6 +578,11 @@ def main():
     if not args.no_gen:
         gB, gK = 20, 10
         trie = synth_item_trie(3416, 7)
+        # random-init weights of the architecture (as every generation number of rounds 1-4's fp32 leg and tools/gen_bench.py): the model the
+        # training loop above has just pushed through 25 steps on NOISE scores every item within ~1e-3 of every other (loss ~ ln V), a regime in
+        # which no lower-precision proposer can know the fp32 top-K -- that number is reported too (`generation_after_noise_training`)
+        trained = model
+        _, model, _ = build_model(args.backbone, args.dtype, device, be, world, rank)
         gdt, dec_len, timing, med, vst = time_generation(model, gB, gK, L, trie, 30, args.gen_batches, world, device, 500 + rank, mode="verified")
         gen = {"mode": "verified (bf16 search with 6 extra beams proposes, one teacher-forced fp32 pass decides; csrc/p5_verify.h)",
                "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3, "ms_per_batch_median_call": med,
@@ -587,6 +592,11 @@ def main():
         gen_draft = {"mode": "draft (plain bf16 search)", "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3,
                      "ms_per_batch_median_call": med, "users_per_batch": gB, "num_beams": gK, "decoded_len": dec_len, "timing_ms": timing}
         model.generation_mode = "verified"
+        gdt, _, _, med, vst2 = time_generation(trained, gB, gK, L, trie, 30, 5, world, device, 500 + rank, mode="verified")
+        gen["after_noise_training"] = {"items_per_s": world * gB * gK * 5 / gdt, "ms_per_batch": gdt / 5 * 1e3, "verify_stats": vst2,
+                                       "note": "the same call on the model the timed training steps left behind (25 steps on random labels): near-uniform item scores, "
+                                               "so the fp32 top-K is not among the bf16 draft's beams for some users; they get a wider draft, then the fp32 search"}
+        model = trained
 
     if rank == 0:
         c = cfg

@@ -116,6 +116,13 @@ int p5_backward_stage_range(const P5Engine* e, int stage, int64_t* begin, int64_
  * layer and one range per stage).  Ranges are contiguous and walk the arena from the back. */
 int p5_backward_final_range(const P5Engine* e, int64_t* begin, int64_t* end);
 int p5_backward_stage_pairs(P5Engine* e, int on);
+/* The staged backward as ONE call: all stages are enqueued on `stream`; ranges[2k], ranges[2k+1] = the k-th gradient range that became final
+ * (arena offsets, in completion order), *n_ranges their number (<= max_ranges, <= p5_backward_num_stages).  Behind each one an event is
+ * recorded on `stream`: p5_backward_staged_wait(e, k, comm_stream) makes `comm_stream` wait for it (hipStreamWaitEvent, no host wait), after
+ * which the caller enqueues the exchange of range k there -- DDP's bucketed all-reduce overlapped with the rest of the backward
+ * (/root/reference/src/src_t5/main.py:158-160 wraps the model in DDP) without one host round trip per stage. */
+int p5_backward_staged(P5Engine* e, const float* dnll, void* stream, int64_t* ranges, int max_ranges, int* n_ranges);
+int p5_backward_staged_wait(P5Engine* e, int k, void* comm_stream);
 
 /* out_partials: float[1024], fully overwritten; p5_adamw_step sums them in a fixed order (bit-identical on every rank) */
 int p5_grad_sumsq(const float* grads, int64_t n, float* out_partials, void* stream);

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "p5_backward_stage_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "p5_backward_final_range": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
     "p5_backward_stage_pairs": (i32, [vp, i32]),
+    "p5_backward_staged": (i32, [vp, vp, vp, C.POINTER(i64), i32, C.POINTER(i32)]),
+    "p5_backward_staged_wait": (i32, [vp, i32, vp]),
     "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     "p5_decode_fold_count": (i64, [vp]),

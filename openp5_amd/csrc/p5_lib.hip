@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void p5_tr_probe_kernel(unsigned short* out, co
 // =====================================================================================================
 // engine
 // =====================================================================================================
+static constexpr int P5_MAX_STAGED = 160;     // final gradient ranges of one staged backward (<= stages: n_dec + n_enc + 4)
 static constexpr int P5_NSETS = 8;      // >= 2 x (sub-layers of a decoder layer), >= 2 x (sub-layers of the encoder layers grouped into one launch)
 struct ParamInfo { std::string name; int64_t off; int rows, cols; };
 struct AttnOff { int64_t q, k, v, o, ln; };
@@ -184,6 +185,10 @@ struct P5Engine {
   hipGraphExec_t gen_graph_exec = nullptr;
   bool gen_graph_failed = false;
   GraphKey gen_graph_key;
+#endif
+  int st_n = 0;                   // p5_backward_staged: final ranges of the last call (events st_ev[0 .. st_n))
+#ifndef P5_EMU
+  hipEvent_t st_ev[P5_MAX_STAGED] = {};
 #endif
   // optional second stream for the weight-gradient GEMMs (off the critical dgrad chain)
   hipStream_t side = nullptr;
@@ -2150,6 +2155,39 @@ int p5_backward_stage(P5Engine* e, const float* dnll, int stage, void* stream) {
 // the gradient range that became FINAL with the most recent p5_backward_stage call (empty while a grouped weight-gradient launch is
 // still collecting problems): contiguous, because the stages walk the arena from the back.  What a data-parallel caller all-reduces.
 int p5_backward_final_range(const P5Engine* e, int64_t* begin, int64_t* end) { *begin = e->rep_b; *end = e->rep_e; return 0; }
+// The whole staged backward in ONE call (round 5): every stage is enqueued back to back; whenever a gradient range becomes final an event is
+// recorded behind it on `stream` and the range is noted.  A data-parallel caller then makes its communication stream wait for event k
+// (p5_backward_staged_wait) and enqueues the all-reduce of range k -- the exchange still overlaps the rest of the backward on the device,
+// and the host pays one library call per step instead of one per stage plus a range query each (16 + 16 at T5-small).
+int p5_backward_staged(P5Engine* e, const float* dnll, void* stream, int64_t* ranges, int max_ranges, int* n_ranges) {
+  P5_REQUIRE(ranges && n_ranges && max_ranges >= 1, "p5_backward_staged: ranges / n_ranges");
+  const int nst = p5_backward_num_stages(e);
+  int n = 0;
+  for (int st = 0; st < nst; ++st) {
+    P5_TRY(p5_backward_stage(e, dnll, st, stream));
+    if (e->rep_e > e->rep_b) {
+      P5_REQUIRE(n < max_ranges && n < P5_MAX_STAGED, "p5_backward_staged: more final ranges than the caller has room for");
+#ifndef P5_EMU
+      if (!e->st_ev[n]) P5_REQUIRE(hipEventCreateWithFlags(&e->st_ev[n], hipEventDisableTiming) == hipSuccess, "hipEventCreate");
+      P5_REQUIRE(hipEventRecord(e->st_ev[n], (hipStream_t)stream) == hipSuccess, "hipEventRecord");
+#endif
+      ranges[2 * n] = e->rep_b; ranges[2 * n + 1] = e->rep_e;
+      ++n;
+    }
+  }
+  e->st_n = n;
+  *n_ranges = n;
+  return 0;
+}
+int p5_backward_staged_wait(P5Engine* e, int k, void* comm_stream) {
+  P5_REQUIRE(k >= 0 && k < e->st_n, "p5_backward_staged_wait: range index");
+#ifndef P5_EMU
+  P5_REQUIRE(hipStreamWaitEvent((hipStream_t)comm_stream, e->st_ev[k], 0) == hipSuccess, "hipStreamWaitEvent");
+#else
+  (void)comm_stream;
+#endif
+  return 0;
+}
 int p5_backward_stage_pairs(P5Engine* e, int on) { e->stage_pairs = on != 0; return 0; }
 int p5_engine_grads_zeroed(P5Engine* e) { e->grads_keep = true; return 0; }
 // zero_grad(set_to_none=True) of the reference loop: the gradients are dead until the next backward rewrites them -- nothing to do

@@ -131,6 +131,7 @@ class P5T5Native(nn.Module):
     # always runs the plain (fp32) search.
     generation_mode = "verified"
     verify_extra_beams = 6
+    verify_escalation = (22,)     # extra beams of the wider draft a FLAGGED user gets before the plain fp32 search is the last resort
     verify_share_encoder = True   # verified mode: the draft starts from the verification pass's fp32 encoder output (one encoder pass per batch)
     prefix_fast_forward = True    # the steps every item shares ("<dataset> item _") as one teacher-forced pass (p5_generate_set_forced_prefix)
 
@@ -159,13 +160,14 @@ class P5T5Native(nn.Module):
         self.ddp_timing = False          # record device time the main stream spends waiting for the gradient exchange (bench.py)
         self.ddp_wait_ms = []
         self._pending = []
+        self._staged_ranges, self._bucket16 = None, None
         self._side = None
         self._comm = None
         self._fold = None
         self._fold_dirty = self._fold_v_dirty = True
         self._engine_v = None       # fp32 engine over the same master arena (verified generation)
         self._fold_v, self._fold_v_dirty, self._ver_ws, self._gen_ws_v, self._ver_hdr, self._ver_ev = None, True, None, None, None, None
-        self.verify_stats = {"calls": 0, "users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0}
+        self.verify_stats = {"calls": 0, "users": 0, "escalated_users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0}
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
         self._grads_dead = False    # zero_grad(set_to_none=True) was called and no backward has run since: `.grad` holds stale values
         self._tr_dirty = True
@@ -493,29 +495,38 @@ class P5T5Native(nn.Module):
         exchange = self.ddp_world > 1 and self._ddp_sync
         if exchange or self.staged_backward:
             import torch.distributed as dist
+            # ONE library call enqueues every stage and records an event behind each gradient range that became final (the staged backward
+            # issues the same grouped weight-gradient launches as the single-GPU step, so ranges leave in two-layer groups); the exchange
+            # of range k goes to a communication stream that waits for event k -- it overlaps the rest of the backward on the device, and
+            # the host makes one call per step instead of one per stage
             nst = lib.p5_backward_num_stages(eng)
-            b, e = ctypes.c_int64(), ctypes.c_int64()
+            if self._staged_ranges is None or len(self._staged_ranges) < 2 * nst:
+                self._staged_ranges = (ctypes.c_int64 * (2 * nst))()
+            nr = ctypes.c_int(0)
+            self._be.check(lib.p5_backward_staged(eng, _ptr(dnll), sp, self._staged_ranges, nst, ctypes.byref(nr)), "p5_backward_staged")
+            self._staged_n = nr.value
             self._pending = []
             half = str(self.ddp_bucket_dtype).replace("torch.", "") in ("bf16", "bfloat16")
-            for st in range(nst):
-                self._be.check(lib.p5_backward_stage(eng, _ptr(dnll), st, sp), "p5_backward_stage")
-                # the range that became final with this stage (empty while a two-layer weight-gradient group is still filling up: the
-                # staged backward issues the same grouped launches as the single-GPU step)
-                lib.p5_backward_final_range(eng, ctypes.byref(b), ctypes.byref(e))
-                if e.value > b.value and exchange:
-                    # the bucket's all-reduce goes to a communication stream ordered after this stage's work (the engine's side
-                    # stream when it has one -- it also carries the stage's weight gradients -- else a stream of our own that
-                    # waits for the main stream here), so that it overlaps the following stages
-                    comm = self._side
-                    if comm is None and self._flat.is_cuda:
-                        if self._comm is None:
-                            self._comm = torch.cuda.Stream(device=self._be.device)
-                        comm = self._comm
-                        comm.wait_stream(torch.cuda.current_stream())
-                    ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
-                    with ctx:
-                        seg = self._grads[b.value:e.value]
-                        buf = seg.to(torch.bfloat16) if half else seg       # bf16 bucket: cast, reduce, cast back (below)
+            if exchange:
+                comm = self._side
+                if comm is None and self._flat.is_cuda:
+                    if self._comm is None:
+                        self._comm = torch.cuda.Stream(device=self._be.device)
+                    comm = self._comm
+                if half and (self._bucket16 is None or self._bucket16.numel() != self._grads.numel()):
+                    self._bucket16 = torch.empty(self._grads.numel(), dtype=torch.bfloat16, device=self._grads.device)      # allocated once, not per step
+                ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
+                with ctx:
+                    for k in range(nr.value):
+                        b0, e0 = int(self._staged_ranges[2 * k]), int(self._staged_ranges[2 * k + 1])
+                        if comm is not None:
+                            self._be.check(lib.p5_backward_staged_wait(eng, k, ctypes.c_void_p(comm.cuda_stream)), "p5_backward_staged_wait")
+                        seg = self._grads[b0:e0]
+                        if half:                     # bf16 bucket: cast, reduce, cast back (below)
+                            buf = self._bucket16[b0:e0]
+                            buf.copy_(seg)
+                        else:
+                            buf = seg
                         self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True), buf, seg))
             timing = self.ddp_timing and exchange and self._flat.is_cuda
             if timing:
@@ -524,8 +535,6 @@ class P5T5Native(nn.Module):
             for w, buf, seg in self._pending:
                 w.wait()
                 if half:
-                    if buf.is_cuda:
-                        buf.record_stream(torch.cuda.current_stream())      # allocated on the side stream, read here
                     seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
             self._pending = []
             for cs in (self._side, self._comm):
@@ -712,12 +721,13 @@ class P5T5Native(nn.Module):
                                                      self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind (verify)")
         return self._engine_v
 
-    def _generate_verified(self, input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc):
+    def _generate_verified(self, input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc, level=0):
         """include/p5hip.h "verified generation": the bf16 search with `verify_extra_beams` more beams proposes, ONE teacher-forced fp32
         pass over the distinct prefixes it kept alive scores them, and HF's beam search of the real width is replayed on those fp32 numbers.
         Users whose replay needed a prefix the draft had dropped are re-run through the plain fp32 search (counted in `verify_stats`)."""
         lib, dev, sp = self._lib, self._be.device, self._be.stream_ptr()
-        Kw = min(64, K + max(0, int(self.verify_extra_beams)))
+        extra = (int(self.verify_extra_beams),) + tuple(int(x) for x in self.verify_escalation)
+        Kw = min(64, K + max(0, extra[min(level, len(extra) - 1)]))
         ev = self._verify_engine()
         common = (input_ids, whole_word_ids, attention_mask, B, L)
         trie_args = (off, tok, nxt, roots_t, excl_t, excl_words, maxc)
@@ -754,25 +764,31 @@ class P5T5Native(nn.Module):
         missing = torch.zeros(B, dtype=torch.int32, device=dev)
         self._be.check(lib.p5_verify_run(ev, PU, _ptr(excl_t), _ptr(seq), _ptr(score), _ptr(ln), _ptr(missing), sp), "p5_verify_run")
         st = self.verify_stats
-        st["calls"] += 1; st["users"] += B; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
-        st["draft_beams"] = Kw
+        st["calls"] += 1; st["users"] += B if level == 0 else 0; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
+        if level == 0:
+            st["draft_beams"] = Kw
         miss = missing.nonzero().flatten()
         if miss.numel():
-            # the fp32 search itself for these users (rare: a prefix the fp32 search ranks among its K was not among the draft's Kw)
-            st["fallback_users"] += int(miss.numel())
-            if self.fuse_decode_norms:
-                if self._fold_v is None:
-                    n = int(lib.p5_decode_fold_count(ev))
-                    self._fold_v = torch.empty(n, dtype=torch.float32, device=dev)
-                    self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(self._fold_v)), "p5_engine_bind_decode_fold (verify)")
-                    self._fold_v_dirty = True
-                if self._fold_v_dirty:
-                    self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
-                    self._fold_v_dirty = False
             sub = lambda t: None if t is None else t[miss].contiguous()     # noqa: E731
             nb = int(miss.numel())
-            s2, sc2, l2 = self._search(ev, "_gen_ws_v", sub(input_ids), sub(whole_word_ids), sub(attention_mask), nb, L, K, max_length, off, tok, nxt,
-                                       sub(roots_t), sub(excl_t), excl_words, maxc)
+            sub_args = (sub(input_ids), sub(whole_word_ids), sub(attention_mask), nb, L, K, max_length, off, tok, nxt, sub(roots_t), sub(excl_t), excl_words, maxc)
+            if level + 1 < len(extra) and K + extra[level + 1] > Kw:
+                # a flagged user first gets a WIDER draft (cheap: a sub-batch, ~2 ms) -- only what that cannot settle goes to the fp32 search
+                st["escalated_users"] += nb
+                s2, sc2, l2 = self._generate_verified(*sub_args, level=level + 1)
+            else:
+                # the fp32 search itself for these users (a prefix the fp32 search ranks among its K was not among the draft's Kw)
+                st["fallback_users"] += nb
+                if self.fuse_decode_norms:
+                    if self._fold_v is None:
+                        n = int(lib.p5_decode_fold_count(ev))
+                        self._fold_v = torch.empty(n, dtype=torch.float32, device=dev)
+                        self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(self._fold_v)), "p5_engine_bind_decode_fold (verify)")
+                        self._fold_v_dirty = True
+                    if self._fold_v_dirty:
+                        self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
+                        self._fold_v_dirty = False
+                s2, sc2, l2 = self._search(ev, "_gen_ws_v", *sub_args)
             seq[miss] = s2; score[miss] = sc2; ln[miss] = l2
         return seq, score, ln
 

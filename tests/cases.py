@@ -1149,7 +1149,7 @@ def backward_reproducible_case(be, ocfg, B, L, T, runs=4, dropout=0.0, dtype="bf
 
 
 def staged_backward_case(be, ocfg, B, L, T, dtype="bf16", dropout=0.0):
-    """The stage-by-stage backward of the data-parallel path (p5_backward_stage + p5_backward_final_range): the ranges it reports are
+    """The staged backward of the data-parallel path (p5_backward_staged = every p5_backward_stage + p5_backward_final_range in one call): the ranges it reports are
     contiguous, walk the arena from the back and tile it exactly; every gradient equals the whole backward's bit for bit -- with and
     without two-layer weight-gradient groups (p5_backward_stage_pairs)."""
     import ctypes
@@ -1165,29 +1165,16 @@ def staged_backward_case(be, ocfg, B, L, T, dtype="bf16", dropout=0.0):
             m.eval()
         m.staged_backward = staged
         be.check(be.lib.p5_backward_stage_pairs(m._engine, 1 if pairs else 0), "pairs")
-        ranges = []
-        if staged:
-            orig = be.lib.p5_backward_final_range
-
-            class Spy:          # record what the model's backward loop is told
-                def __call__(self, eng, b, e):
-                    rc = orig(eng, b, e)
-                    ranges.append((b._obj.value, e._obj.value))
-                    return rc
-            spy = Spy()
-            lib = m._lib
-
-            class LibProxy:
-                def __getattr__(self, k):
-                    return spy if k == "p5_backward_final_range" else getattr(lib, k)
-            m._lib = LibProxy()
         loss = m.loss_and_backward(*a)
         sync(be)
-        return float(loss), m._grads.detach().cpu().clone(), ranges, int(m._n)
+        # what the one-call staged backward (p5_backward_staged) reported: the gradient ranges in the order they became final
+        ranges = [(int(m._staged_ranges[2 * k]), int(m._staged_ranges[2 * k + 1])) for k in range(m._staged_n)] if staged else []
+        nst = int(be.lib.p5_backward_num_stages(m._engine))
+        return float(loss), m._grads.detach().cpu().clone(), ranges, int(m._n), nst
 
-    l0, g0, _, n = run(False, True)
+    l0, g0, _, n, _ = run(False, True)
     for pairs in (True, False):
-        l1, g1, ranges, _ = run(True, pairs)
+        l1, g1, ranges, _, nst = run(True, pairs)
         assert l1 == l0
         assert torch.equal(g1, g0), (pairs, float((g1 - g0).abs().max()))
         got = [r for r in ranges if r[1] > r[0]]
@@ -1195,7 +1182,7 @@ def staged_backward_case(be, ocfg, B, L, T, dtype="bf16", dropout=0.0):
         for (b0, e0), (b1, e1) in zip(got, got[1:]):
             assert e1 == b0, ("ranges must tile the arena from the back", got)
         if pairs and ocfg.num_layers >= 2 and B * L % 64 == 0 and B * T % 64 == 0 and dtype == "bf16":
-            assert len(got) < len(ranges), "two-layer groups: some stages must report nothing"
+            assert len(got) < nst, "two-layer groups: some stages must report nothing"
 
 
 def grad_store_first_case(be, ocfg, B, L, T, exact=True):
@@ -1473,7 +1460,8 @@ def dropped_gap_first(x, x_lp, ranked, ranked_lp):
     return float("inf")
 
 
-def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, loss_drop=0.7, bf16_set_diff_max=BF16_SET_DIFF_MAX, **pipeline):
+def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, loss_drop=0.7, bf16_set_diff_max=BF16_SET_DIFF_MAX, drop_rule="first",
+                 **pipeline):
     """The dataset-level evaluation gate of tests/test_gpu_dataset.py: a model trained through the real pipeline (bf16 engine), then every
     test user of both tasks ranked FOUR ways with the same weights -- fp32 CPU oracle (HF beam search restated + Python trie callbacks), the
     bf16 model in its default "verified" mode (bf16 search with extra beams proposes, one fp32 pass decides: csrc/p5_verify.h), the fp32
@@ -1528,7 +1516,7 @@ def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, 
         assert tf["users"] == c["users"] and tf["score_viol"] == 0 and tf["order_viol"] == 0 and max(tf["dropped"]) <= FP32_TIE_TOL, (name, tf["max_score_err"])
     # (the verification pass may hand a user to the fp32 search when the draft dropped a prefix the fp32 search needs: correct either way,
     #  but it is the slow path -- it must stay the exception)
-    assert vstats["fallback_users"] <= max_fallback_frac * max(1, vstats["users"]), vstats
+    assert vstats["fallback_users"] + vstats["escalated_users"] <= max_fallback_frac * max(1, vstats["users"]), vstats
     # ---- the plain bf16 search: (a) every returned score within BF16_SCORE_TOL of the oracle's score of that sequence, (b) the returned
     # order is the oracle's order of those sequences up to TIE_TOL, (c) the top-K set differs from the oracle's for at most 5 % of the
     # users, and (d) every item the oracle lists and the bf16 search does not was one it was entitled to drop AT THE FIRST STEP its prefix
@@ -1548,7 +1536,10 @@ def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, 
         gaps = [dropped_gap_first(ro[j], o_lp[j], list(ra), r_lp) for j in range(len(ro)) if ro[j] not in ra]
         g = max(gaps + [0.0])
         first_gaps.append(g)
-        if g > TIE_TOL:
+        # drop_rule "first": the item must have been droppable at the FIRST step its prefix is no prefix of a returned item -- exact when the
+        # search decides once (dataset 1).  With several pruning steps the search may have carried the prefix further and dropped it later
+        # (its siblings lost, not the prefix): "any" = droppable at SOME step from the first on (dropped_gap), the first-step figure is printed
+        if (g if drop_rule == "first" else tf16["dropped"][i]) > TIE_TOL:
             unexplained.append((i, round(g, 4), round(tf16["dropped"][i], 4)))
     print(f"[dataset] plain bf16: teacher-forced", {k: v for k, v in tf16.items() if not isinstance(v, list)})
     print(f"[dataset] plain bf16: top-{K} set differs for {set_diff} of {n_users} users; largest first-step dropped gap {max(first_gaps + [0.0]):.4f} per token "
