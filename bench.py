@@ -298,6 +298,15 @@ def in_step_us(kernel_key):
         return None
 
 
+def decode_step_traffic():
+    """bytes per decode step from profiles/pmc_decode_step.json (written on the GPU box by tools/r5_final_run.sh), or None"""
+    path = os.path.join(ROOT, "profiles", "pmc_decode_step.json")
+    try:
+        return float(json.load(open(path))["traffic_bytes_per_step"])
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, shape):
     """HBM bytes per launch of `kernel` at `shape` from profiles/pmc_traffic.json (profiles/collect_pmc.sh: separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- None when not collected."""
@@ -689,7 +698,9 @@ def main():
             gbs = byts / (step_ms * 1e-3) / 1e9
             line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step), plain bf16 search", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": byts, "ms_per_step": step_ms,
-                                           "steps": S, "forced_prefix_steps": int(timing.get("forced_prefix_steps", 0)), "traffic": None,
+                                           "steps": S, "forced_prefix_steps": int(timing.get("forced_prefix_steps", 0)), "traffic": decode_step_traffic(),
+                                           "traffic_source": "profiles/pmc_decode_step.json (tools/r5_final_run.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of the "
+                                                             "decode steps of tools/gen_bench.py, separate --pmc passes, per step; fabric-side counters: L2-miss traffic)",
                                            "time_source": "device time of the decode loop (engine HIP events) / decode steps" if timed else "whole generate() / steps",
                                            "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d)); the steps every item id shares "
                                                    "run as ONE teacher-forced pass before the loop (p5_decode.h) and are not decode steps"}
