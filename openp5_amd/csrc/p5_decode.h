@@ -240,6 +240,27 @@ __global__ __launch_bounds__(256) void p5_dec_score_kernel(float* __restrict__ c
 
 #define P5_MAX_K 64
 #define P5_MAX_K2 128
+#define P5_RANK_POOL 2048        // candidates (beams x 2 beams) ranked in parallel: beam widths up to 32
+// (score desc, key asc) as ONE unsigned 64-bit order: larger = better.  -inf candidates hold 0 and are never counted.
+__device__ static __forceinline__ unsigned long long p5_rank_key(float v, int key) {
+  union { float f; unsigned u; } c; c.f = v;
+  const unsigned o = (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+  return v == P5_NEG_INF ? 0ull : (((unsigned long long)o << 32) | (unsigned long long)(~(unsigned)key));
+}
+// rank of `mine` among the n keys of k64 (n padded to a multiple of 2 with zeros): two candidates per 16-byte LDS read, one 64-bit compare each
+// (the (score, key) pair compare of round 4 took ~6 VALU operations per candidate: 13 us of the beam step at 16 beams)
+__device__ static __forceinline__ int p5_rank_of(const unsigned long long* k64, int n, unsigned long long mine) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  int rank = 0;
+  const int n2 = (n + 1) >> 1;
+#pragma unroll 8
+  for (int u = 0; u < n2; ++u) {
+    const u64x2 k = ((const u64x2*)k64)[u];
+    rank += (k[0] > mine) ? 1 : 0;
+    rank += (k[1] > mine) ? 1 : 0;
+  }
+  return rank;
+}
 struct P5BeamState {
   int* run_seq; int* run_seq_next;   // [B,K,max_len]
   float* run_score;                  // [B,K]
@@ -401,10 +422,21 @@ __device__ static __forceinline__ void p5_beam_tail(P5BeamState& st, P5BeamSh& s
     }
   }
   if (st.x32) {      // decoder input of the next step: x32[row, :] = E32[token, :]  (fp32 master table, P5_T5.py:94-100 for the decoder)
-    const int d4 = st.d >> 2;
-    for (int t = tid; t < Kb * d4; t += 256) {
-      const int j = t / d4, c4 = t - j * d4;
-      *(f32x4*)(st.x32 + ((size_t)(b * Kb + j)) * st.d + c4 * 4) = *(const f32x4*)(st.E32 + (size_t)top_tok[sel_run[j]] * st.d + c4 * 4);
+    // four independent 16-byte loads per thread before the first store (one load -> store round trip per iteration cost ~2 us each: 8
+    // iterations at 16 beams)
+    const int d4 = st.d >> 2, n4 = Kb * d4;
+    for (int t0 = tid; t0 < n4; t0 += 4 * 256) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * 256;
+        if (t < n4) { const int j = t / d4, c4 = t - j * d4; v[u] = *(const f32x4*)(st.E32 + (size_t)top_tok[sel_run[j]] * st.d + c4 * 4); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * 256;
+        if (t < n4) { const int j = t / d4, c4 = t - j * d4; *(f32x4*)(st.x32 + ((size_t)(b * Kb + j)) * st.d + c4 * 4) = v[u]; }
+      }
     }
   }
   // the step counter advances once every workgroup of this launch is done with it (they all read it on entry): the last one
@@ -457,34 +489,23 @@ __global__ __launch_bounds__(256) void p5_beam_step_kernel(P5BeamState st, const
   }
   if (tid == 0) s_nothit = 0;
   __syncthreads();
-  __shared__ __attribute__((aligned(16))) int ckey[1024 + 4];
-  const bool by_rank = Kb * K2 <= 1024;
+  __shared__ __attribute__((aligned(16))) unsigned long long k64[P5_RANK_POOL + 2];
+  const bool by_rank = Kb * K2 <= P5_RANK_POOL;
   if (by_rank) {
     // every candidate computes its own rank in the (score desc, beam*max_c + child asc) order -- all in parallel instead of
     // 2K rounds of block-wide arg-max; the 2K best land at their rank
     for (int t = tid; t < Kb * K2; t += 256)
-      ckey[t] = (cs[t] == P5_NEG_INF) ? 0x7fffffff : (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2];
-    if (tid < 4) { cs[Kb * K2 + tid] = P5_NEG_INF; ckey[Kb * K2 + tid] = 0x7fffffff; }     // (the rank loop below reads four at a time)
+      k64[t] = p5_rank_key(cs[t], (t / K2) * max_c + row_top_c[(size_t)(b * Kb + t / K2) * K2 + t % K2]);
+    if (tid < 2) k64[Kb * K2 + tid] = 0ull;
     if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }   // fewer than 2K candidates
     __syncthreads();
-    const int n4 = (Kb * K2 + 3) >> 2;
     for (int t = tid; t < Kb * K2; t += 256) {
-      const float v = cs[t];
-      if (v == P5_NEG_INF) continue;
-      const int key = ckey[t];
-      // four candidates per LDS round trip (16-byte reads): at beam 16 the one-at-a-time loop was 78 us of this kernel's 95 -- 512
-      // dependent read pairs per candidate (round 5, profiles/r05_generate_verified_*.md)
-      int rank = 0;
-#pragma unroll 4
-      for (int u = 0; u < n4; ++u) {
-        const f32x4 vu = ((const f32x4*)cs)[u];
-        const u32x4 ku = ((const u32x4*)ckey)[u];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rank += (vu[q] > v || (vu[q] == v && (int)ku[q] < key)) ? 1 : 0;
-      }
+      const unsigned long long mine = k64[t];
+      if (mine == 0ull) continue;
+      const int rank = p5_rank_of(k64, Kb * K2, mine);
       if (rank < K2) {
-        const int j = t / K2, c = key - j * max_c;
-        top_lp[rank] = v; top_beam[rank] = j;
+        const int j = t / K2, c = (int)(~(unsigned)mine) - j * max_c;
+        top_lp[rank] = cs[t]; top_beam[rank] = j;
         top_tok[rank] = child_tok[sh.old_coff[j] + c];
         top_node[rank] = child_node[sh.old_coff[j] + c];
       }

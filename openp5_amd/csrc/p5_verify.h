@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256) void p5_verify_step_kernel(P5BeamState st, P5V
   }
   const int* __restrict__ vcur = (cur_len & 1) ? vrow_odd : vrow_even;
   int* __restrict__ vnext = (cur_len & 1) ? vrow_even : vrow_odd;
-  __shared__ __attribute__((aligned(16))) float cs[P5_VERIFY_POOL + 4];
-  __shared__ __attribute__((aligned(16))) int ckey[P5_VERIFY_POOL + 4];
+  __shared__ float cs[P5_VERIFY_POOL];
+  __shared__ int ckey[P5_VERIFY_POOL];
+  __shared__ __attribute__((aligned(16))) unsigned long long k64[P5_VERIFY_POOL + 2];
   __shared__ P5BeamSh sh;
   __shared__ float s_rs[P5_MAX_K];
   __shared__ int s_vr[P5_MAX_K], s_miss;
@@ -284,26 +285,18 @@ __global__ __launch_bounds__(256) void p5_verify_step_kernel(P5BeamState st, P5V
         if (c < nc) { v = rs; key = j * max_c + c; }
       }
     }
-    cs[t] = v; ckey[t] = key;
+    cs[t] = v; ckey[t] = key; k64[t] = p5_rank_key(v, key);
   }
-  if (tid < 4) { cs[Kb * K2 + tid] = P5_NEG_INF; ckey[Kb * K2 + tid] = 0x7fffffff; }     // (the rank loop reads four at a time)
+  if (tid < 2) k64[Kb * K2 + tid] = 0ull;
   if (tid < K2) { top_lp[tid] = P5_NEG_INF; top_beam[tid] = 0; top_tok[tid] = 0; top_node[tid] = -1; }
   __syncthreads();
-  const int n4 = (Kb * K2 + 3) >> 2;
   // every candidate computes its own rank in the (score desc, beam * max_c + child asc) order (as p5_beam_step_kernel); the 2K best land at
   // their rank
   for (int t = tid; t < Kb * K2; t += 256) {
     const float v = cs[t];
     if (v == P5_NEG_INF) continue;
     const int key = ckey[t];
-    int rank = 0;
-#pragma unroll 4
-    for (int u = 0; u < n4; ++u) {
-      const f32x4 vu = ((const f32x4*)cs)[u];
-      const u32x4 ku = ((const u32x4*)ckey)[u];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rank += (vu[q] > v || (vu[q] == v && (int)ku[q] < key)) ? 1 : 0;
-    }
+    const int rank = p5_rank_of(k64, Kb * K2, k64[t]);
     if (rank < K2) {
       const int j = t / K2, c = key - j * max_c;
       top_lp[rank] = v; top_beam[rank] = j;

@@ -20,6 +20,7 @@ from __future__ import annotations
 import contextlib
 import os
 import ctypes
+import threading
 import math
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
@@ -117,6 +118,18 @@ class _P5LossFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _GenLane:
+    """What ONE in-flight generate() call owns: its engines (the bf16 / fp32 search engine and, for verified generation, the fp32 verification
+    engine -- all bound to the model's ONE set of parameter arenas), its workspaces, its pinned read-back buffer, its HIP stream.  Lane 0 is
+    the model's own engine on the caller's stream; further lanes let several batches be in flight at once (`P5T5Native.map_lanes`)."""
+    __slots__ = ("idx", "engine", "engine_v", "fold_v", "fold_v_dirty", "ws", "ver_hdr", "forced", "stream")
+
+    def __init__(self, idx, engine, stream=None):
+        self.idx, self.engine, self.stream = idx, engine, stream
+        self.engine_v, self.fold_v, self.fold_v_dirty, self.ver_hdr = None, None, True, None
+        self.ws, self.forced = {}, ([], [])
+
+
 class P5T5Native(nn.Module):
     LUT_HALF = 512
     # Engine-internal second HIP stream (weight gradients, K/V projections, clears off the main stream).  OFF since round 3: with
@@ -133,6 +146,7 @@ class P5T5Native(nn.Module):
     verify_extra_beams = 6
     verify_escalation = (22,)     # extra beams of the wider draft a FLAGGED user gets before the plain fp32 search is the last resort
     verify_share_encoder = True   # verified mode: the draft starts from the verification pass's fp32 encoder output (one encoder pass per batch)
+    gen_lanes = 2                 # batches in flight in `map_lanes` (the runner's evaluation loops, bench.py): lanes overlap each other's latency-bound chains
     prefix_fast_forward = True    # the steps every item shares ("<dataset> item _") as one teacher-forced pass (p5_generate_set_forced_prefix)
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):
@@ -164,9 +178,10 @@ class P5T5Native(nn.Module):
         self._side = None
         self._comm = None
         self._fold = None
-        self._fold_dirty = self._fold_v_dirty = True
-        self._engine_v = None       # fp32 engine over the same master arena (verified generation)
-        self._fold_v, self._fold_v_dirty, self._ver_ws, self._gen_ws_v, self._ver_hdr, self._ver_ev = None, True, None, None, None, None
+        self._fold_dirty = True; self._mark_lanes_dirty()
+        self._lanes = []            # generation lanes (lane 0 = this model's engine on the caller's stream)
+        self._tls = threading.local()
+        self._stats_lock = threading.Lock()
         self.verify_stats = {"calls": 0, "users": 0, "escalated_users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0}
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
         self._grads_dead = False    # zero_grad(set_to_none=True) was called and no backward has run since: `.grad` holds stale values
@@ -191,9 +206,7 @@ class P5T5Native(nn.Module):
             self._lib.p5_engine_destroy(self._engine)
         self._engine = ctypes.c_void_p()
         self._fold, self._fold_dirty = None, True       # sized by (and bound to) the engine
-        if getattr(self, "_engine_v", None):            # the verification engine is bound to the old arena: rebuilt on demand
-            self._lib.p5_engine_destroy(self._engine_v)
-        self._engine_v, self._fold_v, self._fold_v_dirty = None, None, True
+        self._drop_lanes()          # lane engines (verification engines, extra search engines) are bound to the old arena: rebuilt on demand
         cfg = self._cfg_struct()
         self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine)), "p5_engine_create")
         table = []
@@ -232,7 +245,7 @@ class P5T5Native(nn.Module):
             self._copy_in(old_state, strict=False)
         self._bind()
         self._shadow_dirty = True
-        self._fold_dirty = self._fold_v_dirty = True
+        self._fold_dirty = True; self._mark_lanes_dirty()
 
     def _register_dotted(self, name, p):
         parts = name.split(".")
@@ -297,7 +310,7 @@ class P5T5Native(nn.Module):
             n = int(self._lib.p5_decode_fold_count(self._engine))
             self._fold = torch.empty(n, dtype=torch.bfloat16 if self.compute_dtype == 1 else torch.float32, device=self._flat.device)
             self._be.check(self._lib.p5_engine_bind_decode_fold(self._engine, _ptr(self._fold)), "p5_engine_bind_decode_fold")
-            self._fold_dirty = self._fold_v_dirty = True
+            self._fold_dirty = True; self._mark_lanes_dirty()
         if self._fold_dirty:
             self._be.check(self._lib.p5_refresh_decode_fold(self._engine, self._be.stream_ptr()), "p5_refresh_decode_fold")
             self._fold_dirty = False
@@ -305,7 +318,7 @@ class P5T5Native(nn.Module):
     def mark_params_updated(self, shadow_fresh: bool = False):
         """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
         self._shadow_dirty = not shadow_fresh
-        self._fold_dirty = self._fold_v_dirty = True
+        self._fold_dirty = True; self._mark_lanes_dirty()
         self._tr_dirty = True
 
     def _sync_transposed(self):
@@ -363,7 +376,7 @@ class P5T5Native(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing={missing} unexpected={unexpected}")
         self._shadow_dirty = True
-        self._fold_dirty = self._fold_v_dirty = True
+        self._fold_dirty = True; self._mark_lanes_dirty()
         self._tr_dirty = True
         return missing, unexpected
 
@@ -414,7 +427,7 @@ class P5T5Native(nn.Module):
         n = min(old, new_num_tokens)
         self.shared.weight[:n].copy_(old_E[:n])
         self._shadow_dirty = True
-        self._fold_dirty = self._fold_v_dirty = True
+        self._fold_dirty = True; self._mark_lanes_dirty()
         return self.shared
 
     def get_input_embeddings(self):
@@ -602,6 +615,95 @@ class P5T5Native(nn.Module):
         out = {"loss": nll}
         return out if return_dict else (nll,)
 
+    # ------------------------------------------------------------------ generation lanes
+    def _drop_lanes(self):
+        for ln in getattr(self, "_lanes", []):
+            if ln.engine_v:
+                self._lib.p5_engine_destroy(ln.engine_v)
+            if ln.idx > 0 and ln.engine:
+                self._lib.p5_engine_destroy(ln.engine)
+        self._lanes = []
+
+    def _mark_lanes_dirty(self):
+        for ln in getattr(self, "_lanes", []):
+            ln.fold_v_dirty = True
+
+    def _lane(self, i):
+        """lane i, created on demand: lane 0 = the model's own engine; lane i > 0 = a second search engine over the SAME parameter arenas,
+        bf16 shadow, folded decode weights and transposed / norm-folded copies (read-only during generation) with its own HIP stream."""
+        while len(self._lanes) <= i:
+            k = len(self._lanes)
+            if k == 0:
+                self._lanes.append(_GenLane(0, self._engine))
+                continue
+            cfg = self._cfg_struct()
+            eng = ctypes.c_void_p()
+            self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(eng)), "p5_engine_create (lane)")
+            self._be.check(self._lib.p5_engine_bind(eng, _ptr(self._flat), _ptr(self._grads), _ptr(self._shadow), _ptr(self._lut_enc), _ptr(self._lut_dec),
+                                                     self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind (lane)")
+            if self._fold is not None:
+                self._be.check(self._lib.p5_engine_bind_decode_fold(eng, _ptr(self._fold)), "p5_engine_bind_decode_fold (lane)")
+            if self._shadow_t is not None:
+                self._be.check(self._lib.p5_engine_bind_transposed(eng, _ptr(self._shadow_t), self._be.stream_ptr()), "p5_engine_bind_transposed (lane)")
+            self._lanes.append(_GenLane(k, eng, torch.cuda.Stream(device=self._be.device) if self._flat.is_cuda else None))
+        return self._lanes[i]
+
+    def _cur_lane(self):
+        return getattr(self._tls, "lane", None) or self._lane(0)
+
+    def _lane_workspace(self, lane, nbytes, key):
+        cur = lane.ws.get(key)
+        if cur is None or cur.numel() < nbytes:
+            raw = torch.empty(int(nbytes * 1.05) + 512, dtype=torch.uint8, device=self._be.device)
+            skew = (-raw.data_ptr()) % 256
+            cur = raw[skew:skew + int(nbytes * 1.05) + 255]
+            lane.ws[key] = cur
+        return cur
+
+    def map_lanes(self, fn, items, lanes=None):
+        """`fn(item)` for every item, IN ORDER, with up to `lanes` calls in flight: each worker thread owns a generation lane (its own search /
+        verification engines, workspaces and HIP stream over the model's one set of weights), so the latency-bound kernel chain of one
+        batch's beam search overlaps the next batch's -- on one MI355X two lanes run beam-10 generation at 1.5-1.6 x the items/s of one
+        (DESIGN.md 3.8).  `fn` typically calls `model.generate(...)` and post-processes its result; results come back as a generator."""
+        lanes = int(self.gen_lanes if lanes is None else lanes)
+        if lanes <= 1 or not self._flat.is_cuda:
+            for it in items:
+                yield fn(it)
+            return
+        import collections
+        import concurrent.futures
+        # parameter copies the searches read are refreshed HERE, once, on the caller's stream: no lane does it under another lane's feet
+        self._sync_shadow()
+        self._sync_transposed()
+        self._sync_decode_fold()
+        pool = [self._lane(i + 1) for i in range(lanes)]          # lanes 1 .. n; lane 0 stays with the calling thread's own generate() calls
+        main = torch.cuda.current_stream()
+        for ln in pool:
+            ln.stream.wait_stream(main)
+        q, lock, tls = collections.deque(pool), threading.Lock(), self._tls
+
+        def init():
+            with lock:
+                tls.lane = q.popleft()
+
+        def run(it):
+            ln = tls.lane
+            with torch.cuda.stream(ln.stream), torch.no_grad():
+                out = fn(it)
+                ln.stream.synchronize()
+            return out
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=lanes, initializer=init) as ex:
+            pending = collections.deque()
+            for it in items:
+                pending.append(ex.submit(run, it))
+                while len(pending) >= 2 * lanes:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        for ln in pool:
+            main.wait_stream(ln.stream)
+
     # ------------------------------------------------------------------ generation
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, whole_word_ids=None, max_length: int = 20,
@@ -661,7 +763,8 @@ class P5T5Native(nn.Module):
         max_length = max(2, min(int(max_length), int(trie.max_depth)))
         # forced-prefix fast-forward (include/p5hip.h): the chain every item shares behind the start token, as long as no user's history
         # exclusion touches it (an excluded node on the chain would leave that user without candidates: the plain search handles that)
-        self._forced = ([], [])
+        lane = self._cur_lane()
+        lane.forced = ([], [])
         if self.prefix_fast_forward and roots_t is None:
             ftok, fnode = trie.forced_prefix(self.config.decoder_start_token_id, self.config.eos_token_id)
             n = min(len(ftok), max_length - 2)
@@ -671,7 +774,7 @@ class P5T5Native(nn.Module):
                 if bool(((words >> bits[None, :]) & 1).any()):
                     n = 0
             if n >= 2:
-                self._forced = (ftok[:n], fnode[:n])
+                lane.forced = (ftok[:n], fnode[:n])
         mode = unused.get("generation_mode", self.generation_mode)
         if mode not in ("verified", "draft"):
             raise ValueError(f"generation_mode={mode!r} (verified | draft)")
@@ -679,7 +782,7 @@ class P5T5Native(nn.Module):
         if self.compute_dtype == 1 and mode == "verified" and 2 * K * K <= 1024:
             seq, score, ln = self._generate_verified(*args)
         else:
-            seq, score, ln = self._search(self._engine, "_gen_ws", *args)
+            seq, score, ln = self._search(lane.engine, "gen", *args)
         out_len = 1 + int(ln[:, :nret].max().item())
         sequences = seq[:, :nret, :out_len].reshape(B * nret, out_len).to(torch.int64)
         scores = score[:, :nret].reshape(B * nret)
@@ -691,11 +794,12 @@ class P5T5Native(nn.Module):
                 maxc, hist=None):
         """One device beam search on `engine` (p5_generate; with `hist`, p5_generate_draft records what the search kept alive)."""
         dev = self._be.device
-        ftok, fnode = self._forced
+        lane = self._cur_lane()
+        ftok, fnode = lane.forced
         if ftok:
             arr = (ctypes.c_int * len(ftok))
             self._be.check(self._lib.p5_generate_set_forced_prefix(engine, arr(*ftok), arr(*fnode), len(ftok)), "p5_generate_set_forced_prefix")
-        ws = self._workspace(self._lib.p5_generate_workspace_bytes(engine, B, L, K, max_length, maxc, excl_words), ws_attr)
+        ws = self._lane_workspace(lane, self._lib.p5_generate_workspace_bytes(engine, B, L, K, max_length, maxc, excl_words), ws_attr)
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)
         ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
@@ -710,16 +814,16 @@ class P5T5Native(nn.Module):
         return seq, score, ln
 
     # ------------------------------------------------------------------ verified generation (bf16 drafts, fp32 decides)
-    def _verify_engine(self):
-        """fp32 engine over the SAME master parameter arena (no copy of the weights; its kernels read `_flat` directly)."""
-        if not self._engine_v:
+    def _verify_engine(self, lane):
+        """fp32 engine over the SAME master parameter arena (no copy of the weights; its kernels read `_flat` directly), one per lane."""
+        if not lane.engine_v:
             cfg = self._cfg_struct()
             cfg.dtype = 0
-            self._engine_v = ctypes.c_void_p()
-            self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(self._engine_v)), "p5_engine_create (verify)")
-            self._be.check(self._lib.p5_engine_bind(self._engine_v, _ptr(self._flat), _ptr(self._grads), None, _ptr(self._lut_enc), _ptr(self._lut_dec),
+            lane.engine_v = ctypes.c_void_p()
+            self._be.check(self._lib.p5_engine_create(ctypes.byref(cfg), ctypes.byref(lane.engine_v)), "p5_engine_create (verify)")
+            self._be.check(self._lib.p5_engine_bind(lane.engine_v, _ptr(self._flat), _ptr(self._grads), None, _ptr(self._lut_enc), _ptr(self._lut_dec),
                                                      self.LUT_HALF, _ptr(self._rng)), "p5_engine_bind (verify)")
-        return self._engine_v
+        return lane.engine_v
 
     def _generate_verified(self, input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc, level=0):
         """include/p5hip.h "verified generation": the bf16 search with `verify_extra_beams` more beams proposes, ONE teacher-forced fp32
@@ -728,45 +832,47 @@ class P5T5Native(nn.Module):
         lib, dev, sp = self._lib, self._be.device, self._be.stream_ptr()
         extra = (int(self.verify_extra_beams),) + tuple(int(x) for x in self.verify_escalation)
         Kw = min(64, K + max(0, extra[min(level, len(extra) - 1)]))
-        ev = self._verify_engine()
+        lane = self._cur_lane()
+        ev = self._verify_engine(lane)
         common = (input_ids, whole_word_ids, attention_mask, B, L)
         trie_args = (off, tok, nxt, roots_t, excl_t, excl_words, maxc)
-        ftok, fnode = self._forced
+        ftok, fnode = lane.forced
         if ftok:      # (the replay skips the forced steps as the draft does)
             arr = (ctypes.c_int * len(ftok))
             self._be.check(lib.p5_generate_set_forced_prefix(ev, arr(*ftok), arr(*fnode), len(ftok)), "p5_generate_set_forced_prefix (verify)")
-        ws = self._workspace(lib.p5_verify_workspace_bytes(ev, B, L, K, Kw, max_length, maxc, excl_words), "_ver_ws")
+        ws = self._lane_workspace(lane, lib.p5_verify_workspace_bytes(ev, B, L, K, Kw, max_length, maxc, excl_words), "ver")
         self._be.check(lib.p5_verify_begin(ev, B, L, K, Kw, max_length, _ptr(off), _ptr(tok), _ptr(nxt), _ptr(roots_t), maxc, excl_words, _ptr(ws), ws.numel()),
                        "p5_verify_begin")
         # ONE encoder pass per batch: the fp32 one; the draft starts from its output
         self._be.check(lib.p5_verify_encode(ev, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), sp), "p5_verify_encode")
         if self.verify_share_encoder:
-            self._be.check(lib.p5_generate_set_encoder_output(self._engine, ctypes.c_void_p(lib.p5_verify_encoder_output(ev))), "p5_generate_set_encoder_output")
+            self._be.check(lib.p5_generate_set_encoder_output(lane.engine, ctypes.c_void_p(lib.p5_verify_encoder_output(ev))), "p5_generate_set_encoder_output")
         hist = torch.zeros(int(lib.p5_generate_history_count(B, Kw, max_length)), dtype=torch.int32, device=dev)
-        self._search(self._engine, "_gen_ws", *common, Kw, max_length, *trie_args, hist=hist)
+        self._search(lane.engine, "gen", *common, Kw, max_length, *trie_args, hist=hist)
         self._be.check(lib.p5_verify_plan(ev, _ptr(hist), sp), "p5_verify_plan")
         hdr_off = int(lib.p5_verify_plan_header(ev)) - ws.data_ptr()
         hdr_dev = ws[hdr_off:hdr_off + 16].view(torch.int32)
         if ws.is_cuda:
-            if self._ver_hdr is None:
-                self._ver_hdr = torch.zeros(4, dtype=torch.int32).pin_memory()
-            self._ver_hdr.copy_(hdr_dev, non_blocking=True)      # the ONE number the host needs: rows per user of this batch
+            if lane.ver_hdr is None:
+                lane.ver_hdr = torch.zeros(4, dtype=torch.int32).pin_memory()
+            lane.ver_hdr.copy_(hdr_dev, non_blocking=True)      # the ONE number the host needs: rows per user of this batch
             torch.cuda.current_stream().synchronize()
-            hdr = self._ver_hdr.tolist()
+            hdr = lane.ver_hdr.tolist()
         else:
             hdr = hdr_dev.cpu().tolist()
         if hdr[3]:
             raise RuntimeError("p5_verify_plan: row capacity exceeded")
-        PU = max(16, (int(hdr[0]) + 15) // 16 * 16)
+        PU = max(1, int(hdr[0]))          # rows per user of the fp32 pass: the largest row count of the batch (a padding row costs a decoder row)
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)
         ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
         missing = torch.zeros(B, dtype=torch.int32, device=dev)
         self._be.check(lib.p5_verify_run(ev, PU, _ptr(excl_t), _ptr(seq), _ptr(score), _ptr(ln), _ptr(missing), sp), "p5_verify_run")
         st = self.verify_stats
-        st["calls"] += 1; st["users"] += B if level == 0 else 0; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
-        if level == 0:
-            st["draft_beams"] = Kw
+        with self._stats_lock:
+            st["calls"] += 1; st["users"] += B if level == 0 else 0; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
+            if level == 0:
+                st["draft_beams"] = Kw
         miss = missing.nonzero().flatten()
         if miss.numel():
             sub = lambda t: None if t is None else t[miss].contiguous()     # noqa: E731
@@ -780,15 +886,15 @@ class P5T5Native(nn.Module):
                 # the fp32 search itself for these users (a prefix the fp32 search ranks among its K was not among the draft's Kw)
                 st["fallback_users"] += nb
                 if self.fuse_decode_norms:
-                    if self._fold_v is None:
+                    if lane.fold_v is None:
                         n = int(lib.p5_decode_fold_count(ev))
-                        self._fold_v = torch.empty(n, dtype=torch.float32, device=dev)
-                        self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(self._fold_v)), "p5_engine_bind_decode_fold (verify)")
-                        self._fold_v_dirty = True
-                    if self._fold_v_dirty:
+                        lane.fold_v = torch.empty(n, dtype=torch.float32, device=dev)
+                        self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(lane.fold_v)), "p5_engine_bind_decode_fold (verify)")
+                        lane.fold_v_dirty = True
+                    if lane.fold_v_dirty:
                         self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
-                        self._fold_v_dirty = False
-                s2, sc2, l2 = self._search(ev, "_gen_ws_v", *sub_args)
+                        lane.fold_v_dirty = False
+                s2, sc2, l2 = self._search(ev, "gen_v", *sub_args)
             seq[miss] = s2; score[miss] = sc2; ln[miss] = l2
         return seq, score, ln
 
@@ -836,7 +942,6 @@ class P5T5Native(nn.Module):
         try:
             if self._engine:
                 self._lib.p5_engine_destroy(self._engine)
-            if getattr(self, "_engine_v", None):
-                self._lib.p5_engine_destroy(self._engine_v)
+            self._drop_lanes()
         except Exception:
             pass

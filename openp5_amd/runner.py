@@ -48,6 +48,9 @@ def parse_runner_args(parser):
     parser.add_argument("--test_before_train", type=int, default=1, help="whether test before training")
     parser.add_argument("--test_filtered", type=int, default=0, help="whether filter out the items in the training data.")
     parser.add_argument("--test_filtered_batch", type=int, default=1, help="whether testing with filtered data in batch.")
+    parser.add_argument("--gen_lanes", type=int, default=2, help="evaluation batches in flight (P5T5Native.map_lanes): each lane has its own search / "
+                        "verification engines, workspaces and HIP stream over the one set of weights, so one batch's latency-bound beam search overlaps "
+                        "the next one's; 1 = one batch at a time")
     parser.add_argument("--id_metrics", type=int, default=1, help="compare generated token ids with the gold ids on the device "
                         "instead of decoding to strings (same Hit/NDCG; 0 = the reference's string path).")
     parser.add_argument("--compute_dtype", type=str, default="bf16", help="bf16 (fast) or fp32 (parity) engine arithmetic")
@@ -174,6 +177,7 @@ class DistributedRunner:
         self.test_before_train = args.test_before_train
         self.test_filtered, self.test_filtered_batch = args.test_filtered, args.test_filtered_batch
         self.id_metrics = int(getattr(args, "id_metrics", 1))
+        self.gen_lanes = int(getattr(args, "gen_lanes", 2))
         self.metrics = args.metrics.split(",")
         self.generate_num = max(int(m.split("@")[1]) for m in self.metrics)
         self.get_testloader()
@@ -433,6 +437,13 @@ class DistributedRunner:
                                    return_dict_in_generate=True, **kw)
         return evaluate.rel_results_ids(pred["sequences"], pred["sequences_scores"], batch[3].to(pred["sequences"].device), num_beams)
 
+    def _lanes_map(self, fn, batches):
+        """fn(batch) for every batch in order, several batches in flight when the model offers generation lanes (P5T5Native.map_lanes)."""
+        ml = getattr(self.model, "map_lanes", None)
+        if ml is None or self.gen_lanes <= 1:
+            return (fn(b) for b in batches)
+        return ml(fn, batches, lanes=self.gen_lanes)
+
     def _dataset_trie(self, ds):
         """Item trie of a dataset, compiled once, with the item -> path index used for per-user exclusion."""
         cache = self.__dict__.setdefault("_trie_cache", {})
@@ -468,16 +479,22 @@ class DistributedRunner:
         trie, ct, _ = self._dataset_trie(ds)
         fn = prefix_allowed_tokens_fn(trie)
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
-        for batch in Prefetcher(testloader, pin=self.device.type == "cuda"):      # collation overlaps the previous generate()
+
+        def one(batch):          # runs on a generation lane (its own stream): everything up to the batch's metric sums
             batch = self._to_dev(batch)
             if self.id_metrics:
                 rel = self._generate_ids(batch, self.generate_num, 50, trie=ct)
-                metrics_res = metrics_res + evaluate.get_metrics_results_ids(rel, self.metrics)
-            else:
-                gold, gen, scores = self._generate(batch, fn, self.generate_num, 50)
-                rel = evaluate.rel_results(gen, gold, scores, self.generate_num)
-                metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
-            test_total += len(rel)
+                return evaluate.get_metrics_results_ids(rel, self.metrics), len(rel)
+            gold, gen, scores = self._generate(batch, fn, self.generate_num, 50)
+            rel = evaluate.rel_results(gen, gold, scores, self.generate_num)
+            return evaluate.get_metrics_results(rel, self.metrics), len(rel)
+
+        # (collation overlaps the previous generate(); up to --gen_lanes batches are in flight on the device, results come back in order)
+        for m, n in self._lanes_map(one, Prefetcher(testloader, pin=self.device.type == "cuda")):
+            if torch.is_tensor(m) and m.is_cuda:
+                m.record_stream(torch.cuda.current_stream())      # (allocated on the lane's stream, read here)
+            metrics_res = metrics_res + (m.to(self.device) if torch.is_tensor(m) else m)
+            test_total += n
         return self._finish(metrics_res, test_total, testloader, t0)
 
     @torch.no_grad()
@@ -486,7 +503,8 @@ class DistributedRunner:
         ds = testloader.dataset
         _, ct, index = self._dataset_trie(ds)
         metrics_res, test_total, t0 = 0, 0, time.perf_counter()
-        for batch in Prefetcher(testloader, pin=self.device.type == "cuda"):      # collation overlaps the previous generate()
+
+        def one(batch):
             batch = self._to_dev(batch)
             # the reference rebuilds Trie(all_items - positive) per user (hence its eval_batch_size == 1); here the shared
             # device trie is used with one excluded-node bitmap per user, so any batch size works
@@ -494,7 +512,7 @@ class DistributedRunner:
             excluded = ct.excluded_bitmap([[index[i] for i in ds.positive[u] if i in index] for u in users])
             if self.id_metrics:
                 rel = self._generate_ids(batch, self.generate_num, 30, trie=ct, excluded=excluded)
-                metrics_res = metrics_res + evaluate.get_metrics_results_ids(rel, self.metrics)
+                return evaluate.get_metrics_results_ids(rel, self.metrics), len(rel)
             else:
                 input_ids, attn, whole_ids, output_ids = batch[0], batch[1], batch[2], batch[3]
                 pred = self.model.generate(input_ids=input_ids, attention_mask=attn, whole_word_ids=whole_ids, max_length=30, trie=ct,
@@ -503,8 +521,13 @@ class DistributedRunner:
                 gold = self.tokenizer.batch_decode(output_ids, skip_special_tokens=True)
                 gen = self.tokenizer.batch_decode(pred["sequences"], skip_special_tokens=True)
                 rel = evaluate.rel_results(gen, gold, pred["sequences_scores"].detach().cpu().tolist(), self.generate_num)
-                metrics_res = metrics_res + evaluate.get_metrics_results(rel, self.metrics)
-            test_total += len(rel)
+                return evaluate.get_metrics_results(rel, self.metrics), len(rel)
+
+        for m, n in self._lanes_map(one, Prefetcher(testloader, pin=self.device.type == "cuda")):
+            if torch.is_tensor(m) and m.is_cuda:
+                m.record_stream(torch.cuda.current_stream())      # (allocated on the lane's stream, read here)
+            metrics_res = metrics_res + (m.to(self.device) if torch.is_tensor(m) else m)
+            test_total += n
         return self._finish(metrics_res, test_total, testloader, t0)
 
     @torch.no_grad()
