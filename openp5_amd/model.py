@@ -146,7 +146,7 @@ class P5T5Native(nn.Module):
     verify_extra_beams = 6
     verify_escalation = (22,)     # extra beams of the wider draft a FLAGGED user gets before the plain fp32 search is the last resort
     verify_share_encoder = True   # verified mode: the draft starts from the verification pass's fp32 encoder output (one encoder pass per batch)
-    gen_lanes = 2                 # batches in flight in `map_lanes` (the runner's evaluation loops, bench.py): lanes overlap each other's latency-bound chains
+    gen_lanes = 3                 # batches in flight in `map_lanes` (the runner's evaluation loops, bench.py): lanes overlap each other's latency-bound chains
     prefix_fast_forward = True    # the steps every item shares ("<dataset> item _") as one teacher-forced pass (p5_generate_set_forced_prefix)
 
     def __init__(self, config, dtype: str = "bf16", device=None, backend=None, seed: int = 2023):

@@ -48,7 +48,7 @@ def parse_runner_args(parser):
     parser.add_argument("--test_before_train", type=int, default=1, help="whether test before training")
     parser.add_argument("--test_filtered", type=int, default=0, help="whether filter out the items in the training data.")
     parser.add_argument("--test_filtered_batch", type=int, default=1, help="whether testing with filtered data in batch.")
-    parser.add_argument("--gen_lanes", type=int, default=2, help="evaluation batches in flight (P5T5Native.map_lanes): each lane has its own search / "
+    parser.add_argument("--gen_lanes", type=int, default=3, help="evaluation batches in flight (P5T5Native.map_lanes): each lane has its own search / "
                         "verification engines, workspaces and HIP stream over the one set of weights, so one batch's latency-bound beam search overlaps "
                         "the next one's; 1 = one batch at a time")
     parser.add_argument("--id_metrics", type=int, default=1, help="compare generated token ids with the gold ids on the device "
@@ -177,7 +177,7 @@ class DistributedRunner:
         self.test_before_train = args.test_before_train
         self.test_filtered, self.test_filtered_batch = args.test_filtered, args.test_filtered_batch
         self.id_metrics = int(getattr(args, "id_metrics", 1))
-        self.gen_lanes = int(getattr(args, "gen_lanes", 2))
+        self.gen_lanes = int(getattr(args, "gen_lanes", 3))
         self.metrics = args.metrics.split(",")
         self.generate_num = max(int(m.split("@")[1]) for m in self.metrics)
         self.get_testloader()

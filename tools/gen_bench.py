@@ -28,5 +28,13 @@ for _ in range(n):
     tm.append(model.last_generate_timing())
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 enc = sorted(t["encode_ms"] for t in tm)[n // 2]; dec = sorted(t["decode_ms"] for t in tm)[n // 2]
+lanes = int(os.environ.get("P5_GEN_LANES", "0"))
+if lanes > 1:        # several batches in flight (P5T5Native.map_lanes)
+    model.time_generate(False)
+    list(model.map_lanes(lambda k: model.generate(**k), [kw] * (2 * lanes), lanes=lanes))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    list(model.map_lanes(lambda k: model.generate(**k), [kw] * (4 * n), lanes=lanes))
+    torch.cuda.synchronize(); dl = (time.perf_counter() - t0) / (4 * n)
+    print(f"{lanes} lanes: {dl*1e3:.3f} ms per batch in flight, {gB*K/dl:.0f} items/s")
 print(f"dtype {os.environ.get('P5_GEN_DTYPE', 'bf16')} mode {model.generation_mode}+{model.verify_extra_beams} {model.verify_stats} B={gB} K={K} ms/batch {dt*1e3:.3f} (median device: encode {enc:.3f} decode {dec:.3f}) items/s {gB*K/dt:.0f} "
       f"decoded_len {o['sequences'].shape[1]}")
