@@ -682,7 +682,10 @@ class P5T5Native(nn.Module):
             ln.stream.wait_stream(main)
         q, lock, tls = collections.deque(pool), threading.Lock(), self._tls
 
+        dev = self._be.device
+
         def init():
+            torch.cuda.set_device(dev)          # (the current device is per host thread; rank r of a multi-GPU job is not on device 0)
             with lock:
                 tls.lane = q.popleft()
 

@@ -920,6 +920,9 @@ def list_difference(ranked, ref, r_lp, ro, so, o_lp):
             "dropped": max([dropped_gap(ro[i], o_lp[i], ranked, r_lp) for i in only_o] + [0.0])}
 
 
+_ORACLE_TOKEN_LP = {}
+
+
 def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol, oracle_rankings=None):
     """Every hypothesis a search returned, scored by the ORACLE on the same token sequence (O.sequence_scores): per user
     (a) max |returned score - oracle score of that sequence|, (b) the largest inversion of the returned order under the oracle's
@@ -938,8 +941,12 @@ def teacher_forced_check(runner, params, ocfg, rankings, K, score_tol, order_tol
             with torch.no_grad():
                 ref, tok, _ = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1], _pack_sequences(chunk, K), True)
                 if oracle_rankings is not None:
-                    _, otok, _ = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1],
-                                                   _pack_sequences(oracle_rankings[li][ui:ui + B], K), True)
+                    # (the oracle's token log-probabilities of its OWN lists do not depend on the engine under test: computed once per gate)
+                    key = (id(oracle_rankings), li, ui)
+                    if key not in _ORACLE_TOKEN_LP:
+                        _ORACLE_TOKEN_LP[key] = O.sequence_scores(params, ocfg, batch[0], batch[2], batch[1],
+                                                                   _pack_sequences(oracle_rankings[li][ui:ui + B], K), True)[1]
+                    otok = _ORACLE_TOKEN_LP[key]
             for b, (_, ranked, sc) in enumerate(chunk):
                 err = max(abs(float(ref[b, j]) - sc[j]) for j in range(K))
                 inv = max([float(ref[b, j + 1] - ref[b, j]) for j in range(K - 1)] + [0.0])
@@ -1507,10 +1514,13 @@ def dataset_gate(be, tmp, ocfg_of, K=10, min_users=200, max_fallback_frac=0.05, 
     # ---- headline mode and fp32 engine: every user's ranked list identical to the oracle's up to swaps of items the ORACLE scores within
     # 1e-4 of each other, the gold item at the same rank for every user, every Hit@k / NDCG@k EQUAL, scores within 1e-4; and every returned
     # hypothesis, re-scored by the oracle on the same token sequence (teacher-forced, O.sequence_scores), within 1e-4 and in order
+    _ORACLE_TOKEN_LP.clear()
     for name, c, r, m in (("verified", cver, r_ver, m_ver), ("fp32 engine", c32, r_fp32, m_fp32)):
         assert c["identical_up_to_ties"] == c["users"] and c["max_score_diff"] <= 1e-4, (name, c)
         assert c["identical_lists"] >= 0.98 * c["users"], (name, c)
         assert c["same_gold_rank"] == c["users"] and m == m_or, (name, m, m_or)
+        if name != "verified" and c["identical_lists"] == c["users"]:
+            continue       # (identical lists with scores within 1e-4: the teacher-forced re-scoring would repeat the oracle's own numbers -- a minute of CPU)
         tf = teacher_forced_check(runner, params_o, ocfg, r, K, 1e-4, FP32_TIE_TOL, r_or)
         print(f"[dataset] teacher-forced, {name}:", {k: v for k, v in tf.items() if not isinstance(v, list)}, "max dropped", max(tf["dropped"]))
         assert tf["users"] == c["users"] and tf["score_viol"] == 0 and tf["order_viol"] == 0 and max(tf["dropped"]) <= FP32_TIE_TOL, (name, tf["max_score_err"])

@@ -25,4 +25,5 @@ l = json.load(open('gpurun_out/r05_bench_line.json'))
 print('ms/step', l['ms_per_step'], 'gen', l['generation']['items_per_s'], l['generation']['verify_stats'], 'after noise', l['generation'].get('after_noise_training'), 'plain', l['generation_plain_bf16']['items_per_s'])
 print('roofline_generation', l.get('roofline_generation'))
 "
-timeout 1500 python -m pytest tests/test_gpu_dataset.py -x -q -s -k ml1m > gpurun_out/r5_ml1m_gate.log 2>&1; grep "\[dataset\]\|passed\|failed" gpurun_out/r5_ml1m_gate.log | cut -c1-500 | tail -14
+timeout 2400 python -m pytest tests -q -m gpu -s --durations=15 > gpurun_out/r5_gpu_suite_full.log 2>&1
+grep "\[dataset\]\|\[verified\|passed\|failed\|FAILED" gpurun_out/r5_gpu_suite_full.log | cut -c1-400 | tail -40
