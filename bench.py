@@ -216,14 +216,14 @@ def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, 
     timing = None
     if hasattr(model, "time_generate"):
         model.time_generate(True)
-        enc, dec = [], []
+        enc, dec, ff = [], [], 0
         for _ in range(3):
             model.generate(**kw)
             t = model.last_generate_timing()
             enc.append(t["encode_ms"])
             dec.append(t["decode_ms"])
+            ff = int(t["forced_prefix_steps"])
         model.time_generate(False)
-        ff = len(getattr(model, "_forced", ([], []))[0])
         timing = {"encode_ms": sorted(enc)[1], "decode_ms": sorted(dec)[1], "forced_prefix_steps": ff,
                   "source": "HIP events recorded by p5_generate around its decode loop, median of 3 calls; encode_ms = encoder pass (or the cast of the "
                             "verification pass's encoder output) + the forced-prefix pass + cross-attention K/V + beam state"}

@@ -471,6 +471,178 @@ __global__ __launch_bounds__(NW * 64) void p5_attn_fwd_wg_kernel(P5AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward, one workgroup per (batch, head) for 128 < Lk <= 512 (bf16; C5: T5-large at L = 512).  p5_attn_fwd_kernel<T, 32> streams
+// K and V in 64-key tiles per 64-query block, every tile a global round trip behind a barrier with 8 MFMAs of work per wave in
+// between: 76 TF/s at B=64, H=16, L=512 (profiles/r04_c5_t5large_l512_step_kernels.md).  Here the whole K and V of the head are
+// resident in LDS (2 x 64 KiB at Lk = 512: rows of 128 bytes, no padding, 16-byte pieces XOR-swizzled by the row so that the
+// fragment reads below stay conflict-free), fetched ONCE per head with every load in flight before the single barrier; the 8 waves
+// then take the 16-query blocks round-robin with no further workgroup barrier: scores for all keys in registers, the exact two-pass
+// softmax of p5_attn_fwd_kernel (same operations per score), and O = P V with P handed to the MFMA straight from the score
+// registers -- a lane's eight probabilities of a 32-key chunk (keys 32u + 4g + r and 32u + 16 + 4g + r) become the k-slots 8g..8g+7
+// of the A operand, and the V fragment is read (ds_read_b64_tr_b16) from the rows of exactly those keys, so P never goes through LDS.
+//   K image: piece' = piece ^ ((row >> 1) & 7)      (ds_read_b128 of 16 consecutive rows, one piece: 16 distinct 16-byte slots)
+//   V image: piece' = piece ^ (((row >> 1) & 3) << 1)   (transposed 8-byte reads of 8 consecutive rows x 32 bytes)
+// ------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
+  using T = bf16;
+  using C = AttnC<T>;
+  constexpr int LK = NKT * 16, NT = 512, NP = LK * 8 / NT;
+  static_assert(NKT == 16 || NKT == 32, "whole-head attention forward: 256 or 512 key slots");
+  __shared__ __attribute__((aligned(16))) char tK[LK * 128];
+  __shared__ __attribute__((aligned(16))) char tV[LK * 128];
+  __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * C::TS];        // wave_store_16x64's staging rows, one block per wave
+  __shared__ float sbias[1024];
+  __shared__ __attribute__((aligned(16))) float skneg[LK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+
+  // ---- every global load of the workgroup, then one barrier ----
+  {
+    u32x4 rk[NP], rv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      rk[i] = row < a.Lk ? ld16(K + (size_t)row * a.ldk + pc * 8) : zero16();
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();      // (rows past Lk: zeros, 0 x garbage would be NaN)
+    }
+    const int nrel = a.Lq + a.Lk - 1;
+    for (int i = tid; i < nrel; i += NT)       // (no table -- cross-attention: zeros, the softmax pass below reads the bias unconditionally)
+      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      st16(tK + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rk[i]);
+      st16(tV + row * 128 + ((pc ^ (((row >> 1) & 3) << 1)) << 4), rv[i]);
+    }
+  }
+  u32x4 qn[2];
+  {
+    const int qrow = wave * 16 + li;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) qn[c] = qrow < a.Lq ? ld16(Q + (size_t)qrow * a.ldq + c * 32 + g * 8) : zero16();
+  }
+  __syncthreads();
+
+  const int nkt = (a.Lk + 15) / 16;
+  const bool causal = a.causal != 0;
+  const int koff0 = li * 128 + (((0 + g) ^ ((li >> 1) & 7)) << 4), koff1 = li * 128 + (((4 + g) ^ ((li >> 1) & 7)) << 4);
+  const int vrow = g * 4 + (li >> 2), vsw = ((g * 2 + (li >> 3)) & 3) << 1;
+  char* pw = pbuf + wave * 16 * C::TS;
+  for (int q0 = wave * 16; q0 < a.Lq; q0 += 128) {
+    const u32x4 qf0 = qn[0], qf1 = qn[1];
+    if (q0 + 128 < a.Lq) {           // the next block's Q fragment is in flight under this block's work
+      const int qrow = q0 + 128 + li;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) qn[c] = qrow < a.Lq ? ld16(Q + (size_t)qrow * a.ldq + c * 32 + g * 8) : zero16();
+    }
+    const int qi = q0 + li;
+    const bool qok = qi < a.Lq;
+    const int qic = qok ? qi : a.Lq - 1;
+
+    // ---- scores (transposed: keys along the accumulator rows, see p5_attn_fwd_kernel) ----
+    f32x4 s[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t < nkt) {
+        mma16<T>(s[t], ld16(tK + t * 2048 + koff0), qf0);
+        mma16<T>(s[t], ld16(tK + t * 2048 + koff1), qf1);
+      }
+      if ((t & 3) == 3) P5_SCHED_FENCE();       // (keeps the fragment reads of at most four key blocks in flight: registers)
+    }
+    if (causal) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = (t * 16 + g * 4 + r > qi) ? P5_NEG_INF : s[t][r];
+    }
+    // (key slots past Lk and masked keys carry -inf in skneg, rows past Lq are never stored: no per-element validity select;
+    // a valid score goes through exactly the operations of p5_attn_fwd_kernel: (s + mask) + bias)
+    float m = P5_NEG_INF;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int kb = t * 16 + g * 4;
+      const f32x4 kn = *(const f32x4*)(skneg + kb);
+      const float* pb = sbias + (kb - qic + a.Lq - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (s[t][r] + kn[r]) + pb[r];
+        s[t][r] = v;
+        m = fmaxf(m, v);
+      }
+      if (t & 1) P5_SCHED_FENCE();             // (bias / mask reads of two key blocks at a time, not of all of them)
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (m == P5_NEG_INF) m = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = p5_exp<T>(s[t][r] - m);
+        s[t][r] = p;
+        l += p;
+      }
+      if ((t & 3) == 3) P5_SCHED_FENCE();
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (g == 0 && qok && a.lse) a.lse[((size_t)b * a.H + h) * a.Lq + qi] = m + logf(l);
+    if (a.drop.state != nullptr && a.drop.thr != 0) {
+      const uint32_t seed = p5_seed(a.drop);
+      const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t idx = rowbase + (uint32_t)(t * 16 + g * 4 + r);
+          s[t][r] = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? s[t][r] * a.drop.scale : 0.f;
+        }
+        if ((t & 1) == 1) P5_SCHED_FENCE();      // (eight hash chains interleaved, not all 128: registers)
+      }
+    }
+
+    // ---- O = P V, P from the score registers (32 keys per MFMA: blocks 2u and 2u + 1) ----
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      if (u * 32 < a.Lk) {
+        const float p8[8] = {s[2 * u][0], s[2 * u][1], s[2 * u][2], s[2 * u][3], s[2 * u + 1][0], s[2 * u + 1][1], s[2 * u + 1][2], s[2 * u + 1][3]};
+        const u32x4 pa = pack16<T>(p8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const char* base = tV + (u * 32 + vrow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ vsw) << 4) + (li & 1) * 8;
+          const u32x2 lo = lds_tr16_b64(base);
+          const u32x2 hi = lds_tr16_b64(base + 16 * 128);
+          u32x4 vb;
+          vb[0] = lo[0]; vb[1] = lo[1]; vb[2] = hi[0]; vb[3] = hi[1];
+          mma16<T>(o[dt], pa, vb);
+        }
+      }
+      P5_SCHED_FENCE();
+    }
+    const float inv_q = l > 0.f ? 1.f / l : 0.f;
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv[r] = __shfl(inv_q, g * 4 + r);
+    wave_store_16x64<T>((T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64, a.ldo, q0, a.Lq, o, inv, pw, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // backward, part 1: dQ (+ d rel-bias table, + D = rowsum(dO*O) for part 2).  One wave = 16 queries.
 // ------------------------------------------------------------------------------------------------------------
 template <class T>
@@ -717,6 +889,332 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, pP, lane);
   wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, pS, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward for 128 < L <= 512 (bf16; C5), the operands that every block re-reads resident in LDS as in p5_attn_fwd_head_kernel (rows of
+// 128 bytes, pieces XOR-swizzled by (row >> 1) & 7: the 16-row fragment reads are conflict-free, the transposed reads two-way).  The two
+// kernels above fetch their K / V (Q / dO) tiles per 64-row block behind two barriers each: 28 ms of the 144 ms C5 step
+// (profiles/r04_c5_t5large_l512_step_kernels.md).  Same element arithmetic as those kernels (P recomputed from the saved log-sum-exp);
+// dS (and P) reach the MFMA from the registers that computed them -- keys (queries) 32u + 4g + r and 32u + 16 + 4g + r as the k-slots
+// 8g .. 8g+7, the other operand's rows read in that order -- instead of through an LDS tile.
+//   part 1, dQ (+ D, + d rel-bias): K and V of the head resident; four waves take the 16-query blocks round-robin, per-wave rows of
+//   diagonal sums as in p5_attn_bwd_dq_kernel (dS still goes through the wave's own LDS tile for those), ONE relative-bias slot per
+//   (batch, head).  4 waves, not 8: the four rows of diagonal sums + two resident operands fill the 160 KiB.
+// ------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) {
+  using T = bf16;
+  using C = AttnC<T>;
+  constexpr int LK = NKT * 16, NT = 256, NP = LK * 8 / NT;
+  static_assert(NKT == 16 || NKT == 32, "whole-head attention backward: 256 or 512 key slots");
+  __shared__ __attribute__((aligned(16))) char tK[LK * 128];
+  __shared__ __attribute__((aligned(16))) char tV[LK * 128];
+  __shared__ __attribute__((aligned(16))) char pbuf[4 * 16 * C::TS];
+  __shared__ __attribute__((aligned(16))) float sbias[1024];
+  __shared__ float sdb[4][1024];          // per-wave sums of dS along the diagonals (relative positions)
+  __shared__ __attribute__((aligned(16))) float skneg[LK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+  const T* dO = (const T*)a.dO + (size_t)b * a.Lq * a.lddo + h * 64;
+  const T* O = (const T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64;
+  const int nrel = a.Lq + a.Lk - 1;
+  const int nch = (a.Lk + 63) / 64;
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {          // (K, then V: 16 loads in flight per thread at a time)
+    const T* src = half ? V : K;
+    const int ld = half ? a.ldv : a.ldk;
+    char* dst = half ? tV : tK;
+    u32x4 rr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      rr[i] = row < a.Lk ? ld16(src + (size_t)row * ld + pc * 8) : zero16();
+    }
+    if (half == 0) {
+      for (int i = tid; i < nrel; i += NT)
+        sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+      for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
+      if (a.d_rel_table)
+        for (int i = tid; i < 4 * 1024; i += NT) (&sdb[0][0])[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      st16(dst + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rr[i]);
+    }
+  }
+  // the first block's row operands; the next block's are fetched under the current block's work
+  u32x4 qn[2], don[2], on[2];
+  float lse_n = 0.f;
+  {
+    const int qrow = wave * 16 + li;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      qn[c] = qrow < a.Lq ? ld16(Q + (size_t)qrow * a.ldq + c * 32 + g * 8) : zero16();
+      don[c] = qrow < a.Lq ? ld16(dO + (size_t)qrow * a.lddo + c * 32 + g * 8) : zero16();
+      on[c] = qrow < a.Lq ? ld16(O + (size_t)qrow * a.ldo + c * 32 + g * 8) : zero16();
+    }
+    lse_n = qrow < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + qrow] : 0.f;
+  }
+  __syncthreads();
+
+  const bool causal = a.causal != 0;
+  const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const uint32_t seed = p5_seed(a.drop);
+  const int ksw = (li >> 1) & 7;
+  const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
+  const int trow = g * 4 + (li >> 2), tsw = (g * 2 + (li >> 3)) & 7;
+  char* pw = pbuf + wave * 16 * C::TS;
+  for (int q0 = wave * 16; q0 < a.Lq; q0 += 64) {
+    const u32x4 qf0 = qn[0], qf1 = qn[1], dof0 = don[0], dof1 = don[1];
+    const float lse_q = lse_n;
+    const int qi = q0 + li;
+    const bool qok = qi < a.Lq;
+    const int qic = qok ? qi : a.Lq - 1;
+    float Drow = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float x[8], y[8];
+      unpack16<T>(don[c], x);
+      unpack16<T>(on[c], y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Drow += x[e] * y[e];
+    }
+    Drow += __shfl_xor(Drow, 16);
+    Drow += __shfl_xor(Drow, 32);
+    if (g == 0 && qok) a.Dvec[((size_t)b * a.H + h) * a.Lq + qi] = Drow;
+    const float D_q = Drow;
+    if (q0 + 64 < a.Lq) {
+      const int qrow = q0 + 64 + li;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        qn[c] = qrow < a.Lq ? ld16(Q + (size_t)qrow * a.ldq + c * 32 + g * 8) : zero16();
+        don[c] = qrow < a.Lq ? ld16(dO + (size_t)qrow * a.lddo + c * 32 + g * 8) : zero16();
+        on[c] = qrow < a.Lq ? ld16(O + (size_t)qrow * a.ldo + c * 32 + g * 8) : zero16();
+      }
+      lse_n = qrow < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + qrow] : 0.f;
+    }
+    const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nch; ++ch) {
+      const char* cK = tK + ch * 64 * 128;
+      const char* cV = tV + ch * 64 * 128;
+      float dsv[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+        mma16<T>(sacc, ld16(cK + t * 2048 + koff0), qf0);
+        mma16<T>(sacc, ld16(cK + t * 2048 + koff1), qf1);
+        mma16<T>(dpacc, ld16(cV + t * 2048 + koff0), dof0);
+        mma16<T>(dpacc, ld16(cV + t * 2048 + koff1), dof1);
+        const int kb = ch * 64 + t * 16 + g * 4;
+        const f32x4 kn = *(const f32x4*)(skneg + kb);
+        const float* pb = sbias + (kb - qic + a.Lq - 1);
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (do_drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = kb + r;
+          const bool ok = qok & !(causal & (kj > qi)) & (kn[r] == 0.f);     // (key slots past Lk carry -inf in skneg)
+          const float p = p5_exp<T>((sacc[r] + pb[r]) - lse_q);
+          dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
+        }
+        if (a.d_rel_table) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
+      }
+      if (a.d_rel_table) {
+        // d(rel-bias): sums of dS along the diagonals of this wave's [16 q][64 keys] tile into the wave's OWN row (p5_attn_bwd_dq_kernel)
+        P5_WAVE_SYNC();
+        for (int dd = lane; dd < 79; dd += 64) {
+          float sum = 0.f;
+#pragma unroll
+          for (int qr = 0; qr < 16; ++qr) {
+            const int kcol = dd - 15 + qr;
+            if (kcol >= 0 && kcol < 64) sum += to_f<T>(*(const T*)(pw + qr * C::TS + kcol * C::SZ));
+          }
+          const int idx = ch * 64 + dd - 15 - q0 + a.Lq - 1;
+          if (idx >= 0 && idx < nrel) sdb[wave][idx] += sum;
+        }
+        P5_WAVE_SYNC();
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float d8[8] = {dsv[2 * u][0], dsv[2 * u][1], dsv[2 * u][2], dsv[2 * u][3], dsv[2 * u + 1][0], dsv[2 * u + 1][1], dsv[2 * u + 1][2], dsv[2 * u + 1][3]};
+        const u32x4 da = pack16<T>(d8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const char* base = cK + (u * 32 + trow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ tsw) << 4) + (li & 1) * 8;
+          const u32x2 lo = lds_tr16_b64(base);
+          const u32x2 hi = lds_tr16_b64(base + 16 * 128);
+          u32x4 kb4;
+          kb4[0] = lo[0]; kb4[1] = lo[1]; kb4[2] = hi[0]; kb4[3] = hi[1];
+          mma16<T>(dq[dt], da, kb4);
+        }
+      }
+    }
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, pw, lane);
+  }
+  if (a.d_rel_table) {
+    __syncthreads();
+    for (int i = tid; i < nrel; i += NT) sdb[0][i] = ((sdb[0][i] + sdb[1][i]) + sdb[2][i]) + sdb[3][i];      // (waves in index order)
+    __syncthreads();
+    rel_bias_grad_flush<256>(a, h, b, &sdb[0][0], sbias, tid);      // (sbias is dead from here on)
+  }
+}
+
+//   part 2, dK and dV: Q and dO of the head resident (+ the per-query log-sum-exp and D); eight waves take the 16-key blocks round-robin.
+template <int NQT>
+__global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a) {
+  using T = bf16;
+  using C = AttnC<T>;
+  constexpr int LQ = NQT * 16, NT = 512, NP = LQ * 8 / NT;
+  static_assert(NQT == 16 || NQT == 32, "whole-head attention backward: 256 or 512 query slots");
+  __shared__ __attribute__((aligned(16))) char tQ[LQ * 128];
+  __shared__ __attribute__((aligned(16))) char tDO[LQ * 128];
+  __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * C::TS];
+  __shared__ float sbias[1024];
+  __shared__ __attribute__((aligned(16))) float slse[LQ];
+  __shared__ __attribute__((aligned(16))) float sD[LQ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const T* Q = (const T*)a.Q + (size_t)b * a.Lq * a.ldq + h * 64;
+  const T* K = (const T*)a.K + (size_t)b * a.Lk * a.ldk + h * 64;
+  const T* V = (const T*)a.V + (size_t)b * a.Lk * a.ldv + h * 64;
+  const T* dO = (const T*)a.dO + (size_t)b * a.Lq * a.lddo + h * 64;
+  const int nrel = a.Lq + a.Lk - 1;
+  {
+    u32x4 rq[NP], rd[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      rq[i] = row < a.Lq ? ld16(Q + (size_t)row * a.ldq + pc * 8) : zero16();
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      rd[i] = row < a.Lq ? ld16(dO + (size_t)row * a.lddo + pc * 8) : zero16();
+    }
+    for (int i = tid; i < nrel; i += NT)
+      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int i = tid; i < LQ; i += NT) {
+      slse[i] = i < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
+      sD[i] = i < a.Lq ? a.Dvec[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      st16(tQ + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rq[i]);
+      st16(tDO + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rd[i]);
+    }
+  }
+  u32x4 kn[2], vn[2];
+  bool kok_n;
+  {
+    const int krow = wave * 16 + li;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      kn[c] = krow < a.Lk ? ld16(K + (size_t)krow * a.ldk + c * 32 + g * 8) : zero16();
+      vn[c] = krow < a.Lk ? ld16(V + (size_t)krow * a.ldv + c * 32 + g * 8) : zero16();
+    }
+    kok_n = krow < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + krow] != 0);
+  }
+  __syncthreads();
+
+  const bool causal = a.causal != 0;
+  const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const uint32_t seed = p5_seed(a.drop);
+  const int ksw = (li >> 1) & 7;
+  const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
+  const int trow = g * 4 + (li >> 2), tsw = (g * 2 + (li >> 3)) & 7;
+  char* pw = pbuf + wave * 16 * C::TS;
+  const int nqc = (a.Lq + 63) / 64;
+  for (int k0 = wave * 16; k0 < a.Lk; k0 += 128) {
+    const u32x4 kf0 = kn[0], kf1 = kn[1], vf0 = vn[0], vf1 = vn[1];
+    const bool kok = kok_n;
+    const int kj = k0 + li;
+    if (k0 + 128 < a.Lk) {
+      const int krow = k0 + 128 + li;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        kn[c] = krow < a.Lk ? ld16(K + (size_t)krow * a.ldk + c * 32 + g * 8) : zero16();
+        vn[c] = krow < a.Lk ? ld16(V + (size_t)krow * a.ldv + c * 32 + g * 8) : zero16();
+      }
+      kok_n = krow < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + krow] != 0);
+    }
+    const uint32_t headbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq) * a.Lk) + (uint32_t)kj;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int qc = 0; qc < nqc; ++qc) {
+      const char* cQ = tQ + qc * 64 * 128;
+      const char* cD = tDO + qc * 64 * 128;
+      float pv[4][4], dsv[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+        mma16<T>(sacc, ld16(cQ + t * 2048 + koff0), kf0);
+        mma16<T>(sacc, ld16(cQ + t * 2048 + koff1), kf1);
+        mma16<T>(dpacc, ld16(cD + t * 2048 + koff0), vf0);
+        mma16<T>(dpacc, ld16(cD + t * 2048 + koff1), vf1);
+        const int qb = qc * 64 + t * 16 + g * 4;
+        const f32x4 ls = *(const f32x4*)(slse + qb), dd = *(const f32x4*)(sD + qb);
+        float bias[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qb + r;
+          bias[r] = sbias[kj - (qi < a.Lq ? qi : a.Lq - 1) + a.Lq - 1];
+        }
+        const uint32_t tbase = headbase + (uint32_t)qb * (uint32_t)a.Lk;
+        float mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (do_drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, tbase + (uint32_t)r * (uint32_t)a.Lk, a.drop.thr) ? a.drop.scale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qb + r;
+          const bool ok = kok & (qi < a.Lq) & !(causal & (kj > qi));
+          const float p = p5_exp<T>((sacc[r] + bias[r]) - ls[r]);
+          pv[t][r] = ok ? p * mk[r] : 0.f;
+          dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - dd[r]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float p8[8] = {pv[2 * u][0], pv[2 * u][1], pv[2 * u][2], pv[2 * u][3], pv[2 * u + 1][0], pv[2 * u + 1][1], pv[2 * u + 1][2], pv[2 * u + 1][3]};
+        const float d8[8] = {dsv[2 * u][0], dsv[2 * u][1], dsv[2 * u][2], dsv[2 * u][3], dsv[2 * u + 1][0], dsv[2 * u + 1][1], dsv[2 * u + 1][2], dsv[2 * u + 1][3]};
+        const u32x4 pa = pack16<T>(p8), sa = pack16<T>(d8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int off = (u * 32 + trow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ tsw) << 4) + (li & 1) * 8;
+          u32x2 lo = lds_tr16_b64(cD + off), hi = lds_tr16_b64(cD + off + 16 * 128);
+          u32x4 f;
+          f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+          mma16<T>(dv[dt], pa, f);
+          lo = lds_tr16_b64(cQ + off);
+          hi = lds_tr16_b64(cQ + off + 16 * 128);
+          f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+          mma16<T>(dk[dt], sa, f);
+        }
+      }
+    }
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, pw, lane);
+    wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, pw, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 #include "p5_host.h"
 
 int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")) : 1;   // whole-(batch, head) attention forward (bf16, L <= 128)
+int g_opt_attn_fwd_head = getenv("P5_ATTN_FWD_HEAD") ? atoi(getenv("P5_ATTN_FWD_HEAD")) : 1;   // whole-(batch, head) attention forward with K and V resident in LDS (bf16, 128 < Lk <= 512)
+int g_opt_attn_bwd_head = getenv("P5_ATTN_BWD_HEAD") ? atoi(getenv("P5_ATTN_BWD_HEAD")) : 1;   // attention backward with the re-read operands of a (batch, head) resident in LDS (bf16, 128 < L <= 512)
 int g_opt_attn_small = getenv("P5_ATTN_SMALL") ? atoi(getenv("P5_ATTN_SMALL")) : 1;   // one-launch backward for Lq <= 16
 int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
 
@@ -14,6 +16,13 @@ static int launch_attn_fwd_impl(const P5AttnArgs& a, hipStream_t s) {
     if (g_opt_attn_fwd_wg && a.Lq <= 128 && a.Lk <= 128) {
       if (a.Lq > 64) P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 8>), dim3(a.B * a.H), dim3(512), 0, s, a);
       else P5_LAUNCH((p5_attn_fwd_wg_kernel<T, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      return P5_KCHECK();
+    }
+    // the same for longer key ranges: K and V of the head resident in LDS (2 x 64 KiB at Lk = 512), the waves loop over the query blocks
+    if (g_opt_attn_fwd_head && a.Lk > 128) {
+      P5_PROF_TAG(a.Lk <= 256 ? "head-resident K/V, 256 keys" : "head-resident K/V, 512 keys");
+      if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_head_kernel<16>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_fwd_head_kernel<32>), dim3(a.B * a.H), dim3(512), 0, s, a);
       return P5_KCHECK();
     }
   }
@@ -40,6 +49,17 @@ static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
       return P5_KCHECK();
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    // longer sequences: K / V (dQ pass) and Q / dO (dK, dV pass) of the head resident in LDS, one relative-bias slot per (batch, head)
+    if (g_opt_attn_bwd_head && (a.Lq > 128 || a.Lk > 128)) {
+      if (a.Lk <= 256) P5_LAUNCH((p5_attn_bwd_dq_head_kernel<16>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      else P5_LAUNCH((p5_attn_bwd_dq_head_kernel<32>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      P5_TRY(P5_KCHECK());
+      if (a.Lq <= 256) P5_LAUNCH((p5_attn_bwd_dkv_head_kernel<16>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_bwd_dkv_head_kernel<32>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      return P5_KCHECK();
+    }
+  }
   P5_LAUNCH((p5_attn_bwd_dq_kernel<T>), dim3((a.Lq + 63) / 64, a.B * a.H), block, 0, s, a);
   P5_TRY(P5_KCHECK());
   P5_LAUNCH((p5_attn_bwd_dkv_kernel<T>), dim3((a.Lk + 63) / 64, a.B * a.H), block, 0, s, a);
@@ -52,6 +72,7 @@ static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
 int p5l_attn_bwd_slots(int bf16_mode, int B, int Lq, int Lk) {
   if (g_opt_attn_small && Lq <= 16) return B;
   if (bf16_mode && g_opt_attn_fused && Lq <= 128 && Lk <= 128 && Lq > 16 && Lk > 16) return B;
+  if (bf16_mode && g_opt_attn_bwd_head && (Lq > 128 || Lk > 128)) return B;
   return B * ((Lq + 63) / 64);
 }
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_fwd_impl<bf16>(a, s) : launch_attn_fwd_impl<float>(a, s); }

@@ -52,6 +52,8 @@ extern int g_opt_g4_nst;
 extern int g_opt_g4_wgs;
 extern int g_opt_gemm_ws;
 extern int g_opt_attn_fwd_wg;
+extern int g_opt_attn_fwd_head;
+extern int g_opt_attn_bwd_head;
 extern int g_opt_attn_fused;
 extern int g_opt_attn_small;
 

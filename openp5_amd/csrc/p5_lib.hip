@@ -1889,6 +1889,8 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_small_ring_tiles")) g_opt_gemm_small_ring_tiles = value;
   else if (!strcmp(name, "attn_fused")) g_opt_attn_fused = value;
   else if (!strcmp(name, "attn_fwd_wg")) g_opt_attn_fwd_wg = value;
+  else if (!strcmp(name, "attn_fwd_head")) g_opt_attn_fwd_head = value;
+  else if (!strcmp(name, "attn_bwd_head")) g_opt_attn_bwd_head = value;
   else if (!strcmp(name, "attn_small")) g_opt_attn_small = value;
   else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;

@@ -908,13 +908,14 @@ class P5T5Native(nn.Module):
         self._gen_timed = bool(enable)
 
     def last_generate_timing(self):
-        """{"encode_ms", "decode_ms"} of the most recent `generate` call made while `time_generate()` was armed: device time of the
-        encoder pass + cross-attention K/V projections, and of the decode loop alone (waits for that call to finish).  None if not armed."""
+        """{"encode_ms", "decode_ms", "forced_prefix_steps"} of the calling thread's most recent `generate` call made while `time_generate()`
+        was armed: device time of the encoder pass + cross-attention K/V projections (+ the forced-prefix pass), and of the decode loop
+        alone (waits for that call to finish); the number of steps the forced-prefix pass covered.  None if not armed."""
         if not getattr(self, "_gen_timed", False):
             return None
         a, b = ctypes.c_float(0.0), ctypes.c_float(0.0)
         self._be.check(self._lib.p5_generate_timing(self._engine, 1, ctypes.byref(a), ctypes.byref(b)), "p5_generate_timing")
-        return {"encode_ms": float(a.value), "decode_ms": float(b.value)}
+        return {"encode_ms": float(a.value), "decode_ms": float(b.value), "forced_prefix_steps": len(self._cur_lane().forced[0])}
 
     def _explore_callable(self, fn, B, max_length):
         """Compat path for an arbitrary prefix_allowed_tokens_fn(batch_id, prefix): enumerate it breadth-first into one

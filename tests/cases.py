@@ -369,9 +369,11 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
     return errs
 
 
-def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6):
-    """bf16 attention forward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_fwd_wg_kernel) against the
-    64-query-block kernel on identical inputs and masks.  Same arithmetic in the same order per row: outputs and lse are equal."""
+def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"attn_fwd_wg", exact=True):
+    """bf16 attention forward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_fwd_wg_kernel; for Lk > 128
+    option b"attn_fwd_head": p5_attn_fwd_head_kernel) against the 64-query-block kernel on identical inputs and masks.  Same arithmetic
+    in the same order per row: outputs and lse are equal (exact=False: the log-sum-exp is equal, the outputs agree to one bf16
+    rounding -- the head-resident kernel feeds P to the MFMA in another key order)."""
     g = torch.Generator().manual_seed(seed)
     inner = H * 64
     tt = torch.bfloat16
@@ -394,18 +396,21 @@ def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6):
     rng = dev(be, torch.tensor([4321, 3], dtype=torch.int32))
     res = []
     for wg in (1, 0):
-        be.check(be.lib.p5_set_option(b"attn_fwd_wg", wg), "set_option")
+        be.check(be.lib.p5_set_option(option, wg), "set_option")
         Od = dev(be, torch.zeros(B * Lq, inner, dtype=tt))
         lse = dev(be, torch.zeros(B * H * Lq))
         be.check(be.lib.p5_op_attn_fwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, Lq, Lk, ldq, ldk,
                                        ldk, inner, 1 if mode == "dec" else 0, P(rng), 9, drop_p, be.stream_ptr()), "attn_fwd")
         sync(be)
         res.append((Od.cpu().float(), lse.cpu().clone()))
-    be.check(be.lib.p5_set_option(b"attn_fwd_wg", 1), "set_option")
+    be.check(be.lib.p5_set_option(option, 1), "set_option")
     (oa, la), (ob, lb) = res
     assert ob.abs().max() > 0.05
     assert torch.equal(la, lb), float((la - lb).abs().max())
-    assert torch.equal(oa, ob), float((oa - ob).abs().max())
+    if exact:
+        assert torch.equal(oa, ob), float((oa - ob).abs().max())
+    else:
+        assert bool(((oa - ob).abs() <= ob.abs() * 2.0 ** -7 + 1e-6).all()), float((oa - ob).abs().max())
 
 
 def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"attn_fused"):

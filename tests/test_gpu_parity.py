@@ -218,6 +218,22 @@ def test_generation_lanes_match_one_at_a_time(hip, mode):
                 assert (a["sequences_scores"].cpu() - b["sequences_scores"].cpu()).abs().max() <= 1e-6
 
 
+def test_bench_generation_timing_counts_decode_steps(hip):
+    """bench.time_generation: `forced_prefix_steps` (what roofline_generation divides the decode-loop time by) is the number of steps the
+    forced-prefix pass covered on the lane that ran the timed calls -- 4 for "<dataset> item _ ..." ids -- and the decode loop ran the
+    remaining steps only (with the option off: 0, and the loop takes longer)."""
+    import torch
+    import bench
+    _, model, _ = bench.build_model("t5-small", "bf16", torch.device("cuda:0"), hip, 1, 0, dropout=0.0)
+    trie = bench.synth_item_trie(300, 7)
+    _, dec_len, timing, _, _ = bench.time_generation(model, 8, 10, 64, trie, 30, 3, 1, torch.device("cuda:0"), 500, mode="draft")
+    assert timing["forced_prefix_steps"] == 4 and dec_len >= 8, (timing, dec_len)
+    model.prefix_fast_forward = False
+    _, dec_len2, timing2, _, _ = bench.time_generation(model, 8, 10, 64, trie, 30, 3, 1, torch.device("cuda:0"), 500, mode="draft")
+    assert timing2["forced_prefix_steps"] == 0 and dec_len2 == dec_len, (timing2, dec_len2)
+    assert timing2["decode_ms"] > timing["decode_ms"], (timing, timing2)
+
+
 def test_train_trajectory_fp32(hip):
     cases.train_trajectory_case(hip, O.T5Cfg.named("tiny"), 3, 20, 6)
 
