@@ -78,6 +78,19 @@ def test_attention_forward_whole_head_matches_blocked(hip, mode, Lq, Lk):
     cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode)
 
 
+@pytest.mark.parametrize("mode,Lq,Lk", [("enc", 512, 512), ("enc", 300, 300), ("dec", 150, 150), ("cross", 10, 512), ("cross", 40, 260), ("enc", 129, 129)])
+def test_attention_forward_head_resident_matches_blocked(hip, mode, Lq, Lk):
+    """bf16, dropout on, 128 < Lk <= 512: K and V of a (batch, head) resident in LDS, P to the MFMA from the score registers
+    (p5_attn_fwd_head_kernel) against the 64-query-block kernel: equal log-sum-exp, outputs to one bf16 rounding"""
+    cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode, option=b"attn_fwd_head", exact=False)
+
+
+@pytest.mark.parametrize("mode,L", [("enc", 512), ("dec", 150), ("enc", 300)])
+def test_attention_head_resident_backward_matches_blocked(hip, mode, L):
+    """bf16, dropout on: the L > 128 backward with the re-read operands resident in LDS against the 64-row-block kernels"""
+    cases.attn_fused_bwd_case(hip, 3, 2, L, mode, option=b"attn_bwd_head")
+
+
 @pytest.mark.parametrize("mode,L", [("dec", 8), ("dec", 16), ("enc", 12), ("dec", 5)])
 def test_attention_short_block_backward_matches_split(hip, mode, L):
     """bf16, dropout on: the one-launch backward for Lq <= 16 (p5_attn_bwd_small_kernel: the four waves split the keys) against the
