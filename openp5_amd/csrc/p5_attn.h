@@ -181,9 +181,9 @@ __device__ static __forceinline__ void rel_bias_grad_flush(const P5AttnArgs& a, 
   } else {
     // NT / 64 threads per bucket: each adds a contiguous part of the bucket's interval in order, the parts are added in order
     // (at L = 512 the outermost bucket holds ~400 relative positions: one thread walking them alone took ~17 us per workgroup)
-    static_assert(NT % 64 == 0 && NT / 64 <= 4, "rel_bias_grad_flush: at most four threads per bucket");
+    static_assert(NT % 64 == 0 && NT / 64 <= 8, "rel_bias_grad_flush: at most eight threads per bucket");
     constexpr int NP = NT / 64;
-    float* spart = (float*)scratch + 512;          // [NP][64] behind the interval bounds and the nrel <= 1023 bucket ids (scratch: >= 4 KiB)
+    float* spart = (float*)scratch + 512;          // [NP][64] behind the interval bounds and the nrel <= 1023 bucket ids (scratch: >= 4 KiB = 2 KiB + 8 x 64 sums)
     const int bk = tid & 63, part = tid >> 6;
     float acc = 0.f;
     if (shi[bk] >= 0) {
@@ -898,22 +898,27 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dkv_kernel(P5AttnArgs a) {
 // (profiles/r04_c5_t5large_l512_step_kernels.md).  Same element arithmetic as those kernels (P recomputed from the saved log-sum-exp);
 // dS (and P) reach the MFMA from the registers that computed them -- keys (queries) 32u + 4g + r and 32u + 16 + 4g + r as the k-slots
 // 8g .. 8g+7, the other operand's rows read in that order -- instead of through an LDS tile.
-//   part 1, dQ (+ D, + d rel-bias): K and V of the head resident; four waves take the 16-query blocks round-robin, per-wave rows of
-//   diagonal sums as in p5_attn_bwd_dq_kernel (dS still goes through the wave's own LDS tile for those), ONE relative-bias slot per
-//   (batch, head).  4 waves, not 8: the four rows of diagonal sums + two resident operands fill the 160 KiB.
+//   part 1, dQ (+ D, + d rel-bias): K and V of the head resident; eight waves take the 16-query blocks round-robin.  The sums of dS
+//   along the diagonals (relative positions) stay in REGISTERS: relative position + 16 = 64 J + lane, and a 64-key chunk `ch` of the
+//   wave's i-th query block touches J = ch - 2 i + c, c wave-constant, J + 1 and J + 2 -- with the chunk loop unrolled and the 18
+//   accumulators rotated by two per query block those are the fixed registers R[ch], R[ch + 1], R[ch + 2] (four 4-KiB rows of sums per
+//   workgroup, as p5_attn_bwd_dq_kernel keeps them, would not fit beside K and V; with them the kernel was limited to four waves and ran
+//   at 1.27 ms where the blocked kernel takes 0.74: profiles/r05_call14_attention_head_resident.txt).  The per-wave sums meet in LDS
+//   after the last block (K and V are dead by then) and are added in wave order: ONE relative-bias slot per (batch, head).
 // ------------------------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) {
+__global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) {
   using T = bf16;
   using C = AttnC<T>;
-  constexpr int LK = NKT * 16, NT = 256, NP = LK * 8 / NT;
+  constexpr int LK = NKT * 16, NT = 512, NP = LK * 8 / NT, NCH = NKT / 4;
   static_assert(NKT == 16 || NKT == 32, "whole-head attention backward: 256 or 512 key slots");
-  __shared__ __attribute__((aligned(16))) char tK[LK * 128];
-  __shared__ __attribute__((aligned(16))) char tV[LK * 128];
-  __shared__ __attribute__((aligned(16))) char pbuf[4 * 16 * C::TS];
+  static_assert(2 * LK * 128 >= 8 * 1024 * 4, "the per-wave rows of diagonal sums reuse the K and V images");
+  __shared__ __attribute__((aligned(16))) char tKV[2 * LK * 128];
+  __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * C::TS];
   __shared__ __attribute__((aligned(16))) float sbias[1024];
-  __shared__ float sdb[4][1024];          // per-wave sums of dS along the diagonals (relative positions)
   __shared__ __attribute__((aligned(16))) float skneg[LK];
+  char* tK = tKV;
+  char* tV = tKV + LK * 128;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -924,29 +929,26 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
   const T* O = (const T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64;
   const int nrel = a.Lq + a.Lk - 1;
   const int nch = (a.Lk + 63) / 64;
-
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {          // (K, then V: 16 loads in flight per thread at a time)
-    const T* src = half ? V : K;
-    const int ld = half ? a.ldv : a.ldk;
-    char* dst = half ? tV : tK;
-    u32x4 rr[NP];
+  {
+    u32x4 rk[NP], rv[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
-      rr[i] = row < a.Lk ? ld16(src + (size_t)row * ld + pc * 8) : zero16();
-    }
-    if (half == 0) {
-      for (int i = tid; i < nrel; i += NT)
-        sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
-      for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
-      if (a.d_rel_table)
-        for (int i = tid; i < 4 * 1024; i += NT) (&sdb[0][0])[i] = 0.f;
+      rk[i] = row < a.Lk ? ld16(K + (size_t)row * a.ldk + pc * 8) : zero16();
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
-      st16(dst + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rr[i]);
+      rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();
+    }
+    for (int i = tid; i < nrel; i += NT)
+      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = tid + i * NT, row = p >> 3, pc = p & 7;
+      st16(tK + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rk[i]);
+      st16(tV + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4), rv[i]);
     }
   }
   // the first block's row operands; the next block's are fetched under the current block's work
@@ -966,12 +968,23 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
 
   const bool causal = a.causal != 0;
   const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const bool do_rel = a.d_rel_table != nullptr;
   const uint32_t seed = p5_seed(a.drop);
   const int ksw = (li >> 1) & 7;
   const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
   const int trow = g * 4 + (li >> 2), tsw = (g * 2 + (li >> 3)) & 7;
   char* pw = pbuf + wave * 16 * C::TS;
-  for (int q0 = wave * 16; q0 < a.Lq; q0 += 64) {
+  // diagonal sums: relative position (key - query + Lq - 1) + 16 = 64 (ch - 2 i + cw) + rot + dd for the dd-th diagonal (0 .. 78) of
+  // chunk ch of this wave's i-th block (q0 = 16 wave + 128 i)
+  const int cwf = a.Lq - 16 * wave;                  // > 0 for a wave that has a block
+  const int rot = cwf & 63, cw = cwf >> 6;
+  const int src = (lane - rot) & 63;
+  const bool up = lane >= rot;
+  float R[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) R[k] = 0.f;
+  int nblk = 0;
+  for (int q0 = wave * 16; q0 < a.Lq; q0 += 128, ++nblk) {
     const u32x4 qf0 = qn[0], qf1 = qn[1], dof0 = don[0], dof1 = don[1];
     const float lse_q = lse_n;
     const int qi = q0 + li;
@@ -990,8 +1003,8 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
     Drow += __shfl_xor(Drow, 32);
     if (g == 0 && qok) a.Dvec[((size_t)b * a.H + h) * a.Lq + qi] = Drow;
     const float D_q = Drow;
-    if (q0 + 64 < a.Lq) {
-      const int qrow = q0 + 64 + li;
+    if (q0 + 128 < a.Lq) {
+      const int qrow = q0 + 128 + li;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         qn[c] = qrow < a.Lq ? ld16(Q + (size_t)qrow * a.ldq + c * 32 + g * 8) : zero16();
@@ -1005,72 +1018,106 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nch; ++ch) {
-      const char* cK = tK + ch * 64 * 128;
-      const char* cV = tV + ch * 64 * 128;
-      float dsv[4][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
-        mma16<T>(sacc, ld16(cK + t * 2048 + koff0), qf0);
-        mma16<T>(sacc, ld16(cK + t * 2048 + koff1), qf1);
-        mma16<T>(dpacc, ld16(cV + t * 2048 + koff0), dof0);
-        mma16<T>(dpacc, ld16(cV + t * 2048 + koff1), dof1);
-        const int kb = ch * 64 + t * 16 + g * 4;
-        const f32x4 kn = *(const f32x4*)(skneg + kb);
-        const float* pb = sbias + (kb - qic + a.Lq - 1);
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (do_drop) {
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch < nch) {
+        const char* cK = tK + ch * 64 * 128;
+        const char* cV = tV + ch * 64 * 128;
+        float dsv[4][4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+        for (int t = 0; t < 4; ++t) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+          mma16<T>(sacc, ld16(cK + t * 2048 + koff0), qf0);
+          mma16<T>(sacc, ld16(cK + t * 2048 + koff1), qf1);
+          mma16<T>(dpacc, ld16(cV + t * 2048 + koff0), dof0);
+          mma16<T>(dpacc, ld16(cV + t * 2048 + koff1), dof1);
+          const int kb = ch * 64 + t * 16 + g * 4;
+          const f32x4 kn = *(const f32x4*)(skneg + kb);
+          const float* pb = sbias + (kb - qic + a.Lq - 1);
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (do_drop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kj = kb + r;
+            const bool ok = qok & !(causal & (kj > qi)) & (kn[r] == 0.f);     // (key slots past Lk carry -inf in skneg)
+            const float p = p5_exp<T>((sacc[r] + pb[r]) - lse_q);
+            dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
+          }
+          if (do_rel) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kj = kb + r;
-          const bool ok = qok & !(causal & (kj > qi)) & (kn[r] == 0.f);     // (key slots past Lk carry -inf in skneg)
-          const float p = p5_exp<T>((sacc[r] + pb[r]) - lse_q);
-          dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
-        }
-        if (a.d_rel_table) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
-      }
-      if (a.d_rel_table) {
-        // d(rel-bias): sums of dS along the diagonals of this wave's [16 q][64 keys] tile into the wave's OWN row (p5_attn_bwd_dq_kernel)
-        P5_WAVE_SYNC();
-        for (int dd = lane; dd < 79; dd += 64) {
-          float sum = 0.f;
+        if (do_rel) {
+          // sums of dS (as the MFMA sees it: bf16) along the 79 diagonals of this wave's [16 q][64 keys] tile: lane = diagonal for the
+          // first 64, lanes 0..14 the rest; every read unconditional (clamped column, the value selected away) so that the sixteen of them
+          // are in flight together
+          P5_WAVE_SYNC();
+          float x1 = 0.f, x2 = 0.f;
 #pragma unroll
           for (int qr = 0; qr < 16; ++qr) {
-            const int kcol = dd - 15 + qr;
-            if (kcol >= 0 && kcol < 64) sum += to_f<T>(*(const T*)(pw + qr * C::TS + kcol * C::SZ));
+            const int k1 = lane - 15 + qr, k2 = lane + 49 + qr;
+            const int c1 = k1 < 0 ? 0 : k1, c2 = k2 > 63 ? 63 : k2;
+            const float v1 = to_f<T>(*(const T*)(pw + qr * C::TS + c1 * C::SZ));
+            const float v2 = to_f<T>(*(const T*)(pw + qr * C::TS + c2 * C::SZ));
+            x1 += k1 >= 0 ? v1 : 0.f;
+            x2 += k2 <= 63 ? v2 : 0.f;
           }
-          const int idx = ch * 64 + dd - 15 - q0 + a.Lq - 1;
-          if (idx >= 0 && idx < nrel) sdb[wave][idx] += sum;
+          P5_WAVE_SYNC();
+          const float y1 = __shfl(x1, src), y2 = __shfl(x2, src);
+          R[ch] += up ? y1 : 0.f;
+          R[ch + 1] += up ? y2 : y1;
+          R[ch + 2] += up ? 0.f : y2;
         }
-        P5_WAVE_SYNC();
-      }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float d8[8] = {dsv[2 * u][0], dsv[2 * u][1], dsv[2 * u][2], dsv[2 * u][3], dsv[2 * u + 1][0], dsv[2 * u + 1][1], dsv[2 * u + 1][2], dsv[2 * u + 1][3]};
-        const u32x4 da = pack16<T>(d8);
+        for (int u = 0; u < 2; ++u) {
+          const float d8[8] = {dsv[2 * u][0], dsv[2 * u][1], dsv[2 * u][2], dsv[2 * u][3], dsv[2 * u + 1][0], dsv[2 * u + 1][1], dsv[2 * u + 1][2], dsv[2 * u + 1][3]};
+          const u32x4 da = pack16<T>(d8);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const char* base = cK + (u * 32 + trow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ tsw) << 4) + (li & 1) * 8;
-          const u32x2 lo = lds_tr16_b64(base);
-          const u32x2 hi = lds_tr16_b64(base + 16 * 128);
-          u32x4 kb4;
-          kb4[0] = lo[0]; kb4[1] = lo[1]; kb4[2] = hi[0]; kb4[3] = hi[1];
-          mma16<T>(dq[dt], da, kb4);
+          for (int dt = 0; dt < 4; ++dt) {
+            const char* base = cK + (u * 32 + trow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ tsw) << 4) + (li & 1) * 8;
+            const u32x2 lo = lds_tr16_b64(base);
+            const u32x2 hi = lds_tr16_b64(base + 16 * 128);
+            u32x4 kb4;
+            kb4[0] = lo[0]; kb4[1] = lo[1]; kb4[2] = hi[0]; kb4[3] = hi[1];
+            mma16<T>(dq[dt], da, kb4);
+          }
         }
       }
     }
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
     wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, pw, lane);
+    // the next block's diagonals sit 128 positions lower: J' = J + 2, the accumulators move up by two (the top two wrap to the bottom)
+    {
+      const float t16 = R[16], t17 = R[17];
+#pragma unroll
+      for (int k = 17; k >= 2; --k) R[k] = R[k - 2];
+      R[0] = t16; R[1] = t17;
+    }
   }
-  if (a.d_rel_table) {
+  if (do_rel) {
+    // R[k] holds J = (cw - 2 nblk + k) mod 18 ... after nblk rotations; relative position = 64 J + lane - 16.  Rows of 1024 sums per wave
+    // over the dead K / V images, added in wave order
     __syncthreads();
-    for (int i = tid; i < nrel; i += NT) sdb[0][i] = ((sdb[0][i] + sdb[1][i]) + sdb[2][i]) + sdb[3][i];      // (waves in index order)
+    float* rows = (float*)tKV;
+    for (int i = lane; i < 1024; i += 64) rows[wave * 1024 + i] = 0.f;
+    P5_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      int J = (cw - 2 * nblk + k) % 18;
+      if (J < 0) J += 18;
+      const int idx = 64 * J + lane - 16;
+      if (idx >= 0 && idx < nrel) rows[wave * 1024 + idx] = R[k];
+    }
     __syncthreads();
-    rel_bias_grad_flush<256>(a, h, b, &sdb[0][0], sbias, tid);      // (sbias is dead from here on)
+    for (int i = tid; i < nrel; i += NT) {
+      float t = rows[i];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) t += rows[w * 1024 + i];
+      rows[i] = t;
+    }
+    __syncthreads();
+    rel_bias_grad_flush<512>(a, h, b, rows, sbias, tid);      // (sbias is dead from here on)
   }
 }
 

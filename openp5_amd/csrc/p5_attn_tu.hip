@@ -52,8 +52,8 @@ static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // longer sequences: K / V (dQ pass) and Q / dO (dK, dV pass) of the head resident in LDS, one relative-bias slot per (batch, head)
     if (g_opt_attn_bwd_head && (a.Lq > 128 || a.Lk > 128)) {
-      if (a.Lk <= 256) P5_LAUNCH((p5_attn_bwd_dq_head_kernel<16>), dim3(a.B * a.H), dim3(256), 0, s, a);
-      else P5_LAUNCH((p5_attn_bwd_dq_head_kernel<32>), dim3(a.B * a.H), dim3(256), 0, s, a);
+      if (a.Lk <= 256) P5_LAUNCH((p5_attn_bwd_dq_head_kernel<16>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_bwd_dq_head_kernel<32>), dim3(a.B * a.H), dim3(512), 0, s, a);
       P5_TRY(P5_KCHECK());
       if (a.Lq <= 256) P5_LAUNCH((p5_attn_bwd_dkv_head_kernel<16>), dim3(a.B * a.H), dim3(512), 0, s, a);
       else P5_LAUNCH((p5_attn_bwd_dkv_head_kernel<32>), dim3(a.B * a.H), dim3(512), 0, s, a);
