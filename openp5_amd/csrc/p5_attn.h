@@ -38,6 +38,10 @@ struct P5AttnArgs {
   int rel_copies;        // number of buckets of the relative-bias table: the workgroup STORES that many sums per head into its slot of d_rel_table
   int rel_stride;
   P5Drop drop;
+  // dropout keep decisions of the probabilities, written by the head-resident forward and read by the head-resident backward (bf16,
+  // 128 < L <= 512) instead of being re-hashed twice: per (batch, head, 16-query block) 256 words -- word [half * 128 + n], n = t * 4 + r,
+  // is the lane mask (lanes 32 half .. 32 half + 31; lane = 16 g + li) of keep(query 16 block + li, key 16 t + 4 g + r).  nullptr: hash.
+  uint32_t* keep_bits;
 };
 
 
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) void p5_attn_fwd_wg_kernel(P5AttnArgs a) {
 //   K image: piece' = piece ^ ((row >> 1) & 7)      (ds_read_b128 of 16 consecutive rows, one piece: 16 distinct 16-byte slots)
 //   V image: piece' = piece ^ (((row >> 1) & 3) << 1)   (transposed 8-byte reads of 8 consecutive rows x 32 bytes)
 // ------------------------------------------------------------------------------------------------------------
-template <int NKT>
+template <int NKT, bool BITS>          // BITS: the dropout keep decisions also go out as lane masks (P5AttnArgs::keep_bits != nullptr)
 __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
   using T = bf16;
   using C = AttnC<T>;
@@ -602,6 +606,29 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
     if (a.drop.state != nullptr && a.drop.thr != 0) {
       const uint32_t seed = p5_seed(a.drop);
       const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+      if constexpr (BITS) {
+        // the keep decisions also go out as lane masks for the backward (P5AttnArgs::keep_bits): lane n keeps the mask of (t, r) = n
+        uint32_t mlo[NKT / 16], mhi[NKT / 16];
+#pragma unroll
+        for (int i = 0; i < NKT / 16; ++i) { mlo[i] = 0u; mhi[i] = 0u; }
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t idx = rowbase + (uint32_t)(t * 16 + g * 4 + r);
+            const bool keep = p5_keep(seed, a.drop.site_key, idx, a.drop.thr);
+            s[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
+            const unsigned long long bal = __ballot(keep);
+            const int n = t * 4 + r;
+            mlo[n >> 6] = p5_writelane(mlo[n >> 6], (uint32_t)bal, n & 63);
+            mhi[n >> 6] = p5_writelane(mhi[n >> 6], (uint32_t)(bal >> 32), n & 63);
+          }
+          P5_SCHED_FENCE();
+        }
+        uint32_t* kp = a.keep_bits + (((size_t)b * a.H + h) * ((a.Lq + 15) / 16) + (q0 >> 4)) * 256;
+#pragma unroll
+        for (int i = 0; i < NKT / 16; ++i) { kp[i * 64 + lane] = mlo[i]; kp[128 + i * 64 + lane] = mhi[i]; }
+      } else {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
 #pragma unroll
@@ -609,7 +636,8 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
           const uint32_t idx = rowbase + (uint32_t)(t * 16 + g * 4 + r);
           s[t][r] = p5_keep(seed, a.drop.site_key, idx, a.drop.thr) ? s[t][r] * a.drop.scale : 0.f;
         }
-        if ((t & 1) == 1) P5_SCHED_FENCE();      // (eight hash chains interleaved, not all 128: registers)
+        P5_SCHED_FENCE();      // (four hash chains interleaved, not all 128: registers)
+      }
       }
     }
 
@@ -969,6 +997,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
   const bool causal = a.causal != 0;
   const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
   const bool do_rel = a.d_rel_table != nullptr;
+  const bool use_bits = do_drop && a.keep_bits != nullptr;
   const uint32_t seed = p5_seed(a.drop);
   const int ksw = (li >> 1) & 7;
   const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
@@ -1014,6 +1043,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
       lse_n = qrow < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + qrow] : 0.f;
     }
     const uint32_t rowbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq + qi) * a.Lk);
+    const uint32_t* kp = use_bits ? a.keep_bits + (((size_t)b * a.H + h) * ((a.Lq + 15) / 16) + (q0 >> 4)) * 256 : nullptr;
 
     f32x4 dq[4];
 #pragma unroll
@@ -1024,6 +1054,11 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
         const char* cK = tK + ch * 64 * 128;
         const char* cV = tV + ch * 64 * 128;
         float dsv[4][4];
+        u32x4 kw[4];          // the forward's keep masks of this chunk's 16 (t, r): the half of each that holds this lane
+        if (use_bits) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) kw[t] = ld16(kp + (lane >> 5) * 128 + ch * 16 + t * 4);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
@@ -1035,7 +1070,10 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
           const f32x4 kn = *(const f32x4*)(skneg + kb);
           const float* pb = sbias + (kb - qic + a.Lq - 1);
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (do_drop) {
+          if (use_bits) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[r] = ((kw[t][r] >> (lane & 31)) & 1u) ? a.drop.scale : 0.f;
+          } else if (do_drop) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
           }
@@ -1182,6 +1220,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
 
   const bool causal = a.causal != 0;
   const bool do_drop = a.drop.state != nullptr && a.drop.thr != 0;
+  const bool use_bits = do_drop && a.keep_bits != nullptr;
   const uint32_t seed = p5_seed(a.drop);
   const int ksw = (li >> 1) & 7;
   const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
@@ -1202,6 +1241,9 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
       kok_n = krow < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + krow] != 0);
     }
     const uint32_t headbase = (uint32_t)((((size_t)b * a.H + h) * a.Lq) * a.Lk) + (uint32_t)kj;
+    // the forward's keep masks (P5AttnArgs::keep_bits): this lane's key is (t, r) = (kj / 16, kj % 4) in lanes 16 g' .. 16 g' + 15, g' = kj / 4 % 4
+    const char* kpk = use_bits ? (const char*)(a.keep_bits + ((size_t)b * a.H + h) * ((a.Lq + 15) / 16) * 256) +
+                                     ((((kj >> 3) & 1) * 128 + (kj >> 4) * 4 + (kj & 3)) * 4 + ((kj >> 2) & 1) * 2) : nullptr;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1226,7 +1268,11 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
         }
         const uint32_t tbase = headbase + (uint32_t)qb * (uint32_t)a.Lk;
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (do_drop) {
+        if (use_bits) {
+          const unsigned piece = *(const unsigned short*)(kpk + (size_t)(qc * 4 + t) * 1024);      // 16 queries of block qc * 4 + t
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk[r] = ((piece >> (g * 4 + r)) & 1u) ? a.drop.scale : 0.f;
+        } else if (do_drop) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, tbase + (uint32_t)r * (uint32_t)a.Lk, a.drop.thr) ? a.drop.scale : 0.f;
         }

@@ -4,6 +4,7 @@
 int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")) : 1;   // whole-(batch, head) attention forward (bf16, L <= 128)
 int g_opt_attn_fwd_head = getenv("P5_ATTN_FWD_HEAD") ? atoi(getenv("P5_ATTN_FWD_HEAD")) : 1;   // whole-(batch, head) attention forward with K and V resident in LDS (bf16, 128 < Lk <= 512)
 int g_opt_attn_bwd_head = getenv("P5_ATTN_BWD_HEAD") ? atoi(getenv("P5_ATTN_BWD_HEAD")) : 1;   // attention backward with the re-read operands of a (batch, head) resident in LDS (bf16, 128 < L <= 512)
+int g_opt_attn_keep_bits = getenv("P5_ATTN_KEEP_BITS") ? atoi(getenv("P5_ATTN_KEEP_BITS")) : 1;   // the long-sequence forward stores its dropout decisions as lane masks for the backward (bf16, L > 128; decided when the workspace is laid out)
 int g_opt_attn_small = getenv("P5_ATTN_SMALL") ? atoi(getenv("P5_ATTN_SMALL")) : 1;   // one-launch backward for Lq <= 16
 int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
 
@@ -20,9 +21,13 @@ static int launch_attn_fwd_impl(const P5AttnArgs& a, hipStream_t s) {
     }
     // the same for longer key ranges: K and V of the head resident in LDS (2 x 64 KiB at Lk = 512), the waves loop over the query blocks
     if (g_opt_attn_fwd_head && a.Lk > 128) {
+      // (P5AttnArgs::keep_bits is honoured by the head-resident kernels only: the caller passes it only if forward AND backward take them)
       P5_PROF_TAG(a.Lk <= 256 ? "head-resident K/V, 256 keys" : "head-resident K/V, 512 keys");
-      if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_head_kernel<16>), dim3(a.B * a.H), dim3(512), 0, s, a);
-      else P5_LAUNCH((p5_attn_fwd_head_kernel<32>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      const bool bits = a.keep_bits != nullptr && a.drop.state != nullptr && a.drop.thr != 0;
+      if (a.Lk <= 256 && bits) P5_LAUNCH((p5_attn_fwd_head_kernel<16, true>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else if (a.Lk <= 256) P5_LAUNCH((p5_attn_fwd_head_kernel<16, false>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else if (bits) P5_LAUNCH((p5_attn_fwd_head_kernel<32, true>), dim3(a.B * a.H), dim3(512), 0, s, a);
+      else P5_LAUNCH((p5_attn_fwd_head_kernel<32, false>), dim3(a.B * a.H), dim3(512), 0, s, a);
       return P5_KCHECK();
     }
   }

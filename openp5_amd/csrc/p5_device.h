@@ -282,6 +282,16 @@ template <class T> __device__ static __forceinline__ float p5_exp(float x);
 template <> __device__ __forceinline__ float p5_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float p5_exp<bf16>(float x) { return __expf(x); }
 
+// ---- a wave-uniform value into ONE lane of a register (v_writelane_b32: no compare, no select) -------------------
+#ifdef P5_EMU
+static inline uint32_t p5_writelane(uint32_t old, uint32_t v, int n) { return (int)emu::lane() == n ? v : old; }
+#else
+__device__ static __forceinline__ uint32_t p5_writelane(uint32_t old, uint32_t v, int n) {      // v: wave-uniform, n: compile-time constant
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(n));
+  return old;
+}
+#endif
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll

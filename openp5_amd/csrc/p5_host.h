@@ -54,6 +54,7 @@ extern int g_opt_gemm_ws;
 extern int g_opt_attn_fwd_wg;
 extern int g_opt_attn_fwd_head;
 extern int g_opt_attn_bwd_head;
+extern int g_opt_attn_keep_bits;
 extern int g_opt_attn_fused;
 extern int g_opt_attn_small;
 

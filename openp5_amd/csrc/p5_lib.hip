@@ -75,6 +75,7 @@ struct LayerSave {
   void *x_ca, *n_ca, *q_ca, *kv_ca, *o_ca; float *rstd_ca, *lse_ca;
   void *x_ff, *n_ff, *u_ff, *h_ff; float *rstd_ff;
   float *ssq_sa, *ssq_ca, *ssq_ff;     // [rows, d/64] partial sums of squares of x_sa / x_ca / x_ff (norm folded into the GEMMs)
+  uint32_t* keep_sa;                   // dropout keep masks of the self-attention probabilities (P5AttnArgs::keep_bits) or nullptr
 };
 
 struct Bump {
@@ -614,6 +615,8 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     l.n_sa = b.take(M * d * sz); l.rstd_sa = (float*)b.take(M * 4);
     l.ssq_sa = (float*)b.take(M * (d / 64) * 4); l.ssq_ff = (float*)b.take(M * (d / 64) * 4); l.ssq_ca = nullptr;
     l.qkv = b.take(M * 3 * in * sz); l.o_sa = b.take(M * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * L * 4);
+    // long sequences (the head-resident attention kernels): the forward's dropout decisions as bit masks for the two backward passes
+    l.keep_sa = (with_bwd && c.dtype == 1 && L > 128 && g_opt_attn_keep_bits) ? (uint32_t*)b.take((size_t)B * H * ((L + 15) / 16) * 1024) : nullptr;
     l.x_ff = b.take(M * d * sz);
     l.n_ff = b.take(M * d * sz); l.rstd_ff = (float*)b.take(M * 4);
     l.u_ff = c.gated_gelu ? b.take(M * 2 * F * sz) : nullptr;
@@ -633,6 +636,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
       l.n_sa = b.take(Md * d * sz); l.rstd_sa = (float*)b.take(Md * 4);
       l.ssq_sa = (float*)b.take(Md * (d / 64) * 4); l.ssq_ca = (float*)b.take(Md * (d / 64) * 4); l.ssq_ff = (float*)b.take(Md * (d / 64) * 4);
       l.qkv = b.take(Md * 3 * in * sz); l.o_sa = b.take(Md * in * sz); l.lse_sa = (float*)b.take((size_t)B * H * T * 4);
+      l.keep_sa = nullptr;
       l.x_ca = b.take(Md * d * sz);
       l.n_ca = b.take(Md * d * sz); l.rstd_ca = (float*)b.take(Md * 4);
       l.q_ca = b.take(Md * in * sz); l.o_ca = b.take(Md * in * sz);
@@ -747,6 +751,7 @@ static int encoder_fwd(P5Engine* e, hipStream_t s) {
     a.rel_table = e->P + e->off_enc_rel; a.bucket_lut = e->lut_enc; a.lut_half = e->lut_half; a.kmask = e->mask;
     a.B = e->B; a.H = H; a.Lq = e->L; a.Lk = e->L; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.causal = 0;
     a.drop = mk_drop(e, 0, i, 1);
+    a.keep_bits = (g_opt_attn_fwd_head && g_opt_attn_bwd_head && g_opt_attn_keep_bits) ? l.keep_sa : nullptr;      // (both passes on the head-resident kernels, or neither reads / writes the masks)
     P5_TRY(launch_attn_fwd<T>(a, s));
     if (nf) P5_TRY(gemm_nf<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), in, l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, mk_drop(e, 0, i, 2), nullptr, 0.f, l.ssq_ff, d));
     else P5_TRY(linear_fwd<T>(s, l.o_sa, in, Wc<T>(e, lo.sa.o), l.x_ff, d, M, d, in, P5_EPI_RESID_DROP, l.x_sa, d, 1.f, 0, mk_drop(e, 0, i, 2)));
@@ -917,6 +922,7 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.B = e->B; a.H = H; a.Lq = Lq; a.Lk = Lq; a.ldq = a.ldk = a.ldv = 3 * in; a.ldo = in; a.lddo = in;
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
   a.drop = mk_drop(e, is_dec ? 1 : 0, li, 1);
+  a.keep_bits = (!is_dec && g_opt_attn_fwd_head && g_opt_attn_bwd_head && g_opt_attn_keep_bits) ? l.keep_sa : nullptr;
   P5_TRY(launch_attn_bwd<T>(a, s));
   P5_TRY(linear_wgrad<T>(e, s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
   P5_TRY(dgrad_w<T>(e, s, e->dqkv, 3 * in, lo.sa.q, e->dn, d, rows, 3 * in, d));
@@ -1891,6 +1897,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "attn_fwd_wg")) g_opt_attn_fwd_wg = value;
   else if (!strcmp(name, "attn_fwd_head")) g_opt_attn_fwd_head = value;
   else if (!strcmp(name, "attn_bwd_head")) g_opt_attn_bwd_head = value;
+  else if (!strcmp(name, "attn_keep_bits")) g_opt_attn_keep_bits = value;
   else if (!strcmp(name, "attn_small")) g_opt_attn_small = value;
   else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;

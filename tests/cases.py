@@ -1160,6 +1160,34 @@ def backward_reproducible_case(be, ocfg, B, L, T, runs=4, dropout=0.0, dtype="bf
         assert not bad, (r, bad[:8], len(bad))
 
 
+def attn_keep_bits_case(be, ocfg, B, L, T, dropout=0.1):
+    """bf16, 128 < L <= 512, dropout on: the head-resident attention forward stores its keep decisions as lane masks and the two backward
+    passes read them (P5AttnArgs::keep_bits; workspace laid out per encoder layer) instead of re-evaluating the counter-based hash --
+    the SAME decisions, so the loss and every gradient are bit-identical to the hashed path (option attn_keep_bits 0) and to the blocked
+    kernels' masks (the gradient gates against the oracle's mask run elsewhere)."""
+    params = O.init_params(ocfg, 7)
+    a = synth_batch(ocfg, B, L, T, 3)
+    outs = []
+    try:
+        for bits in (1, 0, 1):
+            be.check(be.lib.p5_set_option(b"attn_keep_bits", bits), "set_option")
+            m = build_model(be, ocfg, params, "bf16", dropout)
+            m.train()
+            m.set_dropout_seed(41, 5)
+            loss = m.loss_and_backward(*a)
+            sync(be)
+            outs.append((float(loss), m._grads.detach().cpu().clone()))
+            views = dict(m._views)
+    finally:
+        be.check(be.lib.p5_set_option(b"attn_keep_bits", 1), "set_option")
+    assert outs[0][1].abs().max() > 0
+    for r in (1, 2):
+        assert outs[r][0] == outs[0][0], (r, outs[r][0], outs[0][0])
+        bad = [(n, float((outs[r][1][o:o + k] - outs[0][1][o:o + k]).abs().max())) for n, (o, k, _) in views.items()
+               if not torch.equal(outs[r][1][o:o + k], outs[0][1][o:o + k])]
+        assert not bad, (r, bad[:8], len(bad))
+
+
 def staged_backward_case(be, ocfg, B, L, T, dtype="bf16", dropout=0.0):
     """The staged backward of the data-parallel path (p5_backward_staged = every p5_backward_stage + p5_backward_final_range in one call): the ranges it reports are
     contiguous, walk the arena from the back and tile it exactly; every gradient equals the whole backward's bit for bit -- with and

@@ -261,6 +261,16 @@ static EmuGridDim gridDim;
 static inline void __syncthreads() { emu::syncthreads(); }
 template <class T> static inline T __shfl_xor(T v, int m) { return emu::shfl_idx(v, (int)emu::lane() ^ m); }
 template <class T> static inline T __shfl(T v, int src) { return emu::shfl_idx(v, src); }
+// 64-bit lane mask of a predicate (full waves only: the slots of lanes that have exited are not cleared)
+static inline unsigned long long __ballot(int pred) {
+  emu::Wave& w = emu::wave();
+  w.slot[emu::lane()][0] = pred ? 1 : 0;
+  emu::wave_barrier();
+  unsigned long long r = 0;
+  for (int i = 0; i < 64; ++i) r |= (unsigned long long)(w.slot[i][0] & 1) << i;
+  emu::wave_barrier();
+  return r;
+}
 template <class T> static inline T __shfl_down(T v, int d) {
   int s = (int)emu::lane() + d;
   return emu::shfl_idx(v, s > 63 ? (int)emu::lane() : s);

@@ -178,6 +178,12 @@ def test_attention_head_resident_backward_matches_blocked(emu, mode, L):
     cases.attn_fused_bwd_case(emu, 2, 2, L, mode, option=b"attn_bwd_head")
 
 
+@pytest.mark.parametrize("L", [150, 270])
+def test_attention_keep_masks_equal_hashed_dropout(emu, L):
+    """the long-sequence forward's stored dropout decisions (lane masks) against the re-hashed ones: bit-identical loss and gradients"""
+    cases.attn_keep_bits_case(emu, O.T5Cfg.named("tiny"), 2, L, 4)
+
+
 @pytest.mark.parametrize("mode,L", [("dec", 8), ("dec", 16), ("enc", 12), ("dec", 5)])
 def test_attention_short_block_backward_matches_split(emu, mode, L):
     """bf16, dropout on: the one-launch backward for Lq <= 16 (p5_attn_bwd_small_kernel: the four waves split the keys) against the

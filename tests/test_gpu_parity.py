@@ -91,6 +91,13 @@ def test_attention_head_resident_backward_matches_blocked(hip, mode, L):
     cases.attn_fused_bwd_case(hip, 3, 2, L, mode, option=b"attn_bwd_head")
 
 
+@pytest.mark.parametrize("L", [512, 200])
+def test_attention_keep_masks_equal_hashed_dropout(hip, L):
+    """bf16, L > 128, dropout on: the forward's stored keep decisions (lane masks read by the dQ and dK/dV passes) against the re-hashed
+    ones: bit-identical loss and gradients (T5-small dims, two layers per stack)"""
+    cases.attn_keep_bits_case(hip, O.T5Cfg.named("t5-small", num_layers=2, num_decoder_layers=2), 4, L, 6)
+
+
 @pytest.mark.parametrize("mode,L", [("dec", 8), ("dec", 16), ("enc", 12), ("dec", 5)])
 def test_attention_short_block_backward_matches_split(hip, mode, L):
     """bf16, dropout on: the one-launch backward for Lq <= 16 (p5_attn_bwd_small_kernel: the four waves split the keys) against the
