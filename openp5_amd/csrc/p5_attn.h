@@ -519,8 +519,10 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
       rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();      // (rows past Lk: zeros, 0 x garbage would be NaN)
     }
     const int nrel = a.Lq + a.Lk - 1;
-    for (int i = tid; i < nrel; i += NT)       // (no table -- cross-attention: zeros, the softmax pass below reads the bias unconditionally)
-      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    // (no table -- cross-attention: zeros, the softmax pass below reads the bias unconditionally, also for the key slots past Lk of the
+    // last block: positions up to LK + Lq - 2 are read, (-inf) + an uninitialised NaN would poison the row maximum)
+    for (int i = tid; i < LK + a.Lq - 1; i += NT)
+      sbias[i] = (a.rel_table && i < nrel) ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
     for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -969,8 +971,8 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
       rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();
     }
-    for (int i = tid; i < nrel; i += NT)
-      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int i = tid; i < LK + a.Lq - 1; i += NT)       // (every position the blocks read, key slots past Lk included)
+      sbias[i] = (a.rel_table && i < nrel) ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
     for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -1192,8 +1194,8 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
       rd[i] = row < a.Lq ? ld16(dO + (size_t)row * a.lddo + pc * 8) : zero16();
     }
-    for (int i = tid; i < nrel; i += NT)
-      sbias[i] = a.rel_table ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int i = tid; i < 1023; i += NT)                // (every position the blocks read, key slots past Lk included)
+      sbias[i] = (a.rel_table && i < nrel) ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
     for (int i = tid; i < LQ; i += NT) {
       slse[i] = i < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
       sD[i] = i < a.Lq ? a.Dvec[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
@@ -1247,10 +1249,20 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    unsigned pcn[4] = {0u, 0u, 0u, 0u};          // this key's keep bits for the four 16-query blocks of the NEXT 64-query chunk
+    if (use_bits) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pcn[t] = t * 16 < a.Lq ? *(const unsigned short*)(kpk + (size_t)t * 1024) : 0u;
+    }
     for (int qc = 0; qc < nqc; ++qc) {
       const char* cQ = tQ + qc * 64 * 128;
       const char* cD = tDO + qc * 64 * 128;
       float pv[4][4], dsv[4][4];
+      const unsigned pcc[4] = {pcn[0], pcn[1], pcn[2], pcn[3]};
+      if (use_bits && (qc + 1) * 64 < a.Lq) {      // fetched under this chunk's work
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pcn[t] = ((qc + 1) * 4 + t) * 16 < a.Lq ? *(const unsigned short*)(kpk + (size_t)((qc + 1) * 4 + t) * 1024) : 0u;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
@@ -1269,7 +1281,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
         const uint32_t tbase = headbase + (uint32_t)qb * (uint32_t)a.Lk;
         float mk[4] = {1.f, 1.f, 1.f, 1.f};
         if (use_bits) {
-          const unsigned piece = *(const unsigned short*)(kpk + (size_t)(qc * 4 + t) * 1024);      // 16 queries of block qc * 4 + t
+          const unsigned piece = pcc[t];                // 16 queries of block qc * 4 + t
 #pragma unroll
           for (int r = 0; r < 4; ++r) mk[r] = ((piece >> (g * 4 + r)) & 1u) ? a.drop.scale : 0.f;
         } else if (do_drop) {
