@@ -544,6 +544,16 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
   const int koff0 = li * 128 + (((0 + g) ^ ((li >> 1) & 7)) << 4), koff1 = li * 128 + (((4 + g) ^ ((li >> 1) & 7)) << 4);
   const int vrow = g * 4 + (li >> 2), vsw = ((g * 2 + (li >> 3)) & 3) << 1;
   char* pw = pbuf + wave * 16 * C::TS;
+  // BITS: a block's masks are stored one block later, after the next block's score MFMAs (and after the loop for the last one), so that
+  // a long vector-only section follows the stores.  HARDWARE NOTE (profiles/r05_call21_keep_mask_bisect.txt): the first versions of this
+  // variant returned 1e38 / NaN in the first 16 output columns of some query blocks -- the first P V MFMA of a block had multiplied by
+  // the registers' PREVIOUS contents (ballot words) instead of the transposed V reads issued just before it, behind a partial
+  // `s_waitcnt lgkmcnt(2)`; different from run to run, only on the hardware, only in this variant (whose dropout pass leaves SGPR-sourced
+  // selects right in front of the reads).  Neither moving the stores nor collecting the masks differently changed it; waiting for ALL
+  // eight transposed reads of a chunk before its four MFMAs (P5_WAIT_LGKM0 between scheduling fences, below) did: 0 differing elements
+  // over repeated runs at every grid size (tests: attn_keep_masks_forward_case).
+  uint32_t keep_lo[NKT / 16] = {}, keep_hi[NKT / 16] = {};
+  uint32_t* keep_dst = nullptr;
   for (int q0 = wave * 16; q0 < a.Lq; q0 += 128) {
     const u32x4 qf0 = qn[0], qf1 = qn[1];
     if (q0 + 128 < a.Lq) {           // the next block's Q fragment is in flight under this block's work
@@ -565,6 +575,12 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
         mma16<T>(s[t], ld16(tK + t * 2048 + koff1), qf1);
       }
       if ((t & 3) == 3) P5_SCHED_FENCE();       // (keeps the fragment reads of at most four key blocks in flight: registers)
+    }
+    if constexpr (BITS) {
+      if (keep_dst) {
+#pragma unroll
+        for (int i = 0; i < NKT / 16; ++i) { keep_dst[i * 64 + lane] = keep_lo[i]; keep_dst[128 + i * 64 + lane] = keep_hi[i]; }
+      }
     }
     if (causal) {
 #pragma unroll
@@ -622,14 +638,13 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
             s[t][r] = keep ? s[t][r] * a.drop.scale : 0.f;
             const unsigned long long bal = __ballot(keep);
             const int n = t * 4 + r;
-            mlo[n >> 6] = p5_writelane(mlo[n >> 6], (uint32_t)bal, n & 63);
-            mhi[n >> 6] = p5_writelane(mhi[n >> 6], (uint32_t)(bal >> 32), n & 63);
+            if (lane == (n & 63)) { mlo[n >> 6] = (uint32_t)bal; mhi[n >> 6] = (uint32_t)(bal >> 32); }
           }
           P5_SCHED_FENCE();
         }
-        uint32_t* kp = a.keep_bits + (((size_t)b * a.H + h) * ((a.Lq + 15) / 16) + (q0 >> 4)) * 256;
 #pragma unroll
-        for (int i = 0; i < NKT / 16; ++i) { kp[i * 64 + lane] = mlo[i]; kp[128 + i * 64 + lane] = mhi[i]; }
+        for (int i = 0; i < NKT / 16; ++i) { keep_lo[i] = mlo[i]; keep_hi[i] = mhi[i]; }
+        keep_dst = a.keep_bits + (((size_t)b * a.H + h) * ((a.Lq + 15) / 16) + (q0 >> 4)) * 256;
       } else {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
@@ -652,15 +667,19 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
       if (u * 32 < a.Lk) {
         const float p8[8] = {s[2 * u][0], s[2 * u][1], s[2 * u][2], s[2 * u][3], s[2 * u + 1][0], s[2 * u + 1][1], s[2 * u + 1][2], s[2 * u + 1][3]};
         const u32x4 pa = pack16<T>(p8);
+        u32x4 vb[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const char* base = tV + (u * 32 + vrow) * 128 + (((dt * 2 + ((li >> 1) & 1)) ^ vsw) << 4) + (li & 1) * 8;
           const u32x2 lo = lds_tr16_b64(base);
           const u32x2 hi = lds_tr16_b64(base + 16 * 128);
-          u32x4 vb;
-          vb[0] = lo[0]; vb[1] = lo[1]; vb[2] = hi[0]; vb[3] = hi[1];
-          mma16<T>(o[dt], pa, vb);
+          vb[dt][0] = lo[0]; vb[dt][1] = lo[1]; vb[dt][2] = hi[0]; vb[dt][3] = hi[1];
         }
+        P5_SCHED_FENCE();
+        P5_WAIT_LGKM0();          // (all eight transposed reads have landed before the first MFMA: HARDWARE NOTE above)
+        P5_SCHED_FENCE();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) mma16<T>(o[dt], pa, vb[dt]);
       }
       P5_SCHED_FENCE();
     }
@@ -669,6 +688,12 @@ __global__ __launch_bounds__(512) void p5_attn_fwd_head_kernel(P5AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) inv[r] = __shfl(inv_q, g * 4 + r);
     wave_store_16x64<T>((T*)a.O + (size_t)b * a.Lq * a.ldo + h * 64, a.ldo, q0, a.Lq, o, inv, pw, lane);
+  }
+  if constexpr (BITS) {
+    if (keep_dst) {
+#pragma unroll
+      for (int i = 0; i < NKT / 16; ++i) { keep_dst[i * 64 + lane] = keep_lo[i]; keep_dst[128 + i * 64 + lane] = keep_hi[i]; }
+    }
   }
 }
 

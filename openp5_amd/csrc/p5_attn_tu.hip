@@ -5,6 +5,7 @@ int g_opt_attn_fwd_wg = getenv("P5_ATTN_FWD_WG") ? atoi(getenv("P5_ATTN_FWD_WG")
 int g_opt_attn_fwd_head = getenv("P5_ATTN_FWD_HEAD") ? atoi(getenv("P5_ATTN_FWD_HEAD")) : 1;   // whole-(batch, head) attention forward with K and V resident in LDS (bf16, 128 < Lk <= 512)
 int g_opt_attn_bwd_head = getenv("P5_ATTN_BWD_HEAD") ? atoi(getenv("P5_ATTN_BWD_HEAD")) : 1;   // attention backward with the re-read operands of a (batch, head) resident in LDS (bf16, 128 < L <= 512)
 int g_opt_attn_keep_bits = getenv("P5_ATTN_KEEP_BITS") ? atoi(getenv("P5_ATTN_KEEP_BITS")) : 1;   // the long-sequence forward stores its dropout decisions as lane masks for the backward (bf16, L > 128; decided when the workspace is laid out)
+int g_opt_attn_op_keep_bits = 0;      // test hook: the standalone attention ops use a keep-mask buffer of their own (p5_lib.hip, op_keep_bits)
 int g_opt_attn_small = getenv("P5_ATTN_SMALL") ? atoi(getenv("P5_ATTN_SMALL")) : 1;   // one-launch backward for Lq <= 16
 int g_opt_attn_fused = getenv("P5_ATTN_FUSED") ? atoi(getenv("P5_ATTN_FUSED")) : 1;   // fused dQ/dK/dV attention backward (bf16, L <= 128)
 

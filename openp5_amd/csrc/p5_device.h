@@ -268,10 +268,12 @@ __device__ static __forceinline__ void gload16_raw(u32x4& dst, const void* p) {
 // P5_SCHED_GROUP(mask, n): next n instructions of class mask (0x008 MFMA, 0x020 VMEM read, 0x100 DS read) in the schedule.
 #ifdef P5_EMU
 #define P5_WAIT_VM(n) ((void)0)
+#define P5_WAIT_LGKM0() ((void)0)
 #define P5_BARRIER_LDS() __syncthreads()
 #define P5_SCHED_GROUP(mask, n) ((void)0)
 #else
 #define P5_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define P5_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define P5_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define P5_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
@@ -281,16 +283,6 @@ __device__ static __forceinline__ void gload16_raw(u32x4& dst, const void* p) {
 template <class T> __device__ static __forceinline__ float p5_exp(float x);
 template <> __device__ __forceinline__ float p5_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float p5_exp<bf16>(float x) { return __expf(x); }
-
-// ---- a wave-uniform value into ONE lane of a register (v_writelane_b32: no compare, no select) -------------------
-#ifdef P5_EMU
-static inline uint32_t p5_writelane(uint32_t old, uint32_t v, int n) { return (int)emu::lane() == n ? v : old; }
-#else
-__device__ static __forceinline__ uint32_t p5_writelane(uint32_t old, uint32_t v, int n) {      // v: wave-uniform, n: compile-time constant
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(n));
-  return old;
-}
-#endif
 
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {

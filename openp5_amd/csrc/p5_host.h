@@ -55,6 +55,7 @@ extern int g_opt_attn_fwd_wg;
 extern int g_opt_attn_fwd_head;
 extern int g_opt_attn_bwd_head;
 extern int g_opt_attn_keep_bits;
+extern int g_opt_attn_op_keep_bits;
 extern int g_opt_attn_fused;
 extern int g_opt_attn_small;
 

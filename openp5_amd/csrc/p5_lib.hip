@@ -1898,6 +1898,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "attn_fwd_head")) g_opt_attn_fwd_head = value;
   else if (!strcmp(name, "attn_bwd_head")) g_opt_attn_bwd_head = value;
   else if (!strcmp(name, "attn_keep_bits")) g_opt_attn_keep_bits = value;
+  else if (!strcmp(name, "attn_op_keep_bits")) g_opt_attn_op_keep_bits = value;
   else if (!strcmp(name, "attn_small")) g_opt_attn_small = value;
   else if (!strcmp(name, "gemm_ring32")) g_opt_gemm_ring32 = value;
   else if (!strcmp(name, "gemm_xcd_rect")) g_opt_gemm_xcd_rect = value;
@@ -2466,6 +2467,27 @@ int p5_op_rmsnorm_bwd(int dtype, float* dres_out, void* dy_next, float* dw, cons
   }
   return 0;
 }
+// test hook (p5_set_option "attn_op_keep_bits"): the standalone attention ops hand the long-sequence kernels a keep-mask buffer of their
+// own (P5AttnArgs::keep_bits: written by p5_op_attn_fwd, read by the p5_op_attn_bwd that follows it), as the engine does per encoder layer
+static uint32_t* op_keep_bits(int dtype, int B, int H, int Lq, int Lk, const P5Drop& d) {
+  static uint32_t* buf = nullptr;
+  static size_t cap = 0;
+  if (!g_opt_attn_op_keep_bits || dtype != 1 || Lk <= 128 || d.state == nullptr || d.thr == 0 || !g_opt_attn_fwd_head || !g_opt_attn_bwd_head) return nullptr;
+  const size_t need = (size_t)B * H * ((Lq + 15) / 16) * 1024;
+  if (need > cap) {
+#ifdef P5_EMU
+    free(buf);
+    buf = (uint32_t*)malloc(need);
+    if (!buf) { cap = 0; return nullptr; }
+#else
+    if (buf) (void)hipFree(buf);
+    buf = nullptr; cap = 0;
+    if (hipMalloc((void**)&buf, need) != hipSuccess) return nullptr;      // (the only allocation of the library: a test hook, off by default)
+#endif
+    cap = need;
+  }
+  return buf;
+}
 int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void* O, float* lse, const float* rel_table, const int* lut,
                    int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int causal,
                    const uint32_t* rng_state, uint32_t site, float drop_p, void* stream) {
@@ -2474,6 +2496,7 @@ int p5_op_attn_fwd(int dtype, const void* Q, const void* K, const void* V, void*
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.lse = lse; a.rel_table = rel_table; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.causal = causal;
   a.drop = op_drop(rng_state, site, drop_p);
+  a.keep_bits = op_keep_bits(dtype, B, H, Lq, Lk, a.drop);
   return dtype == 1 ? launch_attn_fwd<bf16>(a, (hipStream_t)stream) : launch_attn_fwd<float>(a, (hipStream_t)stream);
 }
 int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, float* Dvec,
@@ -2486,6 +2509,7 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
   a.rel_table = rel_table; a.d_rel_table = nullptr; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
   a.lddv = lddv; a.causal = causal; a.rel_copies = rel_buckets; a.rel_stride = rel_buckets * H; a.drop = op_drop(rng_state, site, drop_p);
+  a.keep_bits = op_keep_bits(dtype, B, H, Lq, Lk, a.drop);
   hipStream_t s = (hipStream_t)stream;
   if (d_rel_table) {
     P5_REQUIRE(d_rel_scratch && rel_buckets >= 1 && rel_buckets <= 64, "attn_bwd: d_rel_table needs d_rel_scratch [B * ceil(Lq / 64)][rel_buckets * H] and rel_buckets <= 64");

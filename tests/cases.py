@@ -369,7 +369,7 @@ def attn_case(be, dtype, B, H, Lq, Lk, mode, seed=0):
     return errs
 
 
-def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"attn_fwd_wg", exact=True):
+def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"attn_fwd_wg", exact=True, op_bits=False):
     """bf16 attention forward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_fwd_wg_kernel; for Lk > 128
     option b"attn_fwd_head": p5_attn_fwd_head_kernel) against the 64-query-block kernel on identical inputs and masks.  Same arithmetic
     in the same order per row: outputs and lse are equal (exact=False: the log-sum-exp is equal, the outputs agree to one bf16
@@ -395,6 +395,7 @@ def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"
     km_d = dev(be, kmask) if mode != "dec" else None
     rng = dev(be, torch.tensor([4321, 3], dtype=torch.int32))
     res = []
+    be.check(be.lib.p5_set_option(b"attn_op_keep_bits", 1 if op_bits else 0), "set_option")      # (the forward variant that also stores its keep masks)
     for wg in (1, 0):
         be.check(be.lib.p5_set_option(option, wg), "set_option")
         Od = dev(be, torch.zeros(B * Lq, inner, dtype=tt))
@@ -404,8 +405,9 @@ def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"
         sync(be)
         res.append((Od.cpu().float(), lse.cpu().clone()))
     be.check(be.lib.p5_set_option(option, 1), "set_option")
+    be.check(be.lib.p5_set_option(b"attn_op_keep_bits", 0), "set_option")
     (oa, la), (ob, lb) = res
-    assert ob.abs().max() > 0.05
+    assert ob.abs().max() > 0.05 and bool(torch.isfinite(oa).all()) and bool(torch.isfinite(la).all())
     assert torch.equal(la, lb), float((la - lb).abs().max())
     if exact:
         assert torch.equal(oa, ob), float((oa - ob).abs().max())
@@ -413,7 +415,41 @@ def attn_fwd_wg_case(be, B, H, Lq, Lk, mode="enc", drop_p=0.1, seed=6, option=b"
         assert bool(((oa - ob).abs() <= ob.abs() * 2.0 ** -7 + 1e-6).all()), float((oa - ob).abs().max())
 
 
-def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"attn_fused"):
+def attn_keep_masks_forward_case(be, shapes, reps):
+    """bf16, dropout on, 128 < L <= 512: the forward variant that also stores its keep decisions as lane masks (p5_attn_fwd_head_kernel<.., true>;
+    op hook b"attn_op_keep_bits") returns EXACTLY the output and log-sum-exp of the variant that does not, over repeated runs with fresh
+    seeds and at grids of more workgroups than CUs.  (Regression test of a hardware-only failure: with partial lgkmcnt waits between the
+    transposed V reads and the first P V MFMA the masks variant multiplied by stale register contents -- 1e38 / NaN in the first 16 output
+    columns of some rows, different from run to run -- while the emulator and small grids passed: profiles/r05_call21_keep_mask_bisect.txt.)"""
+    import ctypes
+    tt = torch.bfloat16
+    lut_d = dev(be, relative_position_bucket_lut(512, True, 32, 128))
+    try:
+        for (B, H, L) in shapes:
+            inner = H * 64
+            for rep in range(reps):
+                g = torch.Generator().manual_seed(100 + rep)
+                qkv = dev(be, (0.5 * torch.randn(B * L, 3 * inner, generator=g)).to(tt))
+                table_d = dev(be, 0.5 * torch.randn(32, H, generator=g))
+                km_d = dev(be, torch.ones(B, L, dtype=torch.long))
+                rng = dev(be, torch.tensor([4321 + rep, 3], dtype=torch.int32))
+                outs = []
+                for ob in (0, 1, 1):
+                    be.check(be.lib.p5_set_option(b"attn_op_keep_bits", ob), "set_option")
+                    Od = dev(be, torch.zeros(B * L, inner, dtype=tt))
+                    lse = dev(be, torch.zeros(B * H * L))
+                    be.check(be.lib.p5_op_attn_fwd(1, P(qkv), P(qkv[:, inner:]), P(qkv[:, 2 * inner:]), P(Od), P(lse), P(table_d), P(lut_d), 512, P(km_d), B, H, L, L,
+                                                   3 * inner, 3 * inner, 3 * inner, inner, 0, P(rng), 9, ctypes.c_float(0.1), be.stream_ptr()), "attn_fwd")
+                    sync(be)
+                    outs.append((Od.cpu(), lse.cpu()))
+                assert bool(torch.isfinite(outs[0][0].float()).all())
+                for o, l in outs[1:]:
+                    assert torch.equal(o, outs[0][0]) and torch.equal(l, outs[0][1]), (B, H, L, rep, int((o != outs[0][0]).sum()))
+    finally:
+        be.check(be.lib.p5_set_option(b"attn_op_keep_bits", 0), "set_option")
+
+
+def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"attn_fused", op_bits=False):
     """bf16 attention backward with dropout ON: the one-workgroup-per-(batch, head) kernel (p5_attn_bwd_fused_kernel) against the
     two-kernel path on identical inputs (same forward output, lse and counter-based masks).  Both round P and dS to bf16 at the
     same point, so they differ only by the order of fp32 accumulation."""
@@ -435,6 +471,8 @@ def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"at
     rng = dev(be, torch.tensor([1234, 7], dtype=torch.int32))
     Od = dev(be, torch.zeros(B * L, inner, dtype=tt))
     lse = dev(be, torch.zeros(B * H * L))
+    # op_bits: the forward stores its dropout decisions as lane masks and the head-resident backward reads them (the blocked one re-hashes)
+    be.check(be.lib.p5_set_option(b"attn_op_keep_bits", 1 if op_bits else 0), "set_option")
     be.check(be.lib.p5_op_attn_fwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner,
                                    3 * inner, 3 * inner, inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_fwd")
     res = []
@@ -450,8 +488,9 @@ def attn_fused_bwd_case(be, B, H, L, mode="enc", drop_p=0.1, seed=5, option=b"at
         sync(be)
         res.append((dqkv.cpu().float(), dtab.cpu().clone()))
     be.check(be.lib.p5_set_option(option, 1), "set_option")
+    be.check(be.lib.p5_set_option(b"attn_op_keep_bits", 0), "set_option")
     (ga, ta), (gb, tb) = res
-    assert gb.abs().max() > 0.05
+    assert gb.abs().max() > 0.05 and bool(torch.isfinite(ga).all())
     e_g = (ga - gb).abs().max().item() / gb.abs().max().item()
     e_t = (ta - tb).abs().max().item() / max(1e-6, tb.abs().max().item())
     assert e_g <= 1e-2 and e_t <= 1e-3, f"fused vs two-kernel attention backward: grads {e_g}, rel-bias table {e_t}"

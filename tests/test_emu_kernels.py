@@ -157,11 +157,12 @@ def test_attention_forward_whole_head_matches_blocked(emu, mode, Lq, Lk):
 
 
 @pytest.mark.parametrize("mode,Lq,Lk", [("enc", 200, 200), ("enc", 300, 300), ("dec", 150, 150), ("cross", 10, 512), ("cross", 40, 260), ("enc", 129, 129)])
-def test_attention_forward_head_resident_matches_blocked(emu, mode, Lq, Lk):
+@pytest.mark.parametrize("op_bits", [False, True])
+def test_attention_forward_head_resident_matches_blocked(emu, mode, Lq, Lk, op_bits):
     """bf16, dropout on, 128 < Lk <= 512: the kernel that keeps the whole K and V of a (batch, head) in LDS and hands P to the MFMA from
     the score registers (p5_attn_fwd_head_kernel<16 / 32>) against the 64-query-block kernel: equal log-sum-exp, outputs to one bf16
     rounding; ragged key counts, key-padding masks, causal, cross-attention without a bias table."""
-    cases.attn_fwd_wg_case(emu, 2, 2, Lq, Lk, mode, option=b"attn_fwd_head", exact=False)
+    cases.attn_fwd_wg_case(emu, 2, 2, Lq, Lk, mode, option=b"attn_fwd_head", exact=False, op_bits=op_bits)
 
 
 @pytest.mark.parametrize("mode,Lq,Lk", [("enc", 200, 200), ("dec", 150, 150), ("cross", 40, 260), ("cross", 130, 70), ("enc", 270, 270)])
@@ -172,10 +173,15 @@ def test_attention_long_bf16(emu, mode, Lq, Lk):
 
 
 @pytest.mark.parametrize("mode,L", [("enc", 200), ("dec", 150), ("enc", 300)])
-def test_attention_head_resident_backward_matches_blocked(emu, mode, L):
+@pytest.mark.parametrize("op_bits", [False, True])
+def test_attention_head_resident_backward_matches_blocked(emu, mode, L, op_bits):
     """bf16, dropout on: the backward with the re-read operands of a (batch, head) resident in LDS against the 64-row-block kernels on
     identical inputs: dQ, dK, dV and the relative-bias table's gradient (they differ by the order of fp32 accumulation only)."""
-    cases.attn_fused_bwd_case(emu, 2, 2, L, mode, option=b"attn_bwd_head")
+    cases.attn_fused_bwd_case(emu, 2, 2, L, mode, option=b"attn_bwd_head", op_bits=op_bits)
+
+
+def test_attention_forward_storing_masks_equals_plain_forward(emu):
+    cases.attn_keep_masks_forward_case(emu, [(1, 2, 300), (2, 1, 200)], 1)
 
 
 @pytest.mark.parametrize("L", [150, 270])

@@ -79,16 +79,23 @@ def test_attention_forward_whole_head_matches_blocked(hip, mode, Lq, Lk):
 
 
 @pytest.mark.parametrize("mode,Lq,Lk", [("enc", 512, 512), ("enc", 300, 300), ("dec", 150, 150), ("cross", 10, 512), ("cross", 40, 260), ("enc", 129, 129)])
-def test_attention_forward_head_resident_matches_blocked(hip, mode, Lq, Lk):
+@pytest.mark.parametrize("op_bits", [False, True])
+def test_attention_forward_head_resident_matches_blocked(hip, mode, Lq, Lk, op_bits):
     """bf16, dropout on, 128 < Lk <= 512: K and V of a (batch, head) resident in LDS, P to the MFMA from the score registers
     (p5_attn_fwd_head_kernel) against the 64-query-block kernel: equal log-sum-exp, outputs to one bf16 rounding"""
-    cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode, option=b"attn_fwd_head", exact=False)
+    cases.attn_fwd_wg_case(hip, 3, 2, Lq, Lk, mode, option=b"attn_fwd_head", exact=False, op_bits=op_bits)
 
 
 @pytest.mark.parametrize("mode,L", [("enc", 512), ("dec", 150), ("enc", 300)])
-def test_attention_head_resident_backward_matches_blocked(hip, mode, L):
+@pytest.mark.parametrize("op_bits", [False, True])
+def test_attention_head_resident_backward_matches_blocked(hip, mode, L, op_bits):
     """bf16, dropout on: the L > 128 backward with the re-read operands resident in LDS against the 64-row-block kernels"""
-    cases.attn_fused_bwd_case(hip, 3, 2, L, mode, option=b"attn_bwd_head")
+    cases.attn_fused_bwd_case(hip, 3, 2, L, mode, option=b"attn_bwd_head", op_bits=op_bits)
+
+
+def test_attention_forward_storing_masks_equals_plain_forward(hip):
+    """repeated runs, also at a grid of four workgroups per CU (cases.attn_keep_masks_forward_case)"""
+    cases.attn_keep_masks_forward_case(hip, [(2, 4, 300), (3, 2, 200), (8, 16, 512), (64, 16, 512)], 4)
 
 
 @pytest.mark.parametrize("L", [512, 200])
