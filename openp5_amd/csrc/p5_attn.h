@@ -709,6 +709,10 @@ __global__ __launch_bounds__(256) void p5_attn_bwd_dq_kernel(P5AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sbias[1024];
   __shared__ float sdb[4][1024];          // per-wave sums of dS along the diagonals (relative positions)
   __shared__ __attribute__((aligned(16))) float skneg[512];
+  // static LDS: 3 tiles of [64][TS] + 4 KiB bias + 16 KiB diagonal sums + 2 KiB mask = 49.0 KiB in bf16 (3 workgroups per CU), 73.0 KiB
+  // in fp32 (2 per CU; above the 64 KiB of older parts: gfx950 only).  The 16 KiB of sums are sized for L = 512; bf16 calls with L > 128
+  // take the head-resident kernels below (sums in registers), so this kernel's long-sequence caller is the fp32 parity engine.
+  static_assert(3 * 64 * C::TS + 4096 + 16384 + 2048 <= 80 * 1024, "p5_attn_bwd_dq_kernel: two workgroups per CU in fp32");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
