@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 mkdir -p gpurun_out
 {
-timeout 200 python tools/tmp/dbg_keep4.py 2>&1 | grep -v "^W2026\|^E2026\|amdgpu.ids" | tail -6
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -k "storing_masks" 2>&1 | tail -2      # (was tools/tmp/dbg_keep4.py, now tests/cases.py::attn_keep_masks_forward_case)
 timeout 400 python -m pytest tests/test_gpu_parity.py -q -k "head_resident or keep_masks or attention or L512" 2>&1 | tail -4
 for BITS in 1 0; do
   echo "C5 step, P5_ATTN_KEEP_BITS=$BITS"
