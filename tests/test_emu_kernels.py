@@ -219,6 +219,13 @@ def test_model_bf16(emu):
     cases.model_train_case(emu, O.T5Cfg.named("tiny"), 2, 16, 5, "bf16", 0.0, nll_tol=0.08, grad_tol=0.5)
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_model_bf16_long_sequence(emu, dropout):
+    """the whole training step at L = 150 (bf16): the encoder's attention takes the head-resident kernels (forward with stored dropout masks,
+    dQ and dK/dV passes reading them) -- per-token loss and every gradient against the fp32 oracle with the oracle's own dropout masks"""
+    cases.model_train_case(emu, O.T5Cfg.named("tiny"), 2, 150, 5, "bf16", dropout, nll_tol=0.08, grad_tol=0.5)
+
+
 @pytest.mark.parametrize("name", ["tiny_relu", "tiny_gated"])
 def test_golden(emu, name):
     cases.golden_case(emu, name)
