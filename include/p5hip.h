@@ -118,17 +118,31 @@ int p5_backward_final_range(const P5Engine* e, int64_t* begin, int64_t* end);
 int p5_backward_stage_pairs(P5Engine* e, int on);
 /* The staged backward as ONE call: all stages are enqueued on `stream`; ranges[2k], ranges[2k+1] = the k-th gradient range that became final
  * (arena offsets, in completion order), *n_ranges their number (<= max_ranges, <= p5_backward_num_stages).  Behind each one an event is
- * recorded on `stream`: p5_backward_staged_wait(e, k, comm_stream) makes `comm_stream` wait for it (hipStreamWaitEvent, no host wait), after
+ * recorded on `stream` (and, when the engine has a side stream, a second one there: weight gradients of the range may have been launched
+ * on it): p5_backward_staged_wait(e, k, comm_stream) makes `comm_stream` wait for both (hipStreamWaitEvent, no host wait), after
  * which the caller enqueues the exchange of range k there -- DDP's bucketed all-reduce overlapped with the rest of the backward
  * (/root/reference/src/src_t5/main.py:158-160 wraps the model in DDP) without one host round trip per stage. */
 int p5_backward_staged(P5Engine* e, const float* dnll, void* stream, int64_t* ranges, int max_ranges, int* n_ranges);
 int p5_backward_staged_wait(P5Engine* e, int k, void* comm_stream);
+/* The exchange for a host without torch.distributed ("an p5_allreduce_* shim over RCCL taking an ncclComm_t created once per
+ * process"; replaces what DDP's reducer would do at /root/reference/src/src_t5/runner/DistributedRunner.py:26).  `nccl_comm` is the
+ * caller's ncclComm_t; the library has no link-time RCCL dependency and calls the ncclAllReduce already loaded in the process (the one
+ * that created the communicator), else librccl.so.1.
+ *   p5_allreduce_range(e, k, comm, bf16_scratch, comm_stream): waits on `comm_stream` for range k of the last p5_backward_staged (both of
+ *     its events when weight gradients ran on the engine's side stream) and all-reduces (SUM) that slice of the gradient arena in place
+ *     there; bf16_scratch != NULL (room for the range's elements as bf16): cast -> all-reduce in bf16 -> widen back (half the xGMI bytes).
+ *     The mean over ranks is NOT taken here: pass grad_scale = 1 / world to p5_adamw_step.
+ *   p5_allreduce_sum(buf, count, dtype, comm, stream): any device buffer in place; dtype 0 = f32, 1 = bf16, 2 = f64, 3 = i64 (the metric
+ *     sums of DistributedRunner.py:389-395). */
+int p5_allreduce_range(P5Engine* e, int k, void* nccl_comm, void* bf16_scratch, void* comm_stream);
+int p5_allreduce_sum(void* buf, int64_t count, int dtype, void* nccl_comm, void* stream);
 
 /* out_partials: float[1024], fully overwritten; p5_adamw_step sums them in a fixed order (bit-identical on every rank) */
 int p5_grad_sumsq(const float* grads, int64_t n, float* out_partials, void* stream);
 int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n,
-                  const float* sumsq /* float[1024] from p5_grad_sumsq, or NULL = no clipping */, float max_norm, float grad_scale, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step_t, void* stream);
+                  const float* sumsq /* float[1024] from p5_grad_sumsq, or NULL = no clipping */, double max_norm, double grad_scale, double lr, double beta1,
+                  double beta2, double eps, double weight_decay /* doubles, as the reference's Python floats: derived scalars are rounded once */, int step_t,
+                  void* stream);
 
 /* ---- generation ---- */
 /* Optional: a caller-owned buffer of p5_decode_fold_count(e) elements of the compute dtype.  When bound, p5_generate folds every
@@ -174,11 +188,14 @@ int p5_generate_set_forced_prefix(P5Engine* e, const int* tokens, const int* nod
  *                                     -> one teacher-forced fp32 decoder pass over all rows, full-vocabulary log-sum-exp and the trie
  *                                        children's log-probabilities per row, then HF's beam search of the REAL width K replayed on
  *                                        those numbers.  out_* as p5_generate; out_missing int32 [B]: 1 = the replay needed a prefix the
- *                                        draft had dropped -- that user's result is NOT the fp32 search's and the caller must re-run the
- *                                        user through p5_generate on the fp32 engine (openp5_amd/model.py does).
+ *                                        draft had dropped, or a value of the pass left the range of the split products -- that user's
+ *                                        result is NOT the fp32 search's and the caller must re-run the user through p5_generate on the
+ *                                        fp32 engine (openp5_amd/model.py does).
  * A returned, unflagged list is the fp32 search's list: no bf16 number takes part in any decision or score.  The GEMMs of the fp32 passes
- * multiply on the f16 matrix cores from an exact two-term split of every fp32 operand (csrc/p5_gemm.h; option "verify_split" 0 = fp32
- * MFMAs).  Limits: K <= 22, Kw <= 64.  A forced prefix set on the fp32 engine (p5_generate_set_forced_prefix) before p5_verify_begin
+ * multiply on the f16 matrix cores from a two-term fp16 split of every fp32 operand (x = hi + lo / 4096: 22 mantissa bits, the lo x lo
+ * term dropped, ~2^-22 relative per product, valid for |x| < 2^15 -- csrc/p5_gemm.h; option "verify_split" 0 = exact fp32 MFMAs).  A user
+ * any of whose final hidden rows is non-finite or outside that range (an operand of the pass overflowed the split) is flagged through
+ * out_missing exactly like a user with a missing prefix.  Limits: K <= 22, Kw <= 64, rows_per_user <= 512 and <= p5_verify_row_capacity.  A forced prefix set on the fp32 engine (p5_generate_set_forced_prefix) before p5_verify_begin
  * lets the replay skip the forced steps as the draft does. */
 int64_t p5_generate_history_count(int B, int K, int max_len);      /* ints in `hist` for a draft of beam width K */
 int p5_generate_draft(P5Engine* e, const int64_t* input_ids, const int64_t* whole_word_ids, const int64_t* attention_mask,
@@ -194,6 +211,7 @@ const void* p5_verify_encoder_output(const P5Engine* e);     /* device fp32 [B*L
  * engine's dtype) instead of running its encoder */
 int p5_generate_set_encoder_output(P5Engine* e, const float* enc_out_f32);
 int p5_verify_plan(P5Engine* e, const int* hist, void* stream);
+int p5_verify_row_capacity(int Kw, int max_len);           /* rows per user the workspace of a (Kw, max_len) verification holds (a multiple of 16) */
 const int* p5_verify_plan_header(const P5Engine* e);     /* device int[4]: max rows per user, draft steps, total rows, overflow */
 int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len,
                   int* out_missing, void* stream);

@@ -3,7 +3,7 @@ loader so both bind exactly the symbols the header declares)."""
 import ctypes as C
 
 c_i64p = C.POINTER(C.c_int64)
-vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint32
 
 
 class P5Config(C.Structure):
@@ -47,8 +47,10 @@ PROTOTYPES = {
     "p5_backward_stage_pairs": (i32, [vp, i32]),
     "p5_backward_staged": (i32, [vp, vp, vp, C.POINTER(i64), i32, C.POINTER(i32)]),
     "p5_backward_staged_wait": (i32, [vp, i32, vp]),
+    "p5_allreduce_range": (i32, [vp, i32, vp, vp, vp]),
+    "p5_allreduce_sum": (i32, [vp, i64, i32, vp, vp]),
     "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
-    "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, f64, f64, i32, vp]),
     "p5_decode_fold_count": (i64, [vp]),
     "p5_engine_bind_decode_fold": (i32, [vp, vp]),
     "p5_refresh_decode_fold": (i32, [vp, vp]),
@@ -66,6 +68,7 @@ PROTOTYPES = {
     "p5_generate_set_encoder_output": (i32, [vp, vp]),
     "p5_verify_plan": (i32, [vp, vp, vp]),
     "p5_verify_plan_header": (vp, [vp]),
+    "p5_verify_row_capacity": (i32, [i32, i32]),
     "p5_verify_encode": (i32, [vp, vp, vp, vp, vp]),
     "p5_verify_run": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
     "p5_generate_timing": (i32, [vp, i32, C.POINTER(f32), C.POINTER(f32)]),

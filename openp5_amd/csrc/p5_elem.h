@@ -539,8 +539,8 @@ struct P5AdamArgs {
   void* shadow;            // bf16 compute copy or nullptr
   const float* sumsq;      // device float[P5_SUMSQ_PARTS] partial sums of squared grads; nullptr => no clipping
   size_t n;
-  float lr, beta1, beta2, eps, wd, max_norm, grad_scale;
-  float bc1, bc2;          // 1 - beta1^t, 1 - beta2^t
+  float beta1, beta2, omb1, omb2, eps, max_norm, grad_scale;      // omb = 1 - beta, formed in double by the host
+  float step_size, decay;  // lr * sqrt(1 - beta2^t) / (1 - beta1^t);  lr * weight_decay  (doubles rounded once)
 };
 
 __global__ __launch_bounds__(256) void p5_adamw_kernel(P5AdamArgs a) {
@@ -559,16 +559,16 @@ __global__ __launch_bounds__(256) void p5_adamw_kernel(P5AdamArgs a) {
     const float c = a.max_norm / (norm + 1e-6f);
     coef *= (c < 1.f ? c : 1.f);
   }
-  const float step_size = a.lr * sqrtf(a.bc2) / a.bc1;
+  const float step_size = a.step_size;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
     const float g = a.g[i] * coef;
-    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    const float m = a.beta1 * a.m[i] + a.omb1 * g;
+    const float v = a.beta2 * a.v[i] + a.omb2 * g * g;
     a.m[i] = m;
     a.v[i] = v;
     float p = a.p[i];
     p = p - step_size * (m / (sqrtf(v) + a.eps));
-    p = p - a.lr * a.wd * p;
+    p = p - a.decay * p;
     a.p[i] = p;
     if (a.shadow) ((bf16*)a.shadow)[i] = from_f<bf16>(p);
   }

@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#ifndef P5_EMU
+#include <dlfcn.h>
+#endif
 
 #include "p5_host.h"
 #include "p5_elem.h"
@@ -187,13 +190,17 @@ struct P5Engine {
   bool gen_graph_failed = false;
   GraphKey gen_graph_key;
 #endif
+  bool st_side[P5_MAX_STAGED] = {};
+  int64_t st_range[2 * P5_MAX_STAGED] = {};
   int st_n = 0;                   // p5_backward_staged: final ranges of the last call (events st_ev[0 .. st_n))
 #ifndef P5_EMU
   hipEvent_t st_ev[P5_MAX_STAGED] = {};
+  hipEvent_t st_ev_side[P5_MAX_STAGED] = {};      // the same point of the engine's side stream (weight gradients of the range may run there)
 #endif
   // optional second stream for the weight-gradient GEMMs (off the critical dgrad chain)
   hipStream_t side = nullptr;
 #ifndef P5_EMU
+  bool side_events = false;               // the events below exist (created with the first side stream, destroyed with the engine)
   hipEvent_t ev_pool[32];
   hipEvent_t set_ev[P5_NSETS];            // recorded behind the last weight-gradient launch that reads set p
   hipEvent_t head_wg_ev;                  // ... behind the tied head's weight gradient (plain "+=" into shared.weight's gradient)
@@ -1770,6 +1777,8 @@ static int verify_run_impl(P5Engine* e, int PU, const uint32_t* excluded, int* o
   hipMemsetAsync(w.vrow_a, 0, (size_t)R * 4, s);        // every beam starts on row 0 (the start prefix)
   hipMemsetAsync(w.vrow_b, 0, (size_t)R * 4, s);
   hipMemsetAsync(w.missing, 0, (size_t)B * 4, s);
+  P5_LAUNCH((p5_verify_range_kernel<T>), dim3(B), dim3(256), 0, s, w.missing, (const T*)w.hn, PU, d);      // (ordered behind the clear on this stream)
+  P5_TRY(P5_KCHECK());
   int first = 1;
   if (v.ff.n > 0) {
     // the forced steps of the replay (p5_decode.h): rows 0 .. F-1 are the forced chain (one live prefix per depth), each with ONE child
@@ -1933,7 +1942,7 @@ int p5_set_option(const char* name, int value) {
   else return fail("p5_set_option: unknown option");
   return 0;
 }
-int p5_abi_version(void) { return 3; }    // 2: p5_op_attn_bwd gained d_rel_scratch / rel_buckets (round 4); 3: p5_generate_verified, p5_backward_staged (round 5)
+int p5_abi_version(void) { return 4; }    // 2: p5_op_attn_bwd gained d_rel_scratch / rel_buckets (round 4); 3: p5_generate_verified, p5_backward_staged (round 5); 4: p5_allreduce_range / _sum, p5_verify_row_capacity, range flag in p5_verify_run (round 6)
 // ---- in-run kernel profiler (p5_device.h P5Prof) ----
 int p5_profile_begin(void) {
 #ifndef P5_EMU
@@ -2007,7 +2016,27 @@ int p5_engine_create(const P5Config* cfg, P5Engine** out) {
   *out = e;
   return 0;
 }
-int p5_engine_destroy(P5Engine* e) { if (e) delete e->ver; delete e; return 0; }
+int p5_engine_destroy(P5Engine* e) {
+  if (!e) return 0;
+#ifndef P5_EMU
+  for (int i = 0; i < P5_MAX_STAGED; ++i) {
+    if (e->st_ev[i]) hipEventDestroy(e->st_ev[i]);
+    if (e->st_ev_side[i]) hipEventDestroy(e->st_ev_side[i]);
+  }
+  if (e->zg_ev) hipEventDestroy(e->zg_ev);
+  if (e->tr_ev) hipEventDestroy(e->tr_ev);
+  for (int i = 0; i < 3; ++i) if (e->gen_ev[i]) hipEventDestroy(e->gen_ev[i]);
+  if (e->side_events) {
+    for (int i = 0; i < 32; ++i) hipEventDestroy(e->ev_pool[i]);
+    for (int i = 0; i < P5_NSETS; ++i) hipEventDestroy(e->set_ev[i]);
+    hipEventDestroy(e->head_wg_ev);
+    for (int i = 0; i < 64; ++i) hipEventDestroy(e->kv_ev[i]);
+  }
+#endif
+  delete e->ver;
+  delete e;
+  return 0;
+}
 int64_t p5_param_count(const P5Engine* e) { return e->n_params; }
 int p5_param_table(const P5Engine* e, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols) {
   if (idx < 0 || idx >= (int)e->table.size()) return 1;
@@ -2180,8 +2209,14 @@ int p5_backward_staged(P5Engine* e, const float* dnll, void* stream, int64_t* ra
 #ifndef P5_EMU
       if (!e->st_ev[n]) P5_REQUIRE(hipEventCreateWithFlags(&e->st_ev[n], hipEventDisableTiming) == hipSuccess, "hipEventCreate");
       P5_REQUIRE(hipEventRecord(e->st_ev[n], (hipStream_t)stream) == hipSuccess, "hipEventRecord");
+      if (e->side) {      // weight gradients of this range may have been launched on the side stream: the range is final behind BOTH events
+        if (!e->st_ev_side[n]) P5_REQUIRE(hipEventCreateWithFlags(&e->st_ev_side[n], hipEventDisableTiming) == hipSuccess, "hipEventCreate");
+        P5_REQUIRE(hipEventRecord(e->st_ev_side[n], e->side) == hipSuccess, "hipEventRecord");
+      }
+      e->st_side[n] = e->side != nullptr;
 #endif
       ranges[2 * n] = e->rep_b; ranges[2 * n + 1] = e->rep_e;
+      e->st_range[2 * n] = e->rep_b; e->st_range[2 * n + 1] = e->rep_e;
       ++n;
     }
   }
@@ -2193,10 +2228,68 @@ int p5_backward_staged_wait(P5Engine* e, int k, void* comm_stream) {
   P5_REQUIRE(k >= 0 && k < e->st_n, "p5_backward_staged_wait: range index");
 #ifndef P5_EMU
   P5_REQUIRE(hipStreamWaitEvent((hipStream_t)comm_stream, e->st_ev[k], 0) == hipSuccess, "hipStreamWaitEvent");
+  if (e->st_side[k] && (hipStream_t)comm_stream != e->side)
+    P5_REQUIRE(hipStreamWaitEvent((hipStream_t)comm_stream, e->st_ev_side[k], 0) == hipSuccess, "hipStreamWaitEvent");
 #else
   (void)comm_stream;
 #endif
   return 0;
+}
+// ---- the exchange itself for a caller without torch.distributed: RCCL through the ncclComm_t the caller created ----------------------
+// No link-time dependency on a particular librccl: the symbols are taken from whatever RCCL the process has loaded (the one that made the
+// communicator -- torch ships its own copy next to its HIP runtime, a C host links /opt/rocm/lib/librccl.so), else from librccl.so.1.
+#ifndef P5_EMU
+typedef int (*p5_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*p5_nccl_errstr_fn)(int);
+static p5_nccl_allreduce_fn g_nccl_allreduce = nullptr;
+static p5_nccl_errstr_fn g_nccl_errstr = nullptr;
+static int nccl_resolve() {
+  if (g_nccl_allreduce) return 0;
+  void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+  void* h = nullptr;
+  if (!sym) {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) sym = dlsym(h, "ncclAllReduce");
+  }
+  if (!sym) return fail("p5_allreduce: no RCCL in this process (ncclAllReduce not found; load librccl before creating the communicator)");
+  g_nccl_errstr = (p5_nccl_errstr_fn)(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+  g_nccl_allreduce = (p5_nccl_allreduce_fn)sym;
+  return 0;
+}
+#endif
+// rccl.h: ncclFloat32 = 7, ncclFloat64 = 8, ncclBfloat16 = 9, ncclInt64 = 4; ncclSum = 0
+int p5_allreduce_sum(void* buf, int64_t count, int dtype, void* nccl_comm, void* stream) {
+  P5_REQUIRE(buf && nccl_comm && count >= 0 && dtype >= 0 && dtype <= 3, "p5_allreduce_sum: arguments");
+#ifndef P5_EMU
+  P5_TRY(nccl_resolve());
+  static const int kType[4] = {7, 9, 8, 4};
+  const int rc = g_nccl_allreduce(buf, buf, (size_t)count, kType[dtype], 0, nccl_comm, (hipStream_t)stream);
+  if (rc != 0) return fail(std::string("ncclAllReduce: ") + (g_nccl_errstr ? g_nccl_errstr(rc) : "error ") + " (" + std::to_string(rc) + ")");
+  return 0;
+#else
+  (void)stream;
+  return fail("p5_allreduce_sum: the host emulation has no RCCL");
+#endif
+}
+// bf16 -> fp32 of an exchanged bucket
+__global__ __launch_bounds__(256) void p5_widen_kernel(float* __restrict__ out, const bf16* __restrict__ in, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = to_f<bf16>(in[i]);
+}
+int p5_allreduce_range(P5Engine* e, int k, void* nccl_comm, void* bf16_scratch, void* comm_stream) {
+  P5_REQUIRE(k >= 0 && k < e->st_n, "p5_allreduce_range: range index (call p5_backward_staged first)");
+  P5_REQUIRE(e->G != nullptr, "p5_allreduce_range: no gradient arena bound");
+  P5_TRY(p5_backward_staged_wait(e, k, comm_stream));
+  const int64_t b = e->st_range[2 * k], n = e->st_range[2 * k + 1] - b;
+  if (n <= 0) return 0;
+  hipStream_t cs = (hipStream_t)comm_stream;
+  if (!bf16_scratch) return p5_allreduce_sum(e->G + b, n, 0, nccl_comm, comm_stream);
+  const unsigned blocks = (unsigned)((n / 8 + 255) / 256 > 4096 ? 4096 : (n / 8 + 255) / 256 + 1);
+  P5_LAUNCH((p5_cast_kernel<bf16>), dim3(blocks), dim3(256), 0, cs, (bf16*)bf16_scratch, (const float*)(e->G + b), (size_t)n);
+  P5_TRY(P5_KCHECK());
+  P5_TRY(p5_allreduce_sum(bf16_scratch, n, 1, nccl_comm, comm_stream));
+  P5_LAUNCH(p5_widen_kernel, dim3(blocks), dim3(256), 0, cs, e->G + b, (const bf16*)bf16_scratch, (size_t)n);
+  return P5_KCHECK();
 }
 int p5_backward_stage_pairs(P5Engine* e, int on) { e->stage_pairs = on != 0; return 0; }
 int p5_engine_grads_zeroed(P5Engine* e) { e->grads_keep = true; return 0; }
@@ -2226,7 +2319,8 @@ int p5_engine_clear_grads(P5Engine* e, void* stream) {
 }
 int p5_engine_set_side_stream(P5Engine* e, void* side_stream) {
 #ifndef P5_EMU
-  if (side_stream && !e->side) {
+  if (side_stream && !e->side_events) {
+    e->side_events = true;
     for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming);
     for (int i = 0; i < P5_NSETS; ++i) hipEventCreateWithFlags(&e->set_ev[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&e->head_wg_ev, hipEventDisableTiming);
@@ -2261,13 +2355,18 @@ int p5_grad_sumsq(const float* grads, int64_t n, float* out_scalar, void* stream
   P5_LAUNCH(p5_sumsq_kernel, dim3(P5_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, out_scalar, grads, (size_t)n);
   return P5_KCHECK();
 }
-int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq, float max_norm,
-                  float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step_t, void* stream) {
+int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq, double max_norm,
+                  double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay, int step_t, void* stream) {
+  // Hyper-parameters arrive as the doubles the reference holds them in (Python floats) and every derived scalar is formed in double and
+  // rounded ONCE to fp32 -- as torch does with the Python scalars of transformers' AdamW.step (`alpha=1.0 - beta1`, `value=1.0 - beta2`,
+  // `value=-step_size`, `alpha=-lr * weight_decay`): 1.f - 0.999f is 1.3e-5 off 0.001, which tests/golden/adamw_426.json sees in `v`.
   P5AdamArgs a;
   a.p = params; a.g = grads; a.m = m; a.v = v; a.shadow = shadow_bf16; a.sumsq = sumsq; a.n = (size_t)n;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm; a.grad_scale = grad_scale;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step_t));
-  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step_t));
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps; a.max_norm = (float)max_norm; a.grad_scale = (float)grad_scale;
+  const double bc1 = 1.0 - pow(beta1, (double)step_t), bc2 = 1.0 - pow(beta2, (double)step_t);
+  a.step_size = (float)(lr * sqrt(bc2) / bc1);
+  a.decay = (float)(lr * weight_decay);
   P5_LAUNCH(p5_adamw_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a);
   return P5_KCHECK();
 }
@@ -2376,6 +2475,7 @@ int p5_verify_plan(P5Engine* e, const int* hist, void* stream) {
   P5_REQUIRE(hist, "p5_verify_plan: history of the draft search");
   return verify_plan_impl(e, hist, (hipStream_t)stream);
 }
+int p5_verify_row_capacity(int Kw, int max_len) { return verify_cap(Kw, max_len); }
 const int* p5_verify_plan_header(const P5Engine* e) { return (e->ver && e->ver->begun) ? e->ver->w.pl.hdr : nullptr; }
 int p5_verify_run(P5Engine* e, int rows_per_user, const uint32_t* excluded_nodes, int* out_seq, float* out_score, int* out_len, int* out_missing,
                   void* stream) {

@@ -224,6 +224,20 @@ __global__ __launch_bounds__(256) void p5_verify_forced_kernel(float* __restrict
   if (j >= 0 && j < B * Kb) { vrow_a[j] = F; vrow_b[j] = F; }
 }
 
+// Range guard of the split-product passes (p5_gemm.h::p5_gemm_split_kernel): an fp32 operand x is multiplied as fp16 hi + lo / 4096, which
+// covers |x| < 2^15 (beyond it lo = fp16((x - hi) * 4096) overflows; beyond 65504 hi does).  An operand out of range turns into inf / NaN
+// and reaches the final normalised hidden rows through the residual stream, so ONE look at those rows per user decides: a user with a
+// non-finite or out-of-range value there is flagged like a user with a missing prefix and the caller re-runs that user on the exact-fp32
+// search (p5hip.h, p5_verify_run).  T5's ReLU / gated-GELU hidden units are where such magnitudes are known to occur (bf16 / fp16 T5).
+template <class T>
+__global__ __launch_bounds__(256) void p5_verify_range_kernel(int* __restrict__ missing, const T* __restrict__ hn, int PU, int d) {
+  const int b = blockIdx.x;
+  const T* __restrict__ p = hn + (size_t)b * PU * d;
+  bool bad = false;
+  for (int i = threadIdx.x; i < PU * d; i += 256) bad |= !(fabsf(to_f<T>(p[i])) < 32768.f);
+  if (bad) missing[b] = 1;        // (every writer stores the same value)
+}
+
 #define P5_VERIFY_POOL 1024          // Kb x 2 Kb candidates of the replay: real beam widths up to 22 (the DRAFT may be as wide as P5_MAX_K)
 __global__ __launch_bounds__(256) void p5_verify_step_kernel(P5BeamState st, P5VerifyPlan pl, const float* __restrict__ row_top_score,
                                                             const int* __restrict__ row_top_c, const int* __restrict__ row_n_top, int PU,

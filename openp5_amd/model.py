@@ -18,6 +18,7 @@ contiguous buckets issued while the backward is still running.
 from __future__ import annotations
 
 import contextlib
+import warnings
 import os
 import ctypes
 import threading
@@ -144,6 +145,8 @@ class P5T5Native(nn.Module):
     # always runs the plain (fp32) search.
     generation_mode = "verified"
     verify_extra_beams = 6
+    VERIFY_MAX_K = 22             # the replay's candidate pool (K x 2K <= 1024 entries of LDS, csrc/p5_verify.h)
+    VERIFY_MAX_ROWS = 512         # rows per user of the fp32 pass = queries per (user, head) of its cross-attention launch
     verify_escalation = (22,)     # extra beams of the wider draft a FLAGGED user gets before the plain fp32 search is the last resort
     verify_share_encoder = True   # verified mode: the draft starts from the verification pass's fp32 encoder output (one encoder pass per batch)
     gen_lanes = 3                 # batches in flight in `map_lanes` (the runner's evaluation loops, bench.py): lanes overlap each other's latency-bound chains
@@ -182,7 +185,10 @@ class P5T5Native(nn.Module):
         self._lanes = []            # generation lanes (lane 0 = this model's engine on the caller's stream)
         self._tls = threading.local()
         self._stats_lock = threading.Lock()
-        self.verify_stats = {"calls": 0, "users": 0, "escalated_users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0}
+        self.verify_stats = {"calls": 0, "users": 0, "escalated_users": 0, "fallback_users": 0, "rows": 0, "rows_per_user_max": 0, "draft_beams": 0,
+                             "wide_fp32_users": 0}
+        self.last_generate_path = None      # "verified" | "fp32_search" | "draft_bf16": which search the most recent generate() call ran
+        self._warned_wide_verified = False
         self._shadow_t = None       # transposed bf16 copy of the layer weights (data gradients run on the forward GEMM kernel)
         self._grads_dead = False    # zero_grad(set_to_none=True) was called and no backward has run since: `.grad` holds stale values
         self._tr_dirty = True
@@ -782,10 +788,24 @@ class P5T5Native(nn.Module):
         if mode not in ("verified", "draft"):
             raise ValueError(f"generation_mode={mode!r} (verified | draft)")
         args = (input_ids, whole_word_ids, attention_mask, B, L, K, max_length, off, tok, nxt, roots_t, excl_t, excl_words, maxc)
-        if self.compute_dtype == 1 and mode == "verified" and 2 * K * K <= 1024:
+        if self.compute_dtype == 1 and mode == "verified" and K <= self.VERIFY_MAX_K:
             seq, score, ln = self._generate_verified(*args)
+            path = "verified"
+        elif self.compute_dtype == 1 and mode == "verified":
+            # the replay's candidate pool (K x 2K entries in LDS, csrc/p5_verify.h P5_VERIFY_POOL) ends at K = 22: wider searches run as the
+            # plain fp32 search on the verification engine -- still the fp32 search's lists, at its speed -- and say so
+            if not self._warned_wide_verified:
+                warnings.warn(f"generate(num_beams={K}): verified generation covers num_beams <= {self.VERIFY_MAX_K}; running the plain fp32 beam search "
+                              f"instead (same ranked lists, slower).  generation_mode='draft' selects the plain bf16 search.", RuntimeWarning, stacklevel=2)
+                self._warned_wide_verified = True
+            seq, score, ln = self._search_fp32(*args)
+            with self._stats_lock:
+                self.verify_stats["wide_fp32_users"] += B
+            path = "fp32_search"
         else:
             seq, score, ln = self._search(lane.engine, "gen", *args)
+            path = "draft_bf16" if self.compute_dtype == 1 else "fp32_search"
+        self.last_generate_path = path
         out_len = 1 + int(ln[:, :nret].max().item())
         sequences = seq[:, :nret, :out_len].reshape(B * nret, out_len).to(torch.int64)
         scores = score[:, :nret].reshape(B * nret)
@@ -850,7 +870,10 @@ class P5T5Native(nn.Module):
         self._be.check(lib.p5_verify_encode(ev, _ptr(input_ids), _ptr(whole_word_ids), _ptr(attention_mask), sp), "p5_verify_encode")
         if self.verify_share_encoder:
             self._be.check(lib.p5_generate_set_encoder_output(lane.engine, ctypes.c_void_p(lib.p5_verify_encoder_output(ev))), "p5_generate_set_encoder_output")
-        hist = torch.zeros(int(lib.p5_generate_history_count(B, Kw, max_length)), dtype=torch.int32, device=dev)
+        # (carved out of the lane's workspace: its address is part of the decode-step graph's key, a fresh tensor per call would re-capture it)
+        nh = int(lib.p5_generate_history_count(B, Kw, max_length))
+        hist = self._lane_workspace(lane, nh * 4, "hist")[:nh * 4].view(torch.int32)
+        hist.zero_()
         self._search(lane.engine, "gen", *common, Kw, max_length, *trie_args, hist=hist)
         self._be.check(lib.p5_verify_plan(ev, _ptr(hist), sp), "p5_verify_plan")
         hdr_off = int(lib.p5_verify_plan_header(ev)) - ws.data_ptr()
@@ -865,13 +888,20 @@ class P5T5Native(nn.Module):
             hdr = hdr_dev.cpu().tolist()
         if hdr[3]:
             raise RuntimeError("p5_verify_plan: row capacity exceeded")
-        PU = max(1, int(hdr[0]))          # rows per user of the fp32 pass: the largest row count of the batch (a padding row costs a decoder row)
+        cap = int(lib.p5_verify_row_capacity(Kw, max_length))
+        PU = min(cap, (max(1, int(hdr[0])) + 15) // 16 * 16)      # rows per user of the fp32 pass: the largest row count of the batch, in whole 16-row tiles
+        st = self.verify_stats
+        if PU > self.VERIFY_MAX_ROWS:
+            # the users' rows are the queries of ONE cross-attention launch per layer (<= 512 queries per user): a deep, wide draft beyond that
+            # goes to the plain fp32 search as a whole
+            with self._stats_lock:
+                st["calls"] += 1; st["users"] += B if level == 0 else 0; st["fallback_users"] += B
+            return self._search_fp32(input_ids, whole_word_ids, attention_mask, B, L, K, max_length, *trie_args)
         seq = torch.zeros(B, K, max_length, dtype=torch.int32, device=dev)
         score = torch.zeros(B, K, dtype=torch.float32, device=dev)
         ln = torch.zeros(B, K, dtype=torch.int32, device=dev)
         missing = torch.zeros(B, dtype=torch.int32, device=dev)
         self._be.check(lib.p5_verify_run(ev, PU, _ptr(excl_t), _ptr(seq), _ptr(score), _ptr(ln), _ptr(missing), sp), "p5_verify_run")
-        st = self.verify_stats
         with self._stats_lock:
             st["calls"] += 1; st["users"] += B if level == 0 else 0; st["rows"] += int(hdr[2]); st["rows_per_user_max"] = max(st["rows_per_user_max"], int(hdr[0]))
             if level == 0:
@@ -883,23 +913,35 @@ class P5T5Native(nn.Module):
             sub_args = (sub(input_ids), sub(whole_word_ids), sub(attention_mask), nb, L, K, max_length, off, tok, nxt, sub(roots_t), sub(excl_t), excl_words, maxc)
             if level + 1 < len(extra) and K + extra[level + 1] > Kw:
                 # a flagged user first gets a WIDER draft (cheap: a sub-batch, ~2 ms) -- only what that cannot settle goes to the fp32 search
-                st["escalated_users"] += nb
+                with self._stats_lock:
+                    st["escalated_users"] += nb
                 s2, sc2, l2 = self._generate_verified(*sub_args, level=level + 1)
             else:
-                # the fp32 search itself for these users (a prefix the fp32 search ranks among its K was not among the draft's Kw)
-                st["fallback_users"] += nb
-                if self.fuse_decode_norms:
-                    if lane.fold_v is None:
-                        n = int(lib.p5_decode_fold_count(ev))
-                        lane.fold_v = torch.empty(n, dtype=torch.float32, device=dev)
-                        self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(lane.fold_v)), "p5_engine_bind_decode_fold (verify)")
-                        lane.fold_v_dirty = True
-                    if lane.fold_v_dirty:
-                        self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
-                        lane.fold_v_dirty = False
-                s2, sc2, l2 = self._search(ev, "gen_v", *sub_args)
+                # the fp32 search itself for these users (a prefix the fp32 search ranks among its K was not among the draft's Kw, or a
+                # row of the split-product pass left the range the two-term fp16 split covers)
+                with self._stats_lock:
+                    st["fallback_users"] += nb
+                s2, sc2, l2 = self._search_fp32(*sub_args)
             seq[miss] = s2; score[miss] = sc2; ln[miss] = l2
         return seq, score, ln
+
+    def _search_fp32(self, *args):
+        """The plain fp32 beam search on this lane's verification engine (exact fp32 MFMAs over the master arena): the last resort of the
+        verified mode and what a verified call wider than VERIFY_MAX_K beams runs."""
+        lib, dev, sp = self._lib, self._be.device, self._be.stream_ptr()
+        lane = self._cur_lane()
+        ev = self._verify_engine(lane)
+        ftok, fnode = lane.forced
+        if self.fuse_decode_norms:
+            if lane.fold_v is None:
+                n = int(lib.p5_decode_fold_count(ev))
+                lane.fold_v = torch.empty(n, dtype=torch.float32, device=dev)
+                self._be.check(lib.p5_engine_bind_decode_fold(ev, _ptr(lane.fold_v)), "p5_engine_bind_decode_fold (verify)")
+                lane.fold_v_dirty = True
+            if lane.fold_v_dirty:
+                self._be.check(lib.p5_refresh_decode_fold(ev, sp), "p5_refresh_decode_fold (verify)")
+                lane.fold_v_dirty = False
+        return self._search(ev, "gen_v", *args)
 
     def time_generate(self, enable: bool = True):
         """Benchmark aid: arm (or disarm) the engine's device-time brackets around the next `generate` calls (two event records per

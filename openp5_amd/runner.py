@@ -47,7 +47,8 @@ def parse_runner_args(parser):
     parser.add_argument("--valid_select", type=int, default=0, help="use validation loss to select models")
     parser.add_argument("--test_before_train", type=int, default=1, help="whether test before training")
     parser.add_argument("--test_filtered", type=int, default=0, help="whether filter out the items in the training data.")
-    parser.add_argument("--test_filtered_batch", type=int, default=1, help="whether testing with filtered data in batch.")
+    parser.add_argument("--test_filtered_batch", type=int, default=1, help="whether testing with filtered data in batch (1 = the reference's widened beam, "
+                        "up to 64 beams; 2 = history excluded inside the search, any history length; 0 = per-user protocol).")
     parser.add_argument("--gen_lanes", type=int, default=3, help="evaluation batches in flight (P5T5Native.map_lanes): each lane has its own search / "
                         "verification engines, workspaces and HIP stream over the one set of weights, so one batch's latency-bound beam search overlaps "
                         "the next one's; 1 = one batch at a time")
@@ -537,15 +538,18 @@ class DistributedRunner:
         trie, ct, index = self._dataset_trie(ds)
         fn = prefix_allowed_tokens_fn(trie)
         width = self.generate_num + ds.max_positive
-        if width > MAX_DEVICE_BEAMS:
-            # the reference's DEFAULT flag (SingleRunner.py:39) must keep working on real histories (ML-1M: hundreds of items):
-            # instead of a beam of generate_num + max_history, exclude each user's history INSIDE the constrained search
-            # (shared device trie + per-user excluded-node bitmap) -- history never appears, the top generate_num are kept
-            if self.rank == 0:
-                logging.warning(f"--test_filtered_batch 1 would need num_beams = {self.generate_num} + max history {ds.max_positive} = "
-                                f"{width} > {MAX_DEVICE_BEAMS} (device beam limit); excluding each user's history inside the search instead "
-                                "(the --test_filtered_batch 0 protocol, batched)")
+        if self.test_filtered_batch >= 2:
+            # OPT-IN (--test_filtered_batch 2): exclude each user's history INSIDE the constrained search (shared device trie + per-user
+            # excluded-node bitmap, batched) instead of widening the beam -- history never appears, the top generate_num are kept.  This is
+            # the --test_filtered_batch 0 protocol's result, not the widened-beam protocol's: a beam of generate_num + max_history can
+            # keep items an excluded search prunes, so the two may differ.
             return self.test_dataset_task_filtered(testloader)
+        if width > MAX_DEVICE_BEAMS:
+            # the literal protocol of the reference's DEFAULT flag (SingleRunner.py:39, DistributedRunner.py:235-236) needs
+            # num_beams = generate_num + max history; never silently substitute another protocol for it
+            raise ValueError(f"--test_filtered_batch 1 needs num_beams = {self.generate_num} + max history {ds.max_positive} = {width} > "
+                             f"{MAX_DEVICE_BEAMS} (device beam limit).  Use --test_filtered_batch 2 (history excluded inside the search, batched: "
+                             "the results of --test_filtered_batch 0) or --test_filtered_batch 0 (the released test protocol).")
         seq2idx = None
         if self.id_metrics:     # item token tuple (without the decoder start) -> item index: no batch_decode, no string sets
             seq2idx = self.__dict__.setdefault("_seq2idx_cache", {}).get(ds.dataset)

@@ -2,6 +2,7 @@
 Every case drives the C ABI of include/p5hip.h and checks against plain torch math or the oracle / golden fixtures."""
 import ctypes
 import os
+import math
 import random
 
 import torch
@@ -763,6 +764,84 @@ def generate_excluded_case(be, ocfg, B, L, K, max_len, n_items, dtype="fp32", se
     return out
 
 
+def generate_verified_collab_case(be, K, n_layers=2, B=3, L=40, n_items=400, with_excluded=True, seed=3, score_tol=2e-4, ocfg=None, tok_range=(32100, 32599)):
+    """BASELINE.json configs[3] in the mode bench.py's `c4_t5base_beam20_b20` leg times: bf16 T5-base dims, vocabulary grown by 500 <CIk>
+    tokens (collaborative indexing, main.py:190-193 -> V = 32600), item ids drawn from the added-token range, beam K, `generate()` in its
+    default VERIFIED mode (bf16 search with extra beams proposes, one fp32 pass decides, csrc/p5_verify.h) -- token-exact ranked lists and
+    scores within `score_tol` of the fp32 oracle's beam search (DistributedRunner.py:361-374), with and without per-user history
+    exclusion (DistributedRunner.py:286-297).  K = 22 is the widest verified search; K = 23 must run the plain fp32 search, say so
+    (RuntimeWarning, `last_generate_path`) and still return the oracle's lists."""
+    import warnings
+    from openp5_amd.trie import CompiledTrie
+    if ocfg is None:
+        ocfg = O.T5Cfg.named("t5-base", num_layers=n_layers, num_decoder_layers=n_layers, vocab_size=32600)
+    rnd = random.Random(seed)
+    items = set()
+    while len(items) < n_items:
+        items.add(tuple([0, 5] + [rnd.randint(*tok_range) for _ in range(rnd.randint(2, 4))] + [1]))
+    items = sorted(list(x) for x in items)
+    params = O.init_params(ocfg, 7)
+    m = build_model(be, ocfg, params, "bf16")
+    m.eval()
+    assert m.generation_mode == "verified"
+    ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, 5)
+    ct = CompiledTrie.from_sequences(items)
+    ct.index_items(items)
+    out = {}
+    variants = [("plain", None)]
+    if with_excluded:
+        excluded = [sorted(rnd.sample(range(n_items), int(0.5 * n_items) if b else 0)) for b in range(B)]      # user 0: no history
+        variants.append(("excluded", excluded))
+    for name, excluded in variants:
+        kw = {} if excluded is None else {"excluded": ct.excluded_bitmap(excluded)}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=30, trie=ct, num_beams=K, num_return_sequences=K,
+                             output_scores=True, return_dict_in_generate=True, **kw)
+        wide = [w for w in caught if issubclass(w.category, RuntimeWarning) and "verified generation covers" in str(w.message)]
+        if K <= m.VERIFY_MAX_K:
+            assert m.last_generate_path == "verified" and not wide, (m.last_generate_path, [str(w.message) for w in caught])
+        else:
+            assert m.last_generate_path == "fp32_search", m.last_generate_path
+            assert wide or m._warned_wide_verified, "a verified call wider than VERIFY_MAX_K must say that it ran the fp32 search"
+        if excluded is None:
+            tries = [Trie(items)] * B
+        else:
+            tries = [Trie([it for i, it in enumerate(items) if i not in set(ex)]) for ex in excluded]
+        with torch.no_grad():
+            s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: tries[b].get(s.tolist()), K, 30)
+        compare_generation(got["sequences"].cpu(), got["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
+        out[name] = {"path": m.last_generate_path, "score_err": float((got["sequences_scores"].cpu() - sc_ref).abs().max())}
+    out["verify_stats"] = dict(m.verify_stats)
+    return out
+
+
+def generate_verified_overflow_case(be, ocfg, B=3, L=20, K=5, max_len=12, n_items=40, scale=3.0e5, seed=5, score_tol=5e-5):
+    """An FFN hidden layer far outside the range of the two-term fp16 split (|x| >= 2^15, csrc/p5_gemm.h): wi scaled up and wo down by
+    the same factor leaves the function the same, the fp32 oracle does not care -- the verification pass must flag every user (range
+    guard, csrc/p5_verify.h::p5_verify_range_kernel) and the host re-runs them on the exact-fp32 search: lists still the oracle's."""
+    params = O.init_params(ocfg, 7)
+    for k in list(params):
+        if "DenseReluDense.wi" in k and ".decoder." in "." + k:
+            params[k] = params[k] * scale
+        if "DenseReluDense.wo" in k and ".decoder." in "." + k:
+            params[k] = params[k] / scale
+    m = build_model(be, ocfg, params, "bf16")
+    m.eval()
+    m.verify_escalation = ()          # (a wider draft cannot help an overflowing pass: go straight to the fp32 search)
+    ids, ww, mask, _, _ = synth_batch(ocfg, B, L, 4, seed)
+    items = make_items(n_items, seed, hi=min(60, ocfg.vocab_size - 1))
+    trie = Trie(items)
+    got = m.generate(input_ids=ids, attention_mask=mask, whole_word_ids=ww, max_length=max_len, prefix_allowed_tokens_fn=prefix_allowed_tokens_fn(trie),
+                     num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True)
+    with torch.no_grad():
+        s_ref, sc_ref = O.beam_search(params, ocfg, ids, ww, mask, lambda b, s: trie.get(s.tolist()), K, max_len)
+    compare_generation(got["sequences"].cpu(), got["sequences_scores"].cpu(), s_ref, sc_ref, score_tol)
+    st = dict(m.verify_stats)
+    assert st["fallback_users"] == B, st
+    return st
+
+
 def train_trajectory_case(be, ocfg, B, L, T, steps=3, dtype="fp32", lr=1e-2, tol=2e-4):
     """N fused steps (forward + backward + clip + HF-AdamW + linear warmup) against the oracle's restatement of the
     reference step (DistributedRunner.py:63-87, SingleRunner.py:178-219): parameter trajectories must coincide."""
@@ -796,6 +875,37 @@ def train_trajectory_case(be, ocfg, B, L, T, steps=3, dtype="fp32", lr=1e-2, tol
         if err > worst[0]:
             worst = (err, name)
     assert worst[0] <= tol, f"parameter trajectory diverged: {worst}"
+    return worst
+
+
+def adamw_golden_case(be, tol=2e-6):
+    """p5_grad_sumsq + p5_adamw_step (clip + HF-AdamW in one pass over a flat arena; DistributedRunner.py:81,85-86, SingleRunner.py:191-217)
+    held to tests/golden/adamw_426.json -- the published transformers-4.26 AdamW.step / torch-1.8.1 clip_grad_norm_ / linear-warmup
+    arithmetic run in fp64 Python (tests/golden/make_adamw_426.py).  fp32 kernel vs fp64 fixture: `tol` relative to each tensor's scale."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adamw_426.json")))
+    h, names = gold["hyper"], list(gold["shapes"])
+    flat = lambda d: torch.tensor([x for k in names for x in d[k]], dtype=torch.float64)     # noqa: E731
+    p = dev(be, flat(gold["p0"]).float())
+    n = p.numel()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sumsq = dev(be, torch.zeros(1024))
+    shadow = dev(be, torch.zeros(n, dtype=torch.bfloat16))
+    worst = 0.0
+    for t, st in enumerate(gold["steps"], start=1):
+        g = dev(be, flat(st["grad"]).float())
+        be.check(be.lib.p5_grad_sumsq(P(g), n, P(sumsq), be.stream_ptr()), "p5_grad_sumsq")
+        be.check(be.lib.p5_adamw_step(P(p), P(g), P(m), P(v), P(shadow), n, P(sumsq), h["max_norm"], 1.0, st["lr"], h["beta1"], h["beta2"], h["eps"],
+                                      h["weight_decay"], t, be.stream_ptr()), "p5_adamw_step")
+        sync(be)
+        assert abs(math.sqrt(float(sumsq.double().sum())) - st["total_norm"]) <= 1e-5 * st["total_norm"]
+        for name, got in (("p", p), ("m", m), ("v", v)):
+            ref = flat(st[name])
+            err = float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
+            worst = max(worst, err)
+            assert err <= tol, (t, name, err)
+        assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16)), "the bf16 compute shadow is the updated master value rounded once"
     return worst
 
 

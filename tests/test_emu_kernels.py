@@ -318,6 +318,22 @@ def test_generate_verified_fallback(emu):
     assert out["verify_stats"]["fallback_users"] >= 1, out["verify_stats"]
 
 
+@pytest.mark.parametrize("K", [22, 23])
+def test_generate_verified_widest_and_beyond(emu, K):
+    """K = 22 is the widest search the verified mode replays; K = 23 runs the plain fp32 search and says so (tests/cases.py)."""
+    out = cases.generate_verified_collab_case(emu, K, B=2, L=14, n_items=120, ocfg=O.T5Cfg.named("tiny"), tok_range=(7, 60), score_tol=5e-5)
+    assert out["plain"]["path"] == ("verified" if K <= 22 else "fp32_search"), out
+
+
+def test_generate_verified_split_range_guard(emu):
+    """operands outside the two-term fp16 split's range are flagged and the users re-run on exact fp32 (p5_verify_range_kernel)."""
+    cases.generate_verified_overflow_case(emu, O.T5Cfg.named("tiny"))
+
+
+def test_adamw_kernel_matches_published_426_fixture(emu):
+    print("[adamw golden] worst relative error", cases.adamw_golden_case(emu))
+
+
 def test_generate_draft_mode_is_the_plain_bf16_search(emu):
     cases.generate_case(emu, O.T5Cfg.named("tiny"), 3, 20, 5, 12, 40, dtype="bf16", mode="draft", score_tol=0.05)
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_native_library_loaded(hip):
     assert hip.lib.p5_is_emulator() == 0
-    assert hip.lib.p5_abi_version() == 3
+    assert hip.lib.p5_abi_version() == 4
 
 
 def test_tr_probe(hip):
@@ -212,6 +212,22 @@ def test_generate_verified_edge_cases(hip):
     cases.generate_case(hip, O.T5Cfg.named("t5-small"), 4, 64, 10, 12, 300, score_tol=1e-4, dtype="bf16", mode="verified", extra_beams=0)
 
 
+@pytest.mark.parametrize("K", [20, 22, 23])
+def test_generate_verified_base_beam20(hip, K):
+    """The mode bench.py's C4 leg times (BASELINE.json configs[3]): bf16 T5-base dims, V = 32600, collaborative-range trie, beam 20, VERIFIED
+    generation, with and without per-user history exclusion -- token-exact and <= 2e-4 against O.beam_search.  K = 22 = the widest search
+    the replay's LDS candidate pool holds; K = 23 must run the plain fp32 search LOUDLY (warning + `last_generate_path`)."""
+    out = cases.generate_verified_collab_case(hip, K)
+    print(f"[verified t5-base dims, beam {K}]", out)
+    assert out["plain"]["path"] == ("verified" if K <= 22 else "fp32_search")
+
+
+def test_generate_verified_split_range_guard(hip):
+    """Operands beyond the range of the two-term fp16 split (advisor, round 5): flagged by the verification pass, re-run on exact fp32."""
+    st = cases.generate_verified_overflow_case(hip, O.T5Cfg.named("tiny"))
+    print("[verified, overflowing FFN]", st)
+
+
 def test_released_checkpoint_layout_loads(hip, tmp_path):
     cases.released_checkpoint_case(hip, str(tmp_path), O.T5Cfg.named("tiny"))
     cases.released_checkpoint_case(hip, str(tmp_path), O.T5Cfg.named("t5-small", num_layers=1, num_decoder_layers=1, vocab_size=32100), nll_tol=1e-4)
@@ -259,6 +275,11 @@ def test_bench_generation_timing_counts_decode_steps(hip):
     _, dec_len2, timing2, _, _ = bench.time_generation(model, 8, 10, 64, trie, 30, 3, 1, torch.device("cuda:0"), 500, mode="draft")
     assert timing2["forced_prefix_steps"] == 0 and dec_len2 == dec_len, (timing2, dec_len2)
     assert timing2["decode_ms"] > timing["decode_ms"], (timing, timing2)
+
+
+def test_adamw_kernel_matches_published_426_fixture(hip):
+    """a11 pinned (round-5 verdict): p5_grad_sumsq + p5_adamw_kernel against the fp64 run of the published 4.26 algorithm."""
+    print("[adamw golden] worst relative error", cases.adamw_golden_case(hip))
 
 
 def test_train_trajectory_fp32(hip):

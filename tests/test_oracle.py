@@ -88,6 +88,32 @@ def test_dropout_mask_statistics():
     assert 0.75 < float((keep == k2).float().mean()) < 0.9      # ~0.82 for independent masks
 
 
+def test_optimizer_matches_published_426_fixture():
+    """O.clip_coef / O.linear_schedule_lr / O.adamw_hf_step (the torch-op restatement the GPU trajectory tests compare with) against
+    tests/golden/adamw_426.json: the PUBLISHED transformers-4.26 AdamW.step, linear-warmup lambda and torch-1.8.1 clip_grad_norm_ run in
+    fp64 scalar Python by tests/golden/make_adamw_426.py (three parameters, five steps across the warm-up boundary, clipped and unclipped
+    steps).  Run in float64 the two must agree to rounding."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "adamw_426.json")))
+    h = gold["hyper"]
+    names = list(gold["shapes"])
+    p = {k: torch.tensor(gold["p0"][k], dtype=torch.float64) for k in names}
+    m = {k: torch.zeros_like(p[k]) for k in names}
+    v = {k: torch.zeros_like(p[k]) for k in names}
+    for t, st in enumerate(gold["steps"], start=1):
+        g = {k: torch.tensor(st["grad"][k], dtype=torch.float64) for k in names}
+        total, coef = O.clip_coef([g[k] for k in names], h["max_norm"])
+        assert abs(total - st["total_norm"]) <= 1e-12 * st["total_norm"] and (coef < 1.0) == st["clipped"]
+        lr = O.linear_schedule_lr(h["lr"], t - 1, h["warmup_steps"], h["total_steps"])
+        assert abs(lr - st["lr"]) <= 1e-15
+        for k in names:
+            O.adamw_hf_step(p[k], g[k] * coef, m[k], v[k], t, lr, h["beta1"], h["beta2"], h["eps"], h["weight_decay"])
+            for name, got in (("p", p), ("m", m), ("v", v)):
+                ref = torch.tensor(st[name][k], dtype=torch.float64)
+                assert (got[k] - ref).abs().max() <= 1e-12 * max(1.0, float(ref.abs().max())), (t, k, name)
+
+
 def test_optimizer_restatement():
     """clip + HF-AdamW + linear warmup against torch.optim reference arithmetic written out by hand."""
     assert O.linear_schedule_lr(1e-3, 0, 10, 100) == 0.0

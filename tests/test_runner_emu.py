@@ -372,16 +372,19 @@ def test_resume_mid_epoch_is_exact(emu, tmp_path):
     assert torch.equal(rest.model._flat, straight.model._flat)
 
 
-def test_filtered_batch_falls_back_beyond_device_beams(emu, tmp_path, monkeypatch):
-    """--test_filtered 1 --test_filtered_batch 1 (the reference's default, SingleRunner.py:39) with generate_num + max history
-    beyond the device beam limit must not raise: it evaluates with per-user history exclusion inside the search."""
+def test_filtered_batch_beyond_device_beams_is_opt_in(emu, tmp_path, monkeypatch):
+    """--test_filtered 1 --test_filtered_batch 1 (the reference's default, SingleRunner.py:39) with generate_num + max history beyond the
+    device beam limit must SAY so (no silent switch of protocol, round-5 verdict); --test_filtered_batch 2 opts into per-user history
+    exclusion inside the search and equals that path's results."""
     import openp5_amd.runner as R
     tok = build_offline_tokenizer(VOCAB)
     flags = ["--test_filtered", "1", "--eval_batch_size", "6"]
     monkeypatch.setattr(R, "MAX_DEVICE_BEAMS", 4)
-    a = _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "1"]).test()
+    with pytest.raises(ValueError, match="test_filtered_batch 2"):
+        _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "1"]).test()
+    a = _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "2"]).test()
     monkeypatch.setattr(R, "MAX_DEVICE_BEAMS", 64)
-    # (the collator of the per-user protocol computes whole-word ids row by row; the fallback keeps the batch collator of the
+    # (the collator of the per-user protocol computes whole-word ids row by row; mode 2 keeps the batch collator of the
     #  widened-beam protocol, so compare against the same loaders run through the exclusion path)
     r = _eval_runner(emu, tmp_path, tok, flags + ["--test_filtered_batch", "1"])
     b = [r.test_dataset_task_filtered(loader) for loader in r.testloaders]
