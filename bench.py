@@ -12,8 +12,8 @@ resident in HBM before the timed region).  Prints ONE JSON line on rank 0.
 
 Besides the headline (C2) the line carries, at N = 1 only (`--legs none` drops them):
   * `roofline` (dominant kernel of the step by time, profiles/README.md), `roofline_fwd`, `roofline_generation`;
-    `traffic` fields are read from profiles/pmc_traffic.json (written by profiles/collect_pmc.sh on the GPU box; null if
-    that file has no entry for the kernel + shape);
+    `traffic` and `mfma_busy` are measured by this run itself when rocprofv3 is on the box (separate `--pmc` subprocess passes over
+    tools/gemm_one.py and tools/gen_bench.py, bench.pmc_live); otherwise they come from profiles/pmc_traffic.json with `traffic_stale: true`;
   * `cpu_baseline` (training, oracle port) and `cpu_baseline_generation` (oracle beam search), bounded samples;
   * `legs`: single-GPU measurements of the other BASELINE.json configs -- C3 per-GPU (T5-base, B=64), C4 (T5-base,
     beam 20, 20 users, V=32600), C5 per-GPU (T5-large, L=512) -- and `task_mix`, the real alternation of sequential
@@ -78,15 +78,19 @@ def synth_batch(B, L, T, device, seed, vocab=V):
     return [t.to(device) for t in (ids, ww, mask, labels, out_attn)]
 
 
-def synth_item_trie(n_items, seed, lo=3000, hi=3999, pieces=(2, 2, 3)):
-    """ML1M-like item ids: "<dataset> item_ <digits>" -> shared 4-piece prefix + 2-3 number pieces + </s>."""
-    from openp5_amd.trie import Trie
+def synth_items(n_items, seed, lo=3000, hi=3999, pieces=(2, 2, 3)):
+    """ML1M-like item ids: "<dataset> item_ <digits>" -> decoder start + shared 4-piece prefix + 2-3 number pieces + </s>, sorted."""
     rnd = random.Random(seed)
     items = set()
     while len(items) < n_items:
         n = rnd.choice(pieces)
         items.add(tuple([0, 2000, 2001, 2002, 2003] + [rnd.randint(lo, hi) for _ in range(n)] + [1]))
-    return Trie(sorted(items))
+    return sorted(items)
+
+
+def synth_item_trie(n_items, seed, lo=3000, hi=3999, pieces=(2, 2, 3)):
+    from openp5_amd.trie import Trie
+    return Trie(synth_items(n_items, seed, lo, hi, pieces))
 
 
 def _dist():
@@ -231,6 +235,72 @@ def time_generation(model, gB, gK, L, trie, max_length, batches, world, device, 
     return gdt, int(o["sequences"].shape[1]), timing, sorted(per_call)[len(per_call) // 2], stats
 
 
+def trained_generation_leg(be, device, backbone, dtype, world, rank, gB, gK, L, n_items, gen_batches, train_steps=600, clusters=16, head=200):
+    """The generation headline on TRAINED weights (round-5 verdict 1b): random-init weights score every item within ~1e-3 of every other,
+    weights trained on noise likewise; a recommender's scores are peaked.  A fresh model of the benchmarked architecture is trained with the
+    benchmarked training step on a learnable synthetic task -- the first input token names one of `clusters` user clusters, the target is an
+    item id drawn from that cluster's own Zipf(1.2) popularity over `head` items (cluster-conditional popularity, what a sequential
+    recommender learns first) -- then the verified beam search is timed on users of the same distribution.  Reports items/s, the verification
+    statistics (flagged users), the loss reached, and how often the top-1 item is one of the user's cluster's ten most popular items."""
+    cfg, model, opt = build_model(backbone, dtype, device, be, world, rank, total_steps=train_steps)
+    items = synth_items(n_items, 7)
+    T = max(len(it) for it in items) - 1
+    g = torch.Generator().manual_seed(4242 + rank)
+    perms = [torch.randperm(n_items, generator=g)[:head] for _ in range(clusters)]
+    w = 1.0 / torch.arange(1, head + 1, dtype=torch.float64) ** 1.2
+    item_tok = torch.zeros(n_items, T, dtype=torch.long)
+    for i, it in enumerate(items):
+        item_tok[i, :len(it) - 1] = torch.tensor(it[1:])
+
+    def batch(B, seed):
+        ids, ww, mask, _, _ = synth_batch(B, L, T, "cpu", seed)
+        gg = torch.Generator().manual_seed(seed)
+        cl = torch.randint(0, clusters, (B,), generator=gg)
+        ids[:, 0] = 100 + cl
+        rank_in_cluster = torch.multinomial(w, B, replacement=True, generator=gg)
+        tgt = torch.stack([perms[int(c)][int(r)] for c, r in zip(cl, rank_in_cluster)])
+        labels = item_tok[tgt]
+        return [t.to(device) for t in (ids, ww, mask, labels, (labels != 0).long())], cl
+    model.train()
+    pool = [batch(64, 9000 + i)[0] for i in range(32)]
+    loss = None
+    for st in range(train_steps):
+        loss = train_step(model, opt, pool[st % len(pool)])
+    final_loss = float(loss.detach())
+    (gids, gww, gmask, _, _), cl = batch(gB, 777 + rank)
+    from openp5_amd.trie import Trie, prefix_allowed_tokens_fn
+    fn = prefix_allowed_tokens_fn(Trie(items))
+    model.eval()
+    model.generation_mode = "verified"
+    kw = dict(input_ids=gids, attention_mask=gmask, whole_word_ids=gww, max_length=30, prefix_allowed_tokens_fn=fn, num_beams=gK, num_return_sequences=gK,
+              output_scores=True, return_dict_in_generate=True)
+    lanes = int(getattr(model, "gen_lanes", 1))
+    for _ in model.map_lanes(lambda k: model.generate(**k), [kw] * (2 * lanes), lanes=lanes):
+        pass
+    for k in model.verify_stats:
+        model.verify_stats[k] = 0
+    barrier(world)
+    t0 = time.perf_counter()
+    for o in model.map_lanes(lambda k: model.generate(**k), [kw] * gen_batches, lanes=lanes):
+        pass
+    barrier(world)
+    gdt = max_over_ranks(time.perf_counter() - t0, world, device)
+    vst = dict(model.verify_stats)
+    seq = o["sequences"].view(gB, gK, -1)[:, 0].cpu()
+    sc = o["sequences_scores"].view(gB, gK).cpu()
+    index = {it[1:]: i for i, it in enumerate(items)}
+    hits = 0
+    for b in range(gB):
+        toks = tuple(t for t in seq[b].tolist()[1:] if t != 0)
+        hits += int(index.get(toks, -1) in set(perms[int(cl[b])][:10].tolist()))
+    return {"items_per_s": world * gB * gK * gen_batches / gdt, "ms_per_batch": gdt / gen_batches * 1e3, "lanes": lanes, "verify_stats": vst,
+            "fallback_users": vst.get("fallback_users", 0), "escalated_users": vst.get("escalated_users", 0), "users": vst.get("users", 0),
+            "train_steps": train_steps, "final_train_loss": final_loss, "top1_in_cluster_top10": hits / gB,
+            "score_gap_top1_top10": float((sc[:, 0] - sc[:, -1]).mean()),
+            "note": f"fresh {backbone} trained for {train_steps} benchmark steps (B=64, dropout 0.1, lr 1e-3 linear warm-up) on cluster-conditional Zipf(1.2) item "
+                    f"popularity ({clusters} clusters x {head} items of the {n_items}-item trie), then verified beam-{gK} generation for {gB} users per batch"}
+
+
 def time_gemm_kernel(be, M, N, K, iters=50, wgrad=False):
     """average duration of a GEMM kernel measured with HIP events on the stream the kernel is launched on.
     wgrad=False: forward bf16 GEMM y = x W^T (both operands K-contiguous);
@@ -293,6 +363,85 @@ def time_wgrad_group(be, M, d, F, inner, iters=30, layers=2):
     e1.record(s)
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3, flops, byts
+
+
+def _rocprof_pmc_pass(counters, cmd, timeout_s=150):
+    """One `rocprofv3 --pmc <counters> --kernel-trace -- <cmd>` pass (kernel trace only next to --pmc, as MI355X_MICROARCH.md and gpurun
+    require) -> {kernel_name: {counter: (sum over dispatches, dispatches)}}, or None when rocprofv3 is absent / the pass fails."""
+    import glob, shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out = tempfile.mkdtemp(prefix="p5pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONDONTWRITEBYTECODE="1")
+    try:
+        r = subprocess.run([exe, "--pmc", *counters, "--kernel-trace", "-d", out, "-o", "p", "--"] + cmd, cwd="/tmp", env=env, timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None
+        cur = sqlite3.connect(dbs[0]).cursor()
+        tabs = [t[0] for t in cur.execute("select name from sqlite_master where type='table'")]
+        ev = [t for t in tabs if "pmc_event" in t][0]; info = [t for t in tabs if "info_pmc" in t][0]
+        disp = [t for t in tabs if "kernel_dispatch" in t][0]; sym = [t for t in tabs if "info_kernel_symbol" in t][0]
+        res = {}
+        for k, n, v, c in cur.execute(f"select s.kernel_name, i.name, sum(e.value), count(*) from {ev} e join {info} i on e.pmc_id=i.id join {disp} d on "
+                                      f"e.event_id=d.event_id join {sym} s on d.kernel_id=s.id group by s.kernel_name, i.name"):
+            res.setdefault(k, {})[n] = (float(v), int(c))
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_live(shape, want_decode=True):
+    """HBM-side traffic and matrix-core occupancy of the roofline kernels measured IN THIS RUN (round-5 verdict item 5): separate --pmc passes
+    over tools/gemm_one.py (the forward / data-gradient GEMM at `shape`) -- FETCH_SIZE, WRITE_SIZE (they do not fit one pass; FETCH_SIZE
+    doubled on gfx950, MI355X_MICROARCH.md HBM section) and the SQ activity counters -- and over tools/gen_bench.py (plain bf16 search) for
+    the bytes of one decode step.  Returns {} when rocprofv3 is not on the box."""
+    py = sys.executable
+    gemm = [py, os.path.join(ROOT, "tools", "gemm_one.py")] + [str(int(x)) for x in shape]
+    pick = lambda res, pat: next((v for k, v in (res or {}).items() if pat in k), None)      # noqa: E731
+    out = {}
+    f = pick(_rocprof_pmc_pass(["FETCH_SIZE"], gemm), "p5_gemm5_kernelILb0E")
+    w = pick(_rocprof_pmc_pass(["WRITE_SIZE"], gemm), "p5_gemm5_kernelILb0E")
+    if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+        rd = f["FETCH_SIZE"][0] / f["FETCH_SIZE"][1] * 1024.0 * 2.0
+        wr = w["WRITE_SIZE"][0] / w["WRITE_SIZE"][1] * 1024.0
+        out["gemm"] = {"traffic_bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches": f["FETCH_SIZE"][1],
+                       "source": "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over tools/gemm_one.py, per launch; "
+                                 "FETCH_SIZE x2 (gfx950); fabric-side counters (Infinity-Cache hits included): an upper bound of HBM traffic"}
+    q = pick(_rocprof_pmc_pass(["SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"], gemm), "p5_gemm5_kernelILb0E")
+    if q and "SQ_BUSY_CYCLES" in q and "SQ_VALU_MFMA_BUSY_CYCLES" in q:
+        busy, mf = q["SQ_BUSY_CYCLES"][0], q["SQ_VALU_MFMA_BUSY_CYCLES"][0]
+        wc = q.get("SQ_WAVE_CYCLES", (0.0, 1))[0]
+        out["sq"] = {"mfma_busy": mf / max(1.0, 32.0 * busy), "wait_frac_of_wave_cycles": q.get("SQ_WAIT_ANY", (0.0, 1))[0] / max(1.0, wc),
+                     "issue_frac_of_wave_cycles": q.get("SQ_ACTIVE_INST_ANY", (0.0, 1))[0] / max(1.0, wc),
+                     "source": "this run: rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY over tools/gemm_one.py; "
+                               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 8 x SQ_BUSY_CYCLES) (profiles/pmc_summary.py)"}
+    if want_decode:
+        step_kernels = ("p5_skinny_gemm_kernel", "p5_dec_self_attn2_kernel", "p5_dec_cross_attn3_kernel", "p5_head_lse_kernel", "p5_dec_score2_kernel",
+                        "p5_beam_step_kernel", "p5_rmsnorm_f32in_kernel")
+        gen = [py, os.path.join(ROOT, "tools", "gen_bench.py"), "20", "5", "10"]
+        tot = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            os.environ["P5_GEN_MODE"] = "draft"
+            res = _rocprof_pmc_pass([ctr], gen)
+            os.environ.pop("P5_GEN_MODE", None)
+            if not res:
+                tot = None
+                break
+            v = sum(c[ctr][0] for k, c in res.items() if ctr in c and any(sk in k for sk in step_kernels))
+            steps = sum(c[ctr][1] for k, c in res.items() if ctr in c and "p5_beam_step_kernel" in k)
+            tot[ctr] = (v, steps)
+        if tot and tot["FETCH_SIZE"][1] > 0 and tot["FETCH_SIZE"][1] == tot["WRITE_SIZE"][1]:
+            st = tot["FETCH_SIZE"][1]
+            rd, wr = tot["FETCH_SIZE"][0] * 1024.0 * 2.0 / st, tot["WRITE_SIZE"][0] * 1024.0 / st
+            out["decode"] = {"traffic_bytes_per_step": rd + wr, "read_bytes_per_step": rd, "write_bytes_per_step": wr, "decode_steps": st,
+                             "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/gen_bench.py (plain bf16 search, 20 users, beam 10), "
+                                       "summed over every kernel of the decode steps, per p5_beam_step_kernel dispatch; FETCH_SIZE x2 (gfx950)"}
+    return out
 
 
 def in_step_us(kernel_key):
@@ -550,6 +699,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--legs", default="all", help="all | none | comma list of: configs,task_mix")
     ap.add_argument("--gen-batches", type=int, default=20)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc subprocess passes (roofline.traffic / mfma_busy then come from profiles/*.json, marked stale)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -605,7 +755,8 @@ def main():
                "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3, "ms_per_batch_median_call": med,
                "lanes": vst.get("lanes"), "timing_note": "ms_per_batch = timed region / batches with `lanes` batches in flight (throughput); ms_per_batch_median_call = one "
                "generate() call by itself (latency)", "users_per_batch": gB, "num_beams": gK, "max_length": 30, "trie_items": 3416, "decoded_len": dec_len, "draft_timing_ms": timing,
-               "verify_stats": vst}
+               "verify_stats": vst, "weights": "random-init (near-flat item scores; `generation.trained_model` is the same call on trained weights)",
+               "fallback_users": vst.get("fallback_users", 0), "escalated_users": vst.get("escalated_users", 0), "users": vst.get("users", 0)}
         gdt, dec_len, timing, med, _ = time_generation(model, gB, gK, L, trie, 30, args.gen_batches, world, device, 500 + rank, mode="draft")
         gen_draft = {"mode": "draft (plain bf16 search)", "items_per_s": world * gB * gK * args.gen_batches / gdt, "ms_per_batch": gdt / args.gen_batches * 1e3,
                      "ms_per_batch_median_call": med, "users_per_batch": gB, "num_beams": gK, "decoded_len": dec_len, "timing_ms": timing}
@@ -615,6 +766,10 @@ def main():
                                        "note": "the same call on the model the timed training steps left behind (25 steps on random labels): near-uniform item scores, "
                                                "so the fp32 top-K is not among the bf16 draft's beams for some users; they get a wider draft, then the fp32 search"}
         model = trained
+        try:
+            gen["trained_model"] = trained_generation_leg(be, device, args.backbone, args.dtype, world, rank, gB, gK, L, 3416, args.gen_batches)
+        except Exception as ex:
+            gen["trained_model"] = {"error": repr(ex)[:300]}
 
     if rank == 0:
         c = cfg
@@ -646,6 +801,12 @@ def main():
             "model_tflops": samples_per_s * flops / 1e12,
             "model_flops_frac_of_bf16_peak": samples_per_s * flops / 1e12 / (BF16_PEAK_TFLOPS * world),
             "beam10_items_per_sec": gen["items_per_s"] if gen else None,
+            # users the verification pass could not settle from the bf16 draft (re-run on the plain fp32 search) / users, for the headline call
+            # (random-init weights) and for the same call on a trained model -- the headline's regime is the friendly one only if both are small
+            "beam10_fallback_users_over_users": ([gen["fallback_users"], gen["users"]] if gen else None),
+            "beam10_items_per_sec_trained_model": (gen.get("trained_model", {}).get("items_per_s") if gen else None),
+            "beam10_fallback_users_over_users_trained_model": ([gen["trained_model"].get("fallback_users"), gen["trained_model"].get("users")]
+                                                                if gen and "error" not in gen.get("trained_model", {"error": 1}) else None),
             "generation": gen,
             "generation_plain_bf16": gen_draft,
             "distributed": ddp,
@@ -655,15 +816,28 @@ def main():
             # `roofline_wgrad`: the grouped weight-gradient launch (two encoder layers, round 3's `roofline`), `step_kernels`: the
             # whole per-kernel table of the step.
         }
+        live = {}
+        if world == 1 and not args.no_pmc:
+            try:
+                live = pmc_live((Mg, Ng, Kg), want_decode=gen_draft is not None)
+            except Exception as ex:      # (never lose the bench line to a profiler hiccup)
+                live = {"error": repr(ex)[:200]}
         cls = kernel_classes(prof_rows) if prof_rows else []
         gemm_cls = [c for c in cls if c["flops_per_step"] > 0]
         fwd_alone = {"shape": [Mg, Ng, Kg], "avg_launch_us": t_k * 1e6, "achieved": ach, "frac": ach / BF16_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng),
-                     "traffic_source": "profiles/pmc_traffic.json (profiles/collect_pmc.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"}
+                     "traffic": pmc_traffic("fwd_wide", (Mg, Ng, Kg)), "algorithmic_bytes": 2.0 * (Mg * Kg + Ng * Kg + Mg * Ng), "traffic_stale": True,
+                     "traffic_source": "STALE: profiles/pmc_traffic.json, collected by an earlier run (profiles/collect_pmc.sh: separate FETCH_SIZE / WRITE_SIZE "
+                                       "passes, FETCH_SIZE x2 on gfx950) -- rocprofv3 was not available to this run or --no-pmc was given"}
+        if live.get("gemm"):
+            fwd_alone.update({"traffic": live["gemm"]["traffic_bytes"], "traffic_read": live["gemm"]["read_bytes"], "traffic_write": live["gemm"]["write_bytes"],
+                              "traffic_stale": False, "traffic_source": live["gemm"]["source"]})
+        if live.get("sq"):
+            fwd_alone.update({"mfma_busy": live["sq"]["mfma_busy"], "wait_frac_of_wave_cycles": live["sq"]["wait_frac_of_wave_cycles"],
+                              "issue_frac_of_wave_cycles": live["sq"]["issue_frac_of_wave_cycles"], "mfma_busy_source": live["sq"]["source"]})
         wg_alone = {"shape": [[c.d_model, c.d_ff, Mg], [c.d_ff, c.d_model, Mg], [c.d_model, inner, Mg], [3 * inner, c.d_model, Mg]] * 2,
                     "avg_launch_us": t_w * 1e6, "achieved": ach_w, "frac": ach_w / BF16_PEAK_TFLOPS, "flops_per_launch": fl_w,
-                    "traffic": pmc_traffic("wgrad_group2", (Mg, c.d_model, c.d_ff)), "algorithmic_bytes": by_w,
-                    "traffic_source": "profiles/pmc_traffic.json"}
+                    "traffic": pmc_traffic("wgrad_group2", (Mg, c.d_model, c.d_ff)), "algorithmic_bytes": by_w, "traffic_stale": True,
+                    "traffic_source": "STALE: profiles/pmc_traffic.json (an earlier run of profiles/collect_pmc.sh)"}
         if cls:
             top = cls[0]
             tf = top["flops_per_step"] / max(top["us_per_step"], 1e-9) / 1e6
@@ -672,6 +846,9 @@ def main():
                                 "launches_per_step": top["launches_per_step"], "us_per_step": top["us_per_step"], "flops_per_step": top["flops_per_step"],
                                 "share_of_kernel_time": top["us_per_step"] / max(1e-9, sum(c["us_per_step"] for c in cls)),
                                 "by_grid": top["grids"], "alone": wg_alone if is_ks else fwd_alone, "traffic": (wg_alone if is_ks else fwd_alone)["traffic"],
+                                "traffic_source": (wg_alone if is_ks else fwd_alone)["traffic_source"], "traffic_stale": (wg_alone if is_ks else fwd_alone).get("traffic_stale", True),
+                                "traffic_of": "one launch of the kernel's largest shape in the step (`alone`), per launch like `alone.achieved`",
+                                "mfma_busy": (None if is_ks else fwd_alone.get("mfma_busy")), "mfma_busy_source": (None if is_ks else fwd_alone.get("mfma_busy_source")),
                                 "source": "p5_profile_begin/end in this run: HIP events around every launch of 3 steps (durations include the dispatch gap)"}
             # which number to read: `frac` is computed from event-BRACKETED durations (each includes its launch's dispatch gap: an upper bound of
             # the kernel time, so `frac` is a lower bound).  The smallest bracket of the step (a trivial kernel) bounds that gap from above;
@@ -707,9 +884,12 @@ def main():
             gbs = byts / (step_ms * 1e-3) / 1e9
             line["roofline_generation"] = {"bound": "hbm", "kernel": "decode step (all launches of one step), plain bf16 search", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": byts, "ms_per_step": step_ms,
-                                           "steps": S, "forced_prefix_steps": int(timing.get("forced_prefix_steps", 0)), "traffic": decode_step_traffic(),
-                                           "traffic_source": "profiles/pmc_decode_step.json (tools/r5_final_run.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of the "
-                                                             "decode steps of tools/gen_bench.py, separate --pmc passes, per step; fabric-side counters: L2-miss traffic)",
+                                           "steps": S, "forced_prefix_steps": int(timing.get("forced_prefix_steps", 0)),
+                                           "traffic": live["decode"]["traffic_bytes_per_step"] if live.get("decode") else decode_step_traffic(),
+                                           "traffic_stale": not live.get("decode"),
+                                           "traffic_source": live["decode"]["source"] if live.get("decode") else
+                                           "STALE: profiles/pmc_decode_step.json from an earlier run (FETCH_SIZE x2 + WRITE_SIZE over every kernel of the "
+                                           "decode steps of tools/gen_bench.py, separate --pmc passes, per step; fabric-side counters: L2-miss traffic)",
                                            "time_source": "device time of the decode loop (engine HIP events) / decode steps" if timed else "whole generate() / steps",
                                            "note": "bytes = decoder weights + tied head once + shared cross-KV + self-KV (SURVEY 8(d)); the steps every item id shares "
                                                    "run as ONE teacher-forced pass before the loop (p5_decode.h) and are not decode steps"}

@@ -143,6 +143,13 @@ int p5_adamw_step(float* params, const float* grads, float* m, float* v, void* s
                   const float* sumsq /* float[1024] from p5_grad_sumsq, or NULL = no clipping */, double max_norm, double grad_scale, double lr, double beta1,
                   double beta2, double eps, double weight_decay /* doubles, as the reference's Python floats: derived scalars are rounded once */, int step_t,
                   void* stream);
+/* The same step over the ENGINE's bound arenas (params, grads, bf16 shadow).  With the transposed / norm-folded copies bound
+ * (p5_engine_bind_transposed, bf16 training) the update ALSO writes W^T and W diag(ln) -- the 2-D layer weights are updated in 64 x 64
+ * tiles that are transposed through LDS, a projection behind a T5LayerNorm is multiplied by the norm weight's NEW value -- so the
+ * caller skips p5_refresh_transposed (*copies_fresh = 1; 0 when the flat path ran: fp32 engine, no copy bound, side stream, option
+ * "adam_tiles" 0).  Per element the arithmetic is p5_adamw_step's: parameters, moments and all three copies are bit-identical. */
+int p5_engine_adamw_step(P5Engine* e, float* m, float* v, const float* sumsq, double max_norm, double grad_scale, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, int step_t, int* copies_fresh, void* stream);
 
 /* ---- generation ---- */
 /* Optional: a caller-owned buffer of p5_decode_fold_count(e) elements of the compute dtype.  When bound, p5_generate folds every
@@ -248,7 +255,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
 /* Persistent ring GEMM (openp5_amd/csrc/p5_gemm4.h), bf16 operands: up to 8 problems C[M,N] (+)= A B^T in ONE launch (the weight
  * gradients of a layer; nn.Linear autograd, DistributedRunner.py:80).  ks = 0: A [M, lda], B [N, ldb] (reduction dim contiguous);
  * ks = 1: A [K, lda], B [K, ldb] (reduction dim strided: dW = dy^T x).  epi as p5_op_gemm (0 store, 1 relu(+dropout), 2 residual +
- * dropout, 3 mask by aux > 0, 4 fp32 atomic add, 6 fp32 C += without split-K).  tile_cfg 0 = 128x128, 1 = 256x128, 2 = 128x256.
+ * dropout, 3 mask by aux > 0, 4 fp32 atomic add, 6 fp32 C += without split-K, 5 / 7 gated-GELU forward / backward, below).  tile_cfg 0 = 128x128, 1 = 256x128, 2 = 128x256.
  * rowss / ssq_out: optional T5LayerNorm statistics carried through the epilogue (row sum of squares in, sum of squares of the stored
  * row out), NULL = off.  `probs` is a HOST array. */
 typedef struct P5GemmProblem {
@@ -257,6 +264,11 @@ typedef struct P5GemmProblem {
   float alpha;
   const float* rowss; float rowss_eps; float* ssq_out;
   int rowss_nt, ssq_nt;    /* > 0: the statistics are [rows, nt] partial sums (one per 64 columns), summed in index order / stored per tile; 0: one value per row */
+  /* gated-GELU FFN (T5 v1.1, HF modeling_t5.py:97-123) fused into the GEMMs around it (tile_cfg 1, ks 0, whole 256x128 tiles):
+   * epi 5 = forward: B = [wi_0; wi_1] ([2F, K], read gate-interleaved), N = 2F, C = h = dropout(gelu_new(u0) * u1) [M, F] (ldc), C2 = u =
+   * [u0 | u1] [M, 2F] (ldc2) kept for the backward, gate_F = F;  epi 7 = backward: B = Wo^T [F, K], N = F, aux = u [M, 2F] (ldaux),
+   * C = du = [dh u1 gelu'(u0) | dh gelu(u0)] [M, 2F] (ldc), dh = the product with the dropout mask of h re-applied; gate_F = 0 */
+  void* C2; int ldc2, gate_F;
 } P5GemmProblem;
 int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,
                      void* stream);

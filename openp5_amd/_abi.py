@@ -17,7 +17,8 @@ class P5Config(C.Structure):
 
 class P5GemmProblem(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("aux", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
-                ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp), ("rowss_nt", i32), ("ssq_nt", i32)]
+                ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp), ("rowss_nt", i32), ("ssq_nt", i32),
+                ("C2", vp), ("ldc2", i32), ("gate_F", i32)]
 
 
 # name -> (restype, argtypes)
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "p5_allreduce_sum": (i32, [vp, i64, i32, vp, vp]),
     "p5_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "p5_adamw_step": (i32, [vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, f64, f64, i32, vp]),
+    "p5_engine_adamw_step": (i32, [vp, vp, vp, vp, f64, f64, f64, f64, f64, f64, f64, i32, C.POINTER(i32), vp]),
     "p5_decode_fold_count": (i64, [vp]),
     "p5_engine_bind_decode_fold": (i32, [vp, vp]),
     "p5_refresh_decode_fold": (i32, [vp, vp]),

@@ -26,8 +26,12 @@ enum P5Epi : int {
   P5_EPI_RESID_DROP = 2,  // C = aux + drop(acc)            (aux: residual stream, same dtype as C)
   P5_EPI_MASK_POS = 3,    // C = aux > 0 ? acc * alpha : 0  (relu/dropout backward through saved hidden)
   P5_EPI_ATOMIC = 4,      // C += acc * alpha  (fp32 atomics; split-K wgrad)
-  P5_EPI_GELU_GATE = 5,   // reserved (gated-gelu epilogue handled by an elementwise kernel in v1)
+  P5_EPI_GELU_GATE = 5,   // gated-GELU forward (T5 v1.1 FFN, HF modeling_t5.py:97-123) fused into the wi GEMM: B = [wi_0; wi_1] read gate-interleaved
+                          // (P5GemmArgs::gate_F), C = h = drop(gelu_new(u0) * u1) [M, F], C2 = u = [u0 | u1] [M, 2F] kept for the backward
+                          // (p5_gemm5.h whole-tile epilogue only: bf16, M % 256 == 0, N = 2F, N % 128 == 0)
   P5_EPI_ACCUM = 6,       // C += acc * alpha  (fp32, exclusive ownership: no split-K)
+  P5_EPI_GELU_GATE_BWD = 7,   // gated-GELU backward fused into the wo data-gradient GEMM: acc = dh [M, F], aux = u [M, 2F] (ldaux), C = du =
+                              // [dh u1 gelu'(u0) | dh gelu(u0)] [M, 2F] (ldc); the dropout mask of h is re-hashed (same conditions as above, N = F)
 };
 
 struct P5GemmArgs {
@@ -59,6 +63,11 @@ struct P5GemmArgs {
   // (elements) instead of adding to C with atomics; the caller sums the active splits in index order (p5_reduce_splits_kernel).
   long long c_split_stride;
   int mm_split;          // fp32 operands, K-contiguous: products on the f16 matrix cores from a two-term split of each operand (below); 0 = exact fp32 MFMAs
+  // gated-GELU epilogues (P5_EPI_GELU_GATE / _BWD): second output of the forward, and F = d_ff when the rows of B are read gate-interleaved
+  // -- GEMM column n = 64 t + j is row 32 t + j of wi_0 for j < 32 and row F + 32 t + (j - 32) (= wi_1) otherwise, so that a lane's two
+  // 8-column groups of a 64-column wave tile are u0 and u1 of the SAME eight hidden units
+  void* C2;
+  int ldc2, gate_F;
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets

@@ -18,7 +18,8 @@
 #pragma once
 #include "p5_gemm4.h"
 
-template <bool KS, int ABL = 0>
+// GATE: the instance that carries the gated-GELU epilogues (P5_EPI_GELU_GATE / _BWD); the product instances do not pay for their registers
+template <bool KS, int ABL = 0, bool GATE = false>
 __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   using T = bf16;
   constexpr int BM = 256, BN = 128, NST = 3;
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           const int row = (lw * NDB + i) * 8 + (lane >> 3);
           int gr = u.n0 + row;
           gr = gr < g.N ? gr : g.N - 1;
+          if constexpr (GATE)
+            if (g.gate_F > 0) gr = ((gr & 32) ? g.gate_F : 0) + ((gr >> 6) << 5) + (gr & 31);      // [wi_0; wi_1] read gate-interleaved (p5_gemm.h)
           srcB[i] = (const T*)g.B + (size_t)gr * g.ldb + u.kb + (((lane & 7) ^ g4_sigma_b(row)) * 8);
         }
       }
@@ -153,6 +156,14 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   }
 
   // =========================================== compute waves ===========================================
+  // Optional phase offset (lab, option "gemm5_stagger", units of ~0.4 us): every workgroup of a launch reaches its write phase at the same
+  // time -- 33 MB of stores per 8192x2048 launch while no MFMA runs anywhere on the chip.  Odd workgroups of each XCD start their compute
+  // waves late, so that one half's write-out runs under the other half's K loop.
+#ifndef P5_EMU
+  if (grp.stagger > 0 && (((int)blockIdx.x >> 3) & 1)) {
+    for (int q = 0; q < grp.stagger; ++q) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   const int wm = wave >> 1, wn = wave & 1;
   int offA[KS ? TM : 1], offB[KS ? TN : 1];
   if constexpr (KS) {
@@ -304,8 +315,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   };
   // what the whole-tile epilogue needs from the problem descriptor, as scalars
   struct EpiCtx {
-    void* C; const void* aux; float* ssq; const float* rowss;
-    int epi, N, ldc, ldaux, ssq_nt, rowss_nt;
+    void* C; const void* aux; float* ssq; const float* rowss; void* C2;
+    int epi, N, ldc, ldaux, ssq_nt, rowss_nt, ldc2, gate_F;
     uint32_t thr, hseed;
     float dscale, alpha, invd, eps;
     bool fast, fast32, do_drop;
@@ -313,8 +324,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   auto load_ctx = [&](const Unit& u) {
     const P5GemmArgs& g = grp.p[u.pi];
     EpiCtx c;
-    c.C = g.C; c.aux = g.aux; c.ssq = g.ssq_out; c.rowss = g.rowss;
-    c.epi = g.epi; c.N = g.N; c.ldc = g.ldc; c.ldaux = g.ldaux; c.ssq_nt = g.ssq_nt; c.rowss_nt = g.rowss_nt;
+    c.C = g.C; c.aux = g.aux; c.ssq = g.ssq_out; c.rowss = g.rowss; c.C2 = g.C2;
+    c.epi = g.epi; c.N = g.N; c.ldc = g.ldc; c.ldaux = g.ldaux; c.ssq_nt = g.ssq_nt; c.rowss_nt = g.rowss_nt; c.ldc2 = g.ldc2; c.gate_F = g.gate_F;
     c.thr = g.drop.thr; c.dscale = g.drop.scale; c.alpha = g.alpha; c.invd = g.rowss_invd; c.eps = g.rowss_eps;
     c.do_drop = g.drop.state != nullptr && g.drop.thr != 0;
     c.hseed = p5_mix32(p5_seed(g.drop) + g.drop.site_key);
@@ -324,6 +335,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     } else {
       const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
       c.fast = inside && vec_ok && !g.c_f32 && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM && (g.ssq_out == nullptr || g.ssq_nt > 0);
+      if (g.epi == P5_EPI_GELU_GATE) c.fast = c.fast && g.C2 != nullptr && (g.ldc2 & 7) == 0 && ((uintptr_t)g.C2 & 15) == 0 && g.gate_F * 2 == g.N && g.ssq_out == nullptr;
+      if (g.epi == P5_EPI_GELU_GATE_BWD) c.fast = c.fast && g.aux != nullptr && g.rowss == nullptr && g.ssq_out == nullptr;
       // plain fp32 store of a whole tile (the tied head's logits: 66 MB per step): straight from the accumulators, two 16-byte stores
       // per lane and row block -- the general path below re-reads the descriptor per element (87 us for the 512 x 32100 x 512 head GEMM)
       c.fast32 = inside && g.c_f32 && g.epi == P5_EPI_STORE && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && g.ssq_out == nullptr && g.rowss == nullptr;
@@ -482,7 +495,11 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
             for (int h = 0; h < TN / 2; ++h) {
               T* const cpi = cp + (size_t)i * 16 * ldc + h * 32;
               if constexpr ((ABL & 16) != 0) { if (packed[h][0] == 0x12345678u) st16(cpi, packed[h]); }      // (lab: epilogue math without the stores)
+#if defined(P5_GEMM5_NT) && !defined(P5_EMU)
+              else __builtin_nontemporal_store(packed[h], (u32x4*)cpi);      // (lab build: streaming stores)
+#else
               else st16(cpi, packed[h]);
+#endif
             }
             if (ssq) {
               sq += __shfl_xor(sq, 16);
@@ -492,6 +509,95 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
             }
           }
         };
+        // ---- gated-GELU (T5 v1.1 FFN, HF modeling_t5.py:97-123: h = gelu_new(wi_0 x) * (wi_1 x)), forward: the two 8-column groups of a lane
+        // are u0 and u1 of the same eight hidden units (gate-interleaved B rows); u is stored for the backward in its [u0 | u1] layout
+        // and the gate is taken from the ROUNDED values, i.e. exactly what the stand-alone p5_gated_gelu_fwd_kernel reads back.
+        auto gate_fwd = [&](auto dk) {
+          constexpr bool DROP = decltype(dk)::value != 0;
+          const int F = cx.gate_F, ldc2 = cx.ldc2;
+          const int hc = ((u.n0 + wn * WTN) >> 1) + gl * 8;                // first of this lane's eight hidden units
+          T* const hp = (T*)cx.C + (size_t)row * ldc + hc;
+          T* const up = (T*)cx.C2 + (size_t)row * ldc2 + hc;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float sc = rowss ? __shfl((i & 1) ? sc2[1] : sc2[0], (le & 15) + 16 * (i >> 1)) : alpha;
+            float a[8], b[8], hv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = acc[i][0][r] * sc; a[4 + r] = acc[i][1][r] * sc; b[r] = acc[i][2][r] * sc; b[4 + r] = acc[i][3][r] * sc; }
+            const u32x4 pa = pack16<T>(a), pb = pack16<T>(b);
+            unpack16<T>(pa, a);
+            unpack16<T>(pb, b);
+            const uint32_t idx0 = (uint32_t)((row + i * 16) * F + hc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t = tanhf(0.7978845608028654f * (a[e] + 0.044715f * a[e] * a[e] * a[e]));
+              float v = 0.5f * a[e] * (1.f + t) * b[e];
+              if constexpr (DROP) v = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? v * dscale : 0.f;
+              hv[e] = v;
+            }
+            st16(up + (size_t)i * 16 * ldc2, pa);
+            st16(up + (size_t)i * 16 * ldc2 + F, pb);
+            st16(hp + (size_t)i * 16 * ldc, pack16<T>(hv));
+          }
+        };
+        // ---- backward: acc = dh (grad of the dropped product), aux = the stored u; writes du = [dh u1 gelu'(u0) | dh gelu(u0)]
+        auto gate_bwd = [&](auto dk) {
+          constexpr bool DROP = decltype(dk)::value != 0;
+          const int F = N;
+          const T* const uq = (const T*)cx.aux + (size_t)row * ldaux + col0;
+          T* const dq = (T*)cx.C + (size_t)row * ldc + col0;
+          constexpr int AD = 2;
+          u32x4 ua[AD][TN / 2], ub[AD][TN / 2];
+          auto u_load = [&](int i) {
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h) {
+              ua[i % AD][h] = ld16(uq + (size_t)i * 16 * ldaux + h * 32);
+              ub[i % AD][h] = ld16(uq + (size_t)i * 16 * ldaux + h * 32 + F);
+            }
+          };
+          u_load(0);
+          u_load(1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            u32x4 o0[TN / 2], o1[TN / 2];
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h) {
+              float g8[8], a[8], b[8], d0[8], d1[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { g8[r] = acc[i][2 * h][r] * alpha; g8[4 + r] = acc[i][2 * h + 1][r] * alpha; }
+              {   // dh as the stand-alone path sees it: rounded to the compute dtype by the data-gradient GEMM's store
+                const u32x4 pg = pack16<T>(g8);
+                unpack16<T>(pg, g8);
+              }
+              unpack16<T>(ua[i % AD][h], a);
+              unpack16<T>(ub[i % AD][h], b);
+              const uint32_t idx0 = (uint32_t)((row + i * 16) * F + col0 + h * 32);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float g = g8[e];
+                if constexpr (DROP) g = (p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? g * dscale : 0.f;
+                const float k = 0.7978845608028654f;
+                const float t = tanhf(k * (a[e] + 0.044715f * a[e] * a[e] * a[e]));
+                const float gel = 0.5f * a[e] * (1.f + t);
+                const float dgel = 0.5f * (1.f + t) + 0.5f * a[e] * (1.f - t * t) * k * (1.f + 3.f * 0.044715f * a[e] * a[e]);
+                d0[e] = g * b[e] * dgel;
+                d1[e] = g * gel;
+              }
+              o0[h] = pack16<T>(d0);
+              o1[h] = pack16<T>(d1);
+            }
+            if (i + AD < TM) u_load(i + AD);
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h) {
+              st16(dq + (size_t)i * 16 * ldc + h * 32, o0[h]);
+              st16(dq + (size_t)i * 16 * ldc + h * 32 + F, o1[h]);
+            }
+          }
+        };
+        if constexpr (GATE) {
+          if (epi == P5_EPI_GELU_GATE) { if (cx.do_drop) gate_fwd(P5EpiTag<1>{}); else gate_fwd(P5EpiTag<0>{}); return; }
+          if (epi == P5_EPI_GELU_GATE_BWD) { if (cx.do_drop) gate_bwd(P5EpiTag<1>{}); else gate_bwd(P5EpiTag<0>{}); return; }
+        }
         if (epi == P5_EPI_RELU_DROP) { if (cx.do_drop) all_rows(P5EpiTag<2>{}); else all_rows(P5EpiTag<1>{}); }
         else if (epi == P5_EPI_RESID_DROP) { if (cx.do_drop) all_rows(P5EpiTag<4>{}); else all_rows(P5EpiTag<3>{}); }
         else if (epi == P5_EPI_MASK_POS) all_rows(P5EpiTag<5>{});

@@ -25,6 +25,7 @@ int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;         
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
 int g_opt_split_pipe = getenv("P5_SPLIT_PIPE") ? atoi(getenv("P5_SPLIT_PIPE")) : 1;    // split-f16 fp32 GEMMs: the three-deep pipelined kernel (0 = p5_gemm_kernel<MM = 1>)
 int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 0;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them (0 = the fp32 rule: from 512; measured on the verification pass, 64x64 tiles win below that: 5.05 vs 5.30 ms per batch)
+int g_opt_gemm5_stagger = getenv("P5_GEMM5_STAGGER") ? atoi(getenv("P5_GEMM5_STAGGER")) : 0;   // KC instance: odd workgroups start their compute waves this many x ~0.4 us late
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -146,6 +147,7 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   }
   grp.unit_begin[grp.nprob] = units;
   grp.total_units = units;
+  grp.stagger = (!KS && units > g_opt_g4_wgs) ? g_opt_gemm5_stagger : 0;      // (only where every workgroup has at least two tiles)
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
   {
@@ -159,8 +161,17 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   P5_LAUNCH((p5_gemm5_kernel<KS, KS ? 0 : P5_GEMM5_ABL>), dim3(nwg), dim3(512), 0, s, grp);
 #else
   // (spelled out so that the in-run profiler's stringified kernel name says which instance ran, not "<KS>")
-  if constexpr (KS) P5_LAUNCH((p5_gemm5_kernel<true>), dim3(nwg), dim3(512), 0, s, grp);
-  else P5_LAUNCH((p5_gemm5_kernel<false>), dim3(nwg), dim3(512), 0, s, grp);
+  bool gate = false;
+  for (int i = 0; i < grp.nprob; ++i) gate = gate || grp.p[i].epi == P5_EPI_GELU_GATE || grp.p[i].epi == P5_EPI_GELU_GATE_BWD;
+  if constexpr (KS) {
+    P5_REQUIRE(!gate, "gemm5: the gated-GELU epilogues belong to the K-contiguous instance");
+    P5_LAUNCH((p5_gemm5_kernel<true>), dim3(nwg), dim3(512), 0, s, grp);
+  } else if (gate) {
+    P5_PROF_TAG("KC + gated-GELU epilogue");
+    P5_LAUNCH((p5_gemm5_kernel<false, 0, true>), dim3(nwg), dim3(512), 0, s, grp);
+  } else {
+    P5_LAUNCH((p5_gemm5_kernel<false>), dim3(nwg), dim3(512), 0, s, grp);
+  }
 #endif
   return P5_KCHECK();
 }
@@ -183,9 +194,25 @@ int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
   return launch_gemm4_cfg<128, 128, 2, 2, 5, false>(grp, s);
 }
 
+// the fused gated-GELU epilogues exist in the whole-tile path of p5_gemm5.h only: bf16, both operands K-contiguous, every 256x128 tile
+// inside the output, enough tiles for the wide route.  M rows, N GEMM columns (2F forward, F backward), K reduction length.
+bool p5l_gemm_gate_ok(int M, int N, int K, int lda, int ldb) {
+  return g_opt_gemm_wide && (g_opt_gemm_ws & 1) && !g_opt_gemm_tile && !g_opt_gemm_v2 && (M % 256) == 0 && (N % 128) == 0 && (K % 64) == 0 && (lda % 64) == 0 &&
+         (ldb % 64) == 0 && (long)(M / 256) * (N / 128) >= g_opt_gemm_wide_min_tiles;
+}
+
 template <class T>
 static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
   constexpr int EPF = TT<T>::EPF;
+  if (g.epi == P5_EPI_GELU_GATE || g.epi == P5_EPI_GELU_GATE_BWD) {
+    P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && !g.c_f32 && p5l_gemm_gate_ok(g.M, g.N, g.K, g.lda, g.ldb),
+               "gemm: the gated-GELU epilogues need the whole-tile path of the wide bf16 kernel (caller: check p5l_gemm_gate_ok)");
+    P5_REQUIRE((g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: gated-GELU epilogue output alignment");
+    if (g.epi == P5_EPI_GELU_GATE) P5_REQUIRE(g.C2 && g.gate_F * 2 == g.N && (g.ldc2 % 8) == 0 && ((uintptr_t)g.C2 % 16) == 0 && !g.ssq_out, "gemm: gated-GELU forward arguments");
+    else P5_REQUIRE(g.aux && (g.ldaux % 8) == 0 && ((uintptr_t)g.aux % 16) == 0 && !g.rowss && !g.ssq_out && g.gate_F == 0, "gemm: gated-GELU backward arguments");
+  } else {
+    g.C2 = nullptr; g.ldc2 = 0; g.gate_F = 0;
+  }
   P5_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem");
   P5_REQUIRE(g.lda % EPF == 0 && g.ldb % EPF == 0, "gemm: leading dims must be multiples of 16 bytes");
   P5_REQUIRE(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");

@@ -39,6 +39,7 @@ static int g_opt_dgrad_t = getenv("P5_DGRAD_T") ? atoi(getenv("P5_DGRAD_T")) : 1
 static int g_opt_dec_cross = getenv("P5_DEC_CROSS") ? atoi(getenv("P5_DEC_CROSS")) : 3;   // 3 = MFMA cross-attention, 2 = scalar score / PV loops
 static int g_opt_dec_head = getenv("P5_DEC_HEAD") ? atoi(getenv("P5_DEC_HEAD")) : 1;      // 1 = streaming head (no [R, V] logits), 0 = GEMM + score kernel
 static int g_opt_dec_atomic = getenv("P5_DEC_ATOMIC") ? atoi(getenv("P5_DEC_ATOMIC")) : 0;   // 1 = round-2..4 decode step: residual stream updated with fp32 atomics by K-split workgroups (not bit-reproducible)
+static int g_opt_adam_tiles = getenv("P5_ADAM_TILES") ? atoi(getenv("P5_ADAM_TILES")) : 1;       // p5_engine_adamw_step: tile-wise update that also writes W^T and W diag(ln)
 static int g_opt_gen_ff = getenv("P5_GEN_FF") ? atoi(getenv("P5_GEN_FF")) : 1;             // forced-prefix fast-forward (p5_decode.h): 0 = every step is a decode step
 static int g_opt_dec_head_nv = getenv("P5_DEC_HEAD_NV") ? atoi(getenv("P5_DEC_HEAD_NV")) : 0;   // streaming head: forced E rows per workgroup (0 = auto)
 
@@ -176,7 +177,7 @@ struct P5Engine {
   // transposed bf16 copies of the 2-D layer weights (same arena offsets): the data gradients dx = dy W then read W^T as a
   // K-contiguous operand, i.e. run on the forward kernel (p5_engine_bind_transposed; optional)
   void* St = nullptr;
-  struct TrDesc { int64_t off; int rows, cols, tile0; };
+  struct TrDesc { int64_t off; int rows, cols, tile0; int64_t ln_off; };
   std::vector<TrDesc> tr_list;
   int tr_tiles = 0;
   bool tr_pending = false;
@@ -335,18 +336,20 @@ static void build_layout(P5Engine* e) {
   {
     e->tr_list.clear();
     int tiles = 0;
-    auto add = [&](int64_t off, int rows, int cols) {
-      e->tr_list.push_back({off, rows, cols, tiles});
+    // (ln: the T5LayerNorm weight whose output the projection consumes -- the blocks p5_refresh_transposed folds -- or -1)
+    auto add = [&](int64_t off, int rows, int cols, int64_t ln = -1) {
+      e->tr_list.push_back({off, rows, cols, tiles, ln});
       tiles += ((rows + 63) / 64) * ((cols + 63) / 64);
     };
     const int wi_rows = (c.gated_gelu ? 2 : 1) * F;
     for (int i = 0; i < c.n_enc_layers; ++i) {
-      add(e->enc[i].sa.q, 3 * e->inner, d); add(e->enc[i].sa.o, d, e->inner); add(e->enc[i].wi, wi_rows, d); add(e->enc[i].wo, d, F);
+      add(e->enc[i].sa.q, 3 * e->inner, d, e->enc[i].sa.ln); add(e->enc[i].sa.o, d, e->inner); add(e->enc[i].wi, wi_rows, d, e->enc[i].ff_ln); add(e->enc[i].wo, d, F);
     }
     add(e->dec[0].ca.k, c.n_dec_layers * 2 * e->inner, d);
     for (int i = 0; i < c.n_dec_layers; ++i) {
-      add(e->dec[i].sa.q, 3 * e->inner, d); add(e->dec[i].sa.o, d, e->inner); add(e->dec[i].ca.q, e->inner, d); add(e->dec[i].ca.o, d, e->inner);
-      add(e->dec[i].wi, wi_rows, d); add(e->dec[i].wo, d, F);
+      add(e->dec[i].sa.q, 3 * e->inner, d, e->dec[i].sa.ln); add(e->dec[i].sa.o, d, e->inner); add(e->dec[i].ca.q, e->inner, d, e->dec[i].ca.ln);
+      add(e->dec[i].ca.o, d, e->inner);
+      add(e->dec[i].wi, wi_rows, d, e->dec[i].ff_ln); add(e->dec[i].wo, d, F);
     }
     e->tr_tiles = tiles;
   }
@@ -395,6 +398,7 @@ static int gemm(hipStream_t s, const void* A, int lda, int aks, const void* Bm, 
                 int K, int epi, const void* aux, int ldaux, float alpha, int c_f32, P5Drop drop, const float* rowss = nullptr,
                 float rowss_eps = 0.f, float* ssq_out = nullptr) {
   P5GemmArgs g;
+  memset(&g, 0, sizeof(g));
   g.A = A; g.B = Bm; g.C = C; g.aux = aux; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.a_ks = aks; g.b_ks = bks; g.epi = epi; g.c_f32 = c_f32; g.splitk = 0; g.ring = 0; g.alpha = alpha; g.drop = drop;
   g.rowss = rowss; g.rowss_invd = 1.0f / (float)K; g.rowss_eps = rowss_eps; g.ssq_out = ssq_out;
@@ -711,13 +715,29 @@ template <class T> static bool norm_fused(const P5Engine* e) {
 template <class T> static const T* Wnf(const P5Engine* e, int64_t off) { return (const T*)((const bf16*)e->Sf + off); }
 
 // xout = x_ff + drop(wo(act(wi(norm(x_ff)))));  ssq_next: where to leave the statistics of xout (fused mode)
+// gated-GELU FFN (T5 v1.1; HF modeling_t5.py:97-123): the gate runs in the epilogue of the wi GEMM (forward) / of the wo data-gradient GEMM
+// (backward) wherever those GEMMs take the wide whole-tile path (p5_gemm5.h: bf16, rows % 256 == 0, >= 160 tiles); elsewhere -- the
+// decoder's 512 rows, fp32 parity mode, ragged batches -- the stand-alone p5_gated_gelu_fwd / _bwd kernels.  Option "gate_fuse" 0 = never.
+static int g_opt_gate_fuse = getenv("P5_GATE_FUSE") ? atoi(getenv("P5_GATE_FUSE")) : 1;
+template <class T> static bool gate_fused(int rows, int N, int K) {
+  return sizeof(T) == 2 && g_opt_gate_fuse != 0 && p5l_gemm_gate_ok(rows, N, K, K, K);
+}
 template <class T>
 static int ffn_fwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, void* xout, int rows, int stack, int li, float* ssq_next) {
   const P5Config& c = e->c;
   const int d = c.d_model, F = c.d_ff;
   const bool nf = norm_fused<T>(e);
   if (!nf) P5_TRY(rmsnorm_fwd<T>(s, l.n_ff, l.rstd_ff, l.x_ff, e->P + lo.ff_ln, rows, d, c.eps, no_drop()));
-  if (c.gated_gelu) {
+  if (c.gated_gelu && gate_fused<T>(rows, 2 * F, d)) {
+    // h = drop(gelu_new(u0) * u1) in the epilogue of ONE GEMM over [wi_0; wi_1] (rows read gate-interleaved), u kept for the backward
+    P5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = nf ? l.x_ff : l.n_ff; g.B = nf ? Wnf<T>(e, lo.wi) : Wc<T>(e, lo.wi); g.C = l.h_ff; g.C2 = l.u_ff;
+    g.M = rows; g.N = 2 * F; g.K = d; g.lda = d; g.ldb = d; g.ldc = F; g.ldc2 = 2 * F; g.gate_F = F;
+    g.epi = P5_EPI_GELU_GATE; g.alpha = 1.f; g.drop = mk_drop(e, stack, li, 5);
+    if (nf) { g.rowss = l.ssq_ff; g.rowss_invd = 1.0f / (float)d; g.rowss_eps = c.eps; g.rowss_nt = d / 64; }
+    P5_TRY(launch_gemm<T>(g, s));
+  } else if (c.gated_gelu) {
     if (nf) P5_TRY(gemm_nf<T>(s, l.x_ff, d, Wnf<T>(e, lo.wi), d, l.u_ff, 2 * F, rows, 2 * F, d, P5_EPI_STORE, nullptr, 0, no_drop(), l.ssq_ff, c.eps, nullptr, d));
     else P5_TRY(linear_fwd<T>(s, l.n_ff, d, Wc<T>(e, lo.wi), l.u_ff, 2 * F, rows, 2 * F, d));
     const size_t n = (size_t)rows * F;
@@ -859,11 +879,21 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
   const float hscale = (e->training && c.dropout > 0.f) ? 1.f / (1.f - c.dropout) : 1.f;
   P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
   if (c.gated_gelu) {
-    P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.wo, e->dh, F, rows, d, F));
-    const size_t n = (size_t)rows * F;
-    P5_LAUNCH((p5_gated_gelu_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
-              (T*)e->du, (const T*)e->dh, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
-    P5_TRY(P5_KCHECK());
+    if (sizeof(T) == 2 && e->St && g_opt_dgrad_t && gate_fused<T>(rows, F, d)) {
+      // dh = dy Wo never reaches memory: the epilogue of the data-gradient GEMM (on the transposed weight copy) writes du
+      P5GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = e->dy; g.B = (const T*)e->St + lo.wo; g.C = e->du; g.aux = l.u_ff;
+      g.M = rows; g.N = F; g.K = d; g.lda = d; g.ldb = d; g.ldc = 2 * F; g.ldaux = 2 * F;
+      g.epi = P5_EPI_GELU_GATE_BWD; g.alpha = 1.f; g.drop = mk_drop(e, stack, li, 5);
+      P5_TRY(launch_gemm<T>(g, s));
+    } else {
+      P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.wo, e->dh, F, rows, d, F));
+      const size_t n = (size_t)rows * F;
+      P5_LAUNCH((p5_gated_gelu_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s,
+                (T*)e->du, (const T*)e->dh, (const T*)l.u_ff, rows, F, mk_drop(e, stack, li, 5));
+      P5_TRY(P5_KCHECK());
+    }
     P5_TRY(linear_wgrad<T>(e, s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
     P5_TRY(dgrad_w<T>(e, s, e->du, 2 * F, lo.wi, e->dn, d, rows, 2 * F, d));
   } else {
@@ -1856,7 +1886,7 @@ __global__ __launch_bounds__(256) void p5_fold_rows_kernel(bf16* __restrict__ ou
 }
 
 // out[c, r] = in[r, c] for every [rows, cols] block of the descriptor table (64 x 64 tiles through LDS, 16-byte row accesses)
-struct P5TrDesc { int64_t off; int rows, cols, tile0; };
+struct P5TrDesc { int64_t off; int rows, cols, tile0; int64_t ln_off; };      // ln_off >= 0: the T5LayerNorm weight folded into this block's copy (W diag(ln)), else -1
 __global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restrict__ out, const bf16* __restrict__ in, const P5TrDesc* __restrict__ tab,
                                                                  int ndesc) {
   __shared__ unsigned short tile[64][66];
@@ -1888,6 +1918,133 @@ __global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restri
       for (int q = 0; q < 4; ++q) v[q] = (unsigned)tile[p + 2 * q][c] | ((unsigned)tile[p + 2 * q + 1][c] << 16);
       st16(dst + (size_t)(c0 + c) * dsc.rows + r0 + p, v);
     }
+  }
+}
+
+// ---- clip + HF-AdamW over the arena that ALSO writes every bf16 copy the next step reads (round 6) --------------------------------------
+// p5_adamw_kernel streams the flat arena and writes the bf16 shadow; the transposed copy W^T (data gradients) and the norm-folded copy
+// W diag(ln) (training forward) were then rebuilt by two more launches that re-read what the update had just held in registers
+// (p5_transpose_blocks_kernel + p5_fold_rows_kernel: 0.27 GB, ~80 us of the T5-small step).  Here the 2-D layer weights are updated tile by
+// tile (the 64 x 64 tiles of the transpose table): a workgroup updates p / m / v of its tile, writes the shadow rows, transposes the bf16
+// tile through LDS into W^T, and -- for a projection behind a T5LayerNorm -- multiplies by the NEW norm weight, which it derives itself from
+// that weight's old state (64 columns: the same update formula on values nobody has overwritten yet; the norm weights themselves are
+// updated by a second, tiny launch ordered behind this one).  Blocks past the tiles update the leading range of the arena (tied embedding,
+// whole-word table, relative-bias tables) flat.  Same arithmetic per element as p5_adamw_kernel: bit-identical parameters and copies.
+struct P5AdamTileArgs {
+  P5AdamArgs a;
+  const P5TrDesc* tab;
+  int ndesc, ntiles;
+  bf16* St; bf16* Sf;           // transposed / norm-folded copies (arena offsets), Sf may be null
+  size_t flat_n;                // [0, flat_n): flat update by the blocks behind the tiles
+};
+__device__ static __forceinline__ float p5_adam_clip_coef(const P5AdamArgs& a, float* sp) {
+  float coef = a.grad_scale;
+  if (a.sumsq) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < P5_SUMSQ_PARTS; i += 256) t += a.sumsq[i];      // (the association of p5_adamw_kernel: same bits)
+    sp[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if ((int)threadIdx.x < st) sp[threadIdx.x] += sp[threadIdx.x + st];
+      __syncthreads();
+    }
+    const float norm = sqrtf(sp[0]) * a.grad_scale;
+    const float c = a.max_norm / (norm + 1e-6f);
+    coef *= (c < 1.f ? c : 1.f);
+  }
+  return coef;
+}
+__device__ static __forceinline__ float p5_adam_update(const P5AdamArgs& a, float coef, float p, float g0, float& m, float& v) {
+  const float g = g0 * coef;
+  m = a.beta1 * m + a.omb1 * g;
+  v = a.beta2 * v + a.omb2 * g * g;
+  p = p - a.step_size * (m / (sqrtf(v) + a.eps));
+  p = p - a.decay * p;
+  return p;
+}
+__global__ __launch_bounds__(256) void p5_adamw_tiles_kernel(P5AdamTileArgs t) {
+  __shared__ float sp[256];
+  __shared__ unsigned short tile[64][66];
+  const P5AdamArgs& a = t.a;
+  const float coef = p5_adam_clip_coef(a, sp);
+  const int b = blockIdx.x;
+  if (b >= t.ntiles) {                       // ---- flat leading range
+    const size_t nb = gridDim.x - t.ntiles;
+    for (size_t i = (size_t)(b - t.ntiles) * 256 + threadIdx.x; i < t.flat_n; i += nb * 256) {
+      float m = a.m[i], v = a.v[i];
+      const float p = p5_adam_update(a, coef, a.p[i], a.g[i], m, v);
+      a.m[i] = m; a.v[i] = v; a.p[i] = p;
+      if (a.shadow) ((bf16*)a.shadow)[i] = from_f<bf16>(p);
+    }
+    return;
+  }
+  int lo = 0, hi = t.ndesc - 1;              // last descriptor with tile0 <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.tab[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const P5TrDesc dsc = t.tab[lo];
+  const int tc = (dsc.cols + 63) / 64;
+  const int lt = b - dsc.tile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
+  const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;       // 4 threads per row, 16 columns each (cols % 8 == 0)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = c0 + cq + h * 8;
+    const bool ok = r0 + r < dsc.rows && c < dsc.cols;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    if (ok) {
+      const size_t i0 = (size_t)dsc.off + (size_t)(r0 + r) * dsc.cols + c;
+      float p[8], g[8], m[8], v[8];
+      ldf<8>(a.p + i0, p); ldf<8>(a.g + i0, g); ldf<8>(a.m + i0, m); ldf<8>(a.v + i0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = p5_adam_update(a, coef, p[e], g[e], m[e], v[e]);
+      stf<8>(a.p + i0, o); stf<8>(a.m + i0, m); stf<8>(a.v + i0, v);
+      const u32x4 pk = pack16<bf16>(o);
+      if (a.shadow) st16((bf16*)a.shadow + i0, pk);
+      if (t.Sf && dsc.ln_off >= 0) {
+        // the norm weight AFTER this step, from its state before it (the launch that updates it runs behind this one)
+        const size_t l0 = (size_t)dsc.ln_off + c;
+        float lp[8], lg[8], lm[8], lv[8], f[8];
+        ldf<8>(a.p + l0, lp); ldf<8>(a.g + l0, lg); ldf<8>(a.m + l0, lm); ldf<8>(a.v + l0, lv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = o[e] * p5_adam_update(a, coef, lp[e], lg[e], lm[e], lv[e]);
+        st16(t.Sf + i0, pack16<bf16>(f));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { tile[r][cq + h * 8 + 2 * q] = (unsigned short)(pk[q] & 0xFFFF); tile[r][cq + h * 8 + 2 * q + 1] = (unsigned short)(pk[q] >> 16); }
+    }
+  }
+  __syncthreads();
+  unsigned short* dst = (unsigned short*)t.St + dsc.off;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {        // 64 output rows (= input columns) x 8 pieces, as p5_transpose_blocks_kernel
+    const int c = i >> 3, p8 = (i & 7) * 8;
+    if (c0 + c < dsc.cols && r0 + p8 < dsc.rows) {
+      u32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (unsigned)tile[p8 + 2 * q][c] | ((unsigned)tile[p8 + 2 * q + 1][c] << 16);
+      st16(dst + (size_t)(c0 + c) * dsc.rows + r0 + p8, v);
+    }
+  }
+}
+// the parameters the tiles and the leading range do not cover: the T5LayerNorm weights (one segment each), updated LAST
+__global__ __launch_bounds__(256) void p5_adamw_segments_kernel(P5AdamArgs a, P5ZeroTab tab) {
+  __shared__ float sp[256];
+  const float coef = p5_adam_clip_coef(a, sp);
+  const int b = blockIdx.x;
+  int lo = 0, hi = tab.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab.e[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const int i0 = (b - tab.e[lo].blk0) * 8192, n = tab.e[lo].count;
+  for (int j = i0 + threadIdx.x; j < i0 + 8192 && j < n; j += 256) {
+    const size_t i = (size_t)tab.e[lo].off + j;
+    float m = a.m[i], v = a.v[i];
+    const float p = p5_adam_update(a, coef, a.p[i], a.g[i], m, v);
+    a.m[i] = m; a.v[i] = v; a.p[i] = p;
+    if (a.shadow) ((bf16*)a.shadow)[i] = from_f<bf16>(p);
   }
 }
 
@@ -1931,6 +2088,9 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
+  else if (!strcmp(name, "gemm5_stagger")) g_opt_gemm5_stagger = value;
+  else if (!strcmp(name, "gate_fuse")) g_opt_gate_fuse = value;
+  else if (!strcmp(name, "adam_tiles")) g_opt_adam_tiles = value;
   else if (!strcmp(name, "gemm_wide_min_tiles")) g_opt_gemm_wide_min_tiles = value;
   else if (!strcmp(name, "gemm_ring128_min_k")) g_opt_gemm_ring128_min_k = value;
   else if (!strcmp(name, "gemm_ring128_min_tiles")) g_opt_gemm_ring128_min_tiles = value;
@@ -2071,7 +2231,7 @@ int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream) {
   P5_REQUIRE(e->c.dtype == 1, "the transposed weight copy serves the bf16 mode only");
   // the descriptor table lives behind the copy itself (the library allocates nothing)
   std::vector<P5TrDesc> tab;
-  for (auto& t : e->tr_list) tab.push_back({t.off, t.rows, t.cols, t.tile0});
+  for (auto& t : e->tr_list) tab.push_back({t.off, t.rows, t.cols, t.tile0, t.ln_off});
   char* at = (char*)buf + tr_table_off(e);
   e->Sf = (char*)buf + tr_fold_off(e);
 #ifndef P5_EMU
@@ -2081,6 +2241,51 @@ int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream) {
 #else
   memcpy(at, tab.data(), tab.size() * sizeof(P5TrDesc));
 #endif
+  return 0;
+}
+// clip + AdamW over the ENGINE's arenas; with the transposed / folded copies bound (bf16 training) the update writes them too and the
+// caller need not call p5_refresh_transposed.  *copies_fresh = 1 when it did.  Otherwise identical to p5_adamw_step(P, G, m, v, S, n, ...).
+int p5_engine_adamw_step(P5Engine* e, float* m, float* v, const float* sumsq, double max_norm, double grad_scale, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, int step_t, int* copies_fresh, void* stream) {
+  P5_REQUIRE(e->P && e->G && m && v, "p5_engine_adamw_step: arenas not bound");
+  if (copies_fresh) *copies_fresh = 0;
+  const bool tiles = g_opt_adam_tiles != 0 && e->c.dtype == 1 && e->St && e->S && !e->side;
+  if (!tiles) return p5_adamw_step(e->P, e->G, m, v, e->S, e->n_params, sumsq, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step_t, stream);
+  P5AdamTileArgs t;
+  P5AdamArgs& a = t.a;
+  a.p = e->P; a.g = e->G; a.m = m; a.v = v; a.shadow = e->S; a.sumsq = sumsq; a.n = (size_t)e->n_params;
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps; a.max_norm = (float)max_norm; a.grad_scale = (float)grad_scale;
+  const double bc1 = 1.0 - pow(beta1, (double)step_t), bc2 = 1.0 - pow(beta2, (double)step_t);
+  a.step_size = (float)(lr * sqrt(bc2) / bc1);
+  a.decay = (float)(lr * weight_decay);
+  t.tab = (const P5TrDesc*)((char*)e->St + tr_table_off(e));
+  t.ndesc = (int)e->tr_list.size(); t.ntiles = e->tr_tiles;
+  t.St = (bf16*)e->St; t.Sf = (bf16*)e->Sf;
+  t.flat_n = (size_t)e->off_small_end;
+  hipStream_t s = (hipStream_t)stream;
+  P5_LAUNCH(p5_adamw_tiles_kernel, dim3(e->tr_tiles + 1024), dim3(256), 0, s, t);
+  P5_TRY(P5_KCHECK());
+  {
+    const P5Config& c = e->c;
+    P5ZeroTab tab;
+    tab.n = 0;
+    int blocks = 0;
+    auto add = [&](int64_t off, int64_t count) {
+      P5ZeroTab::D& q = tab.e[tab.n++];
+      q.off = off; q.count = (int)count; q.blk0 = blocks;
+      blocks += (int)((count + 8191) / 8192);
+    };
+    P5_REQUIRE(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2 < 200, "p5_engine_adamw_step: too many norm segments");
+    for (const LayerOff& l : e->enc) { add(l.sa.ln, c.d_model); add(l.ff_ln, c.d_model); }
+    for (const LayerOff& l : e->dec) { add(l.sa.ln, c.d_model); add(l.ca.ln, c.d_model); add(l.ff_ln, c.d_model); }
+    add(e->off_enc_fln, c.d_model);
+    add(e->off_dec_fln, c.d_model);
+    P5_LAUNCH(p5_adamw_segments_kernel, dim3(blocks), dim3(256), 0, s, a, tab);
+    P5_TRY(P5_KCHECK());
+  }
+  e->tr_pending = false;       // (same stream as the next forward / backward: nothing to wait for)
+  if (copies_fresh) *copies_fresh = 1;
   return 0;
 }
 // Rebuild the transposed copy from the bf16 shadow (call after every parameter update, e.g. right after p5_adamw_step).  With a
@@ -2548,6 +2753,11 @@ int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs
     g.a_ks = ks; g.b_ks = ks; g.epi = q.epi; g.c_f32 = q.c_f32; g.splitk = q.splitk; g.alpha = q.alpha; g.drop = op_drop(rng_state, site, drop_p);
     g.rowss = q.rowss; g.rowss_invd = q.rowss ? 1.0f / (float)q.K : 0.f; g.rowss_eps = q.rowss_eps; g.ssq_out = q.ssq_out;
     g.rowss_nt = q.rowss_nt; g.ssq_nt = q.ssq_nt;
+    g.C2 = q.C2; g.ldc2 = q.ldc2; g.gate_F = q.gate_F;
+    if (q.epi == P5_EPI_GELU_GATE || q.epi == P5_EPI_GELU_GATE_BWD)
+      P5_REQUIRE(tile_cfg == P5_G4_256x128 && !ks && (g_opt_gemm_ws & 1) && (q.M % 256) == 0 && (q.N % 128) == 0 && !q.c_f32 &&
+                 (q.epi == P5_EPI_GELU_GATE ? (q.C2 && q.gate_F * 2 == q.N) : (q.aux && q.gate_F == 0)),
+                 "gemm_group: the gated-GELU epilogues run on whole 256x128 tiles of the wave-specialised kernel (tile_cfg 1, ks 0)");
   }
   return launch_gemm4(tile_cfg, ks != 0, grp, (hipStream_t)stream);
 }

@@ -321,11 +321,12 @@ class P5T5Native(nn.Module):
             self._be.check(self._lib.p5_refresh_decode_fold(self._engine, self._be.stream_ptr()), "p5_refresh_decode_fold")
             self._fold_dirty = False
 
-    def mark_params_updated(self, shadow_fresh: bool = False):
-        """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow itself)."""
+    def mark_params_updated(self, shadow_fresh: bool = False, copies_fresh: bool = False):
+        """Call after writing parameters outside the fused optimizer (which refreshes the bf16 shadow -- and, `copies_fresh`, the transposed
+        and norm-folded copies -- itself)."""
         self._shadow_dirty = not shadow_fresh
         self._fold_dirty = True; self._mark_lanes_dirty()
-        self._tr_dirty = True
+        self._tr_dirty = not (copies_fresh and shadow_fresh)
 
     def _sync_transposed(self):
         """W^T of the layer weights for the next backward, and W diag(ln) of the projections behind a T5LayerNorm for the next forward

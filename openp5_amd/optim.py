@@ -56,10 +56,12 @@ class FusedAdamW:
         use_clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if use_clip:
             be.check(lib.p5_grad_sumsq(P(mdl._grads), mdl._n, P(self.sumsq), sp), "p5_grad_sumsq")
-        be.check(lib.p5_adamw_step(P(mdl._flat), P(mdl._grads), P(self.m), P(self.v), P(mdl._shadow), mdl._n,
-                                   P(self.sumsq) if use_clip else None, float(self.max_grad_norm or 0.0), 1.0 / (world * max(1, int(grad_accum))),
-                                   float(self.current_lr()), self.betas[0], self.betas[1], self.eps, self.wd, self.t, sp), "p5_adamw_step")
-        mdl.mark_params_updated(shadow_fresh=mdl._shadow is not None)
+        # over the engine's own arenas: with the transposed / norm-folded bf16 copies bound the update writes them as well (csrc: p5_adamw_tiles_kernel)
+        fresh = ctypes.c_int(0)
+        be.check(lib.p5_engine_adamw_step(mdl._engine, P(self.m), P(self.v), P(self.sumsq) if use_clip else None, float(self.max_grad_norm or 0.0),
+                                          1.0 / (world * max(1, int(grad_accum))), float(self.current_lr()), self.betas[0], self.betas[1], self.eps, self.wd,
+                                          self.t, ctypes.byref(fresh), sp), "p5_engine_adamw_step")
+        mdl.mark_params_updated(shadow_fresh=mdl._shadow is not None, copies_fresh=bool(fresh.value))
         self.sched_steps += 1   # scheduler.step() (DistributedRunner.py:86)
 
     def zero_grad(self, set_to_none=True):

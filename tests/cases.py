@@ -206,6 +206,77 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0,
     return worst
 
 
+def _gelu_new(a):
+    return 0.5 * a * (1.0 + torch.tanh(0.7978845608028654 * (a + 0.044715 * a ** 3)))
+
+
+def gemm_gate_case(be, M, F, K, drop_p=0.0, stats_nt=0, seed=0):
+    """Gated-GELU FFN (T5 v1.1, HF modeling_t5.py:97-123) fused into the GEMMs around it (p5_gemm5.h whole-tile epilogues).
+    Forward (epi 5): ONE GEMM over [wi_0; wi_1] writes u = [u0 | u1] and h = dropout(gelu_new(u0) * u1); backward (epi 7): the data-gradient
+    GEMM dh = dy Wo writes du = [dh' u1 gelu'(u0) | dh' gelu(u0)] with dh' = dh under h's dropout mask.  Against plain torch."""
+    from openp5_amd._abi import P5GemmProblem
+    g = torch.Generator().manual_seed(seed)
+    tt = torch.bfloat16
+    rng = dev(be, torch.tensor([77, 3], dtype=torch.int32)) if drop_p > 0 else None
+    keepm = O.dropout_keep_mask((77 + 3 * 0x632BE5AB) & 0xFFFFFFFF, 5, M * F, drop_p).view(M, F) if drop_p > 0 else None
+    bf = lambda t: t.to(tt).float()      # noqa: E731
+    # ---- forward
+    A = torch.randn(M, K, generator=g).to(tt)
+    W = (torch.randn(2 * F, K, generator=g) / K ** 0.5).to(tt)
+    pre = A.float() @ W.float().t()
+    arr = (P5GemmProblem * 1)()
+    q = arr[0]
+    Ad, Wd = dev(be, A), dev(be, W)
+    hd = dev(be, torch.full((M, F), float("nan")).to(tt))
+    ud = dev(be, torch.full((M, 2 * F), float("nan")).to(tt))
+    keep = [Ad, Wd, hd, ud]
+    q.A, q.B, q.C, q.aux, q.C2 = Ad.data_ptr(), Wd.data_ptr(), hd.data_ptr(), None, ud.data_ptr()
+    q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux, q.ldc2, q.gate_F = M, 2 * F, K, K, K, F, 0, 2 * F, F
+    q.epi, q.c_f32, q.splitk, q.alpha = 5, 0, 1, 1.0
+    q.rowss, q.rowss_eps, q.ssq_out, q.rowss_nt, q.ssq_nt = None, 0.0, None, 0, 0
+    if stats_nt > 0:
+        part = (torch.rand(M, stats_nt, generator=g) * (2.0 * K / stats_nt)).float()
+        ssum = torch.zeros(M)
+        for t in range(stats_nt):
+            ssum = ssum + part[:, t]
+        pre = pre * torch.rsqrt(ssum / K + 1e-6)[:, None]
+        partd = dev(be, part)
+        keep.append(partd)
+        q.rowss, q.rowss_eps, q.rowss_nt = partd.data_ptr(), 1e-6, stats_nt
+    be.check(be.lib.p5_op_gemm_group(1, 0, 1, arr, P(rng), 5, drop_p, be.stream_ptr()), "gemm_group (gate fwd)")
+    sync(be)
+    u_got, h_got = ud.cpu().float(), hd.cpu().float()
+    assert (u_got - pre).abs().max().item() <= 2e-2 * max(1.0, float(pre.abs().max())), "gate fwd: stored u"
+    h_ref = _gelu_new(u_got[:, :F]) * u_got[:, F:]            # the gate of the STORED (rounded) u, as the stand-alone kernel computes it
+    if keepm is not None:
+        h_ref = torch.where(keepm, h_ref / (1 - drop_p), torch.zeros_like(h_ref))
+    err_h = (h_got - bf(h_ref)).abs().max().item()
+    assert err_h <= 1.6e-2 * max(1.0, float(h_ref.abs().max())), f"gate fwd: h off by {err_h}"      # (one bf16 rounding of a value near the max)
+    assert torch.equal(h_got == 0, bf(h_ref) == 0) or keepm is None, "gate fwd: dropout mask"
+    # ---- backward
+    dy = torch.randn(M, K, generator=g).to(tt)
+    WoT = (torch.randn(F, K, generator=g) / K ** 0.5).to(tt)
+    u = torch.randn(M, 2 * F, generator=g).to(tt)
+    dh = bf(dy.float() @ WoT.float().t())
+    if keepm is not None:
+        dh = torch.where(keepm, dh / (1 - drop_p), torch.zeros_like(dh))
+    a, b = u[:, :F].float().requires_grad_(True), u[:, F:].float().requires_grad_(True)
+    (_gelu_new(a) * b).backward(dh)
+    du_ref = torch.cat([a.grad, b.grad], 1)
+    dyd, Wod, uq = dev(be, dy), dev(be, WoT), dev(be, u)
+    dud = dev(be, torch.full((M, 2 * F), float("nan")).to(tt))
+    keep += [dyd, Wod, uq, dud]
+    q.A, q.B, q.C, q.aux, q.C2 = dyd.data_ptr(), Wod.data_ptr(), dud.data_ptr(), uq.data_ptr(), None
+    q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ldaux, q.ldc2, q.gate_F = M, F, K, K, K, 2 * F, 2 * F, 0, 0
+    q.epi = 7
+    q.rowss, q.rowss_eps, q.rowss_nt = None, 0.0, 0
+    be.check(be.lib.p5_op_gemm_group(1, 0, 1, arr, P(rng), 5, drop_p, be.stream_ptr()), "gemm_group (gate bwd)")
+    sync(be)
+    err_d = (dud.cpu().float() - du_ref).abs().max().item()
+    assert err_d <= 2e-2 * max(1.0, float(du_ref.abs().max())), f"gate bwd: du off by {err_d}"
+    return err_h, err_d
+
+
 def gemm_v2_case(be, stages, M, N, K, epi, tile=128, ks=0):
     lib = be.lib
     try:
@@ -907,6 +978,37 @@ def adamw_golden_case(be, tol=2e-6):
             assert err <= tol, (t, name, err)
         assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16)), "the bf16 compute shadow is the updated master value rounded once"
     return worst
+
+
+def adamw_tiles_case(be, ocfg, steps=3, seed=11):
+    """p5_engine_adamw_step's tile-wise update (the AdamW pass writes the transposed copy W^T and the norm-folded copy W diag(ln) itself,
+    csrc p5_adamw_tiles_kernel) against the flat update followed by p5_refresh_transposed: parameters, both moments, the bf16 shadow and the
+    whole transposed / folded buffer bit-identical after several steps (so the norm weights' moments are non-trivial when they are re-derived)."""
+    from openp5_amd.optim import FusedAdamW
+    out = {}
+    for tiles in (1, 0):
+        be.check(be.lib.p5_set_option(b"adam_tiles", tiles), "opt")
+        try:
+            m = build_model(be, ocfg, O.init_params(ocfg, 7), "bf16")
+            opt = FusedAdamW(m, lr=1e-2, eps=1e-6, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=1, total_steps=10)
+            g = torch.Generator().manual_seed(seed)
+            m._sync_shadow(); m._sync_transposed()
+            for st in range(steps):
+                m._grads.copy_(dev(be, torch.randn(m._grads.numel(), generator=g) * (0.05 if st % 2 else 2.0)))
+                m._grads_dead = False
+                opt.step()
+                assert m._tr_dirty == (tiles == 0), "the tile-wise step leaves the copies fresh, the flat one does not"
+                m._sync_shadow(); m._sync_transposed()
+            sync(be)
+            nb = 2 * int(m._n)
+            fold_off = int(be.lib.p5_transposed_bytes(m._engine)) - nb - 256       # (the descriptor table in between has uninitialised padding bytes)
+            out[tiles] = [t.detach().cpu().clone() for t in (m._flat, opt.m, opt.v, m._shadow.view(torch.int16), m._shadow_t[:nb],
+                                                              m._shadow_t[fold_off:fold_off + nb])]
+        finally:
+            be.lib.p5_set_option(b"adam_tiles", 1)
+    for name, a, b in zip(("params", "m", "v", "shadow", "transposed copy", "norm-folded copy"), out[1], out[0]):
+        assert torch.equal(a, b), f"tile-wise AdamW differs from flat AdamW + refresh in {name}: {(a != b).sum().item()} elements"
+    return True
 
 
 def bf16_training_converges_case(be, steps=40):

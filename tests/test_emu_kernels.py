@@ -330,8 +330,19 @@ def test_generate_verified_split_range_guard(emu):
     cases.generate_verified_overflow_case(emu, O.T5Cfg.named("tiny"))
 
 
+@pytest.mark.parametrize("act", ["relu", "gated-gelu"])
+def test_adamw_tiles_write_every_copy(emu, act):
+    cases.adamw_tiles_case(emu, O.T5Cfg.named("tiny", ff_act=act))
+
+
 def test_adamw_kernel_matches_published_426_fixture(emu):
     print("[adamw golden] worst relative error", cases.adamw_golden_case(emu))
+
+
+@pytest.mark.parametrize("drop_p,stats_nt", [(0.0, 0), (0.1, 4)])
+def test_gemm_gated_gelu_epilogues(emu, drop_p, stats_nt):
+    """north_star "fused RMSNorm+GatedGeLU": the gate in the epilogue of the wi GEMM / of the wo data-gradient GEMM (p5_gemm5.h)."""
+    print("[gate epilogues]", cases.gemm_gate_case(emu, 256, 128, 64, drop_p=drop_p, stats_nt=stats_nt))
 
 
 def test_generate_draft_mode_is_the_plain_bf16_search(emu):
