@@ -463,6 +463,46 @@ __global__ __launch_bounds__(256) void p5_ce_fwd_kernel(float* __restrict__ nll,
   }
 }
 
+// Logit-free cross-entropy, second half of the forward: the head GEMM's epilogue (p5_gemm5.h, P5_EPI_CE_STATS) left, per row,
+// `np` pairs (max, sum of exp) -- one per 64 vocabulary columns -- and the logit at the label; one wave per row merges them in index order:
+// lse = M + log(sum_k s_k exp(m_k - M)), nll = lse - logit[label]  (P5_T5.py:368-369, reduction "none"; ignore_index -100 -> 0).
+template <class T>
+__global__ __launch_bounds__(256) void p5_ce_finish_kernel(float* __restrict__ nll, float* __restrict__ lse_out, const float* __restrict__ part,
+                                                          const float* __restrict__ lab_logit, const int64_t* __restrict__ labels, int rows, int np) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = part + (size_t)row * np * 2;
+  float m = P5_NEG_INF;
+  for (int k = lane; k < np; k += 64) m = fmaxf(m, pr[2 * k]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int k = lane; k < np; k += 64) s += pr[2 * k + 1] * p5_exp<T>(pr[2 * k] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float lse = m + logf(s);
+    lse_out[row] = lse;
+    const int64_t lab = labels[row];
+    nll[row] = (lab == -100) ? 0.f : lse - lab_logit[row];
+  }
+}
+// g[row] = gradient of the row's NLL: dnll[row] (autograd), or the runner's masked-mean loss (p5_ce_bwd_kernel's rule), 0 for ignored labels
+__global__ __launch_bounds__(256) void p5_ce_gscale_kernel(float* __restrict__ g_out, const int64_t* __restrict__ labels, const float* __restrict__ dnll,
+                                                          const int64_t* __restrict__ out_attn, int Tlen, float gscale, int rows) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float g;
+  if (dnll) {
+    g = dnll[row];
+  } else {
+    const int b = row / Tlen;
+    float cnt = 0.f;
+    for (int t = 0; t < Tlen; ++t) cnt += out_attn[(size_t)b * Tlen + t] != 0 ? 1.f : 0.f;
+    g = out_attn[row] != 0 ? gscale / fmaxf(cnt, 1.f) : 0.f;
+  }
+  if (labels[row] == -100) g = 0.f;
+  g_out[row] = g;
+}
+
 // Runner loss behind the CE kernel (DistributedRunner.py:72-77):
 //   loss = mean_b( sum_t nll[b,t] * m[b,t] / max(sum_t m[b,t], 1) ),  m = (output_attention != 0)
 // one workgroup, fixed summation order (deterministic): thread i owns batch rows i, i+256, ...

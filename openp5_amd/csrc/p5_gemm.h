@@ -30,6 +30,9 @@ enum P5Epi : int {
                           // (P5GemmArgs::gate_F), C = h = drop(gelu_new(u0) * u1) [M, F], C2 = u = [u0 | u1] [M, 2F] kept for the backward
                           // (p5_gemm5.h whole-tile epilogue only: bf16, M % 256 == 0, N = 2F, N % 128 == 0)
   P5_EPI_ACCUM = 6,       // C += acc * alpha  (fp32, exclusive ownership: no split-K)
+  P5_EPI_CE_STATS = 8,    // logit-free cross-entropy, forward (P5_T5.py:361-369): nothing is stored but, per row and 64-column group,
+                          // (max, sum of exp) of acc * alpha, and the logit at the row's label -> P5GemmArgs::ce_part / ce_lab (p5_gemm5.h)
+  P5_EPI_CE_GRAD = 9,     // ... backward: the same GEMM recomputed, C = dlogits = (exp(acc * alpha - lse[row]) - [col == label]) * g[row]
   P5_EPI_GELU_GATE_BWD = 7,   // gated-GELU backward fused into the wo data-gradient GEMM: acc = dh [M, F], aux = u [M, 2F] (ldaux), C = du =
                               // [dh u1 gelu'(u0) | dh gelu(u0)] [M, 2F] (ldc); the dropout mask of h is re-hashed (same conditions as above, N = F)
 };
@@ -68,6 +71,12 @@ struct P5GemmArgs {
   // 8-column groups of a 64-column wave tile are u0 and u1 of the SAME eight hidden units
   void* C2;
   int ldc2, gate_F;
+  // logit-free cross-entropy (P5_EPI_CE_STATS / _GRAD): labels [M]; forward outputs ce_part [M, 2 * ce_np] ((max, sum exp) per 64-column group,
+  // ce_np = ceil(N / 64)) and ce_lab [M] (logit at the label); backward inputs ce_lse [M], ce_g [M] (gradient of the row's NLL)
+  const int64_t* ce_labels;
+  float* ce_part; float* ce_lab;
+  const float* ce_lse; const float* ce_g;
+  int ce_np;
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets

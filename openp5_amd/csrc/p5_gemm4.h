@@ -27,7 +27,6 @@
 #define P5_MAX_GROUP 8
 struct P5GemmGroup {
   int nprob, total_units;
-  int stagger;                        // p5_gemm5.h: phase offset of the odd workgroups of each XCD (0 = off)
   int unit_begin[P5_MAX_GROUP + 1];   // first unit of problem p; units of a problem: tile-major (n fastest), K-split fastest
   P5GemmArgs p[P5_MAX_GROUP];         // .g4_tiles_n / .g4_nk / .splitk filled by the launcher
 };

@@ -18,9 +18,11 @@
 #pragma once
 #include "p5_gemm4.h"
 
-// GATE: the instance that carries the gated-GELU epilogues (P5_EPI_GELU_GATE / _BWD); the product instances do not pay for their registers
-template <bool KS, int ABL = 0, bool GATE = false>
+// VAR: 0 = the product instances; 1 = the instance that carries the gated-GELU epilogues (P5_EPI_GELU_GATE / _BWD); 2 = the logit-free
+// cross-entropy epilogues (P5_EPI_CE_STATS / _GRAD) -- the product instances do not pay for their registers
+template <bool KS, int ABL = 0, int VAR = 0>
 __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
+  constexpr bool GATE = VAR == 1;
   using T = bf16;
   constexpr int BM = 256, BN = 128, NST = 3;
   constexpr int NWC = 4, NWL = 4;                          // compute waves (2 x 2), loader waves
@@ -156,14 +158,6 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   }
 
   // =========================================== compute waves ===========================================
-  // Optional phase offset (lab, option "gemm5_stagger", units of ~0.4 us): every workgroup of a launch reaches its write phase at the same
-  // time -- 33 MB of stores per 8192x2048 launch while no MFMA runs anywhere on the chip.  Odd workgroups of each XCD start their compute
-  // waves late, so that one half's write-out runs under the other half's K loop.
-#ifndef P5_EMU
-  if (grp.stagger > 0 && (((int)blockIdx.x >> 3) & 1)) {
-    for (int q = 0; q < grp.stagger; ++q) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
   const int wm = wave >> 1, wn = wave & 1;
   int offA[KS ? TM : 1], offB[KS ? TN : 1];
   if constexpr (KS) {
@@ -358,6 +352,62 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
 #ifndef P5_EMU
     asm volatile("" : "+v"(le));      // (keeps hipcc from hoisting every lane-dependent output offset out of the unit loop)
 #endif
+    if constexpr (VAR == 2 && !KS) {
+      // ---- logit-free cross-entropy (tied head, P5_T5.py:352-369): the [rows, V] logits never reach memory.  A lane holds 16 of the 64
+      // columns of its wave tile for one row per row block; the row's (max, sum exp) over those 64 columns is two shuffles away.
+      const P5GemmArgs& g = grp.p[u.pi];
+      const int M = g.M, N = g.N, gl = le >> 4;
+      const float alpha = g.alpha;
+      const int cw = u.n0 + wn * WTN;                       // first column of the wave tile
+      const int row0 = u.m0 + wm * WTM + (le & 15);
+      if (cw >= N) return;
+      const bool stats = g.epi == P5_EPI_CE_STATS;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = row0 + i * 16;
+        const bool row_ok = row < M;
+        const long long lab = row_ok ? (long long)g.ce_labels[row] : -1;
+        float v[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[h * 8 + e] = acc[i][2 * h + (e >> 2)][e & 3] * alpha;
+        if (stats) {
+          float m = P5_NEG_INF;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int col = cw + (q >> 3) * 32 + gl * 8 + (q & 7);
+            if (col < N) m = fmaxf(m, v[q]);
+            if (row_ok && col == lab) g.ce_lab[row] = v[q];          // (exactly one lane of the launch per row)
+          }
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float sum = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int col = cw + (q >> 3) * 32 + gl * 8 + (q & 7);
+            if (col < N) sum += p5_exp<T>(v[q] - m);
+          }
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          if (gl == 0 && row_ok) {
+            float* pp = g.ce_part + ((size_t)row * g.ce_np + (cw >> 6)) * 2;
+            pp[0] = m; pp[1] = sum;
+          }
+        } else {
+          const float lse = row_ok ? g.ce_lse[row] : 0.f, gg = row_ok ? g.ce_g[row] : 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int col = cw + h * 32 + gl * 8;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (col + e < N) ? (p5_exp<T>(v[h * 8 + e] - lse) - (col + e == lab ? 1.f : 0.f)) * gg : 0.f;
+            if (row_ok && col < g.ldc) st16((T*)g.C + (size_t)row * g.ldc + col, pack16<T>(o));      // (ldc % 8 == 0: padded columns N .. ldc get exact zeros)
+          }
+        }
+      }
+      return;
+    }
     // Fast path: a whole tile inside the output, 16-byte stores.  Everything the eight row blocks need from the problem descriptor
     // was read ONCE into scalars (EpiCtx): the general code below reads descriptor
     // fields where it uses them, and with the accumulators holding the scalar registers' spill space hipcc re-issues those kernarg
@@ -495,8 +545,10 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
             for (int h = 0; h < TN / 2; ++h) {
               T* const cpi = cp + (size_t)i * 16 * ldc + h * 32;
               if constexpr ((ABL & 16) != 0) { if (packed[h][0] == 0x12345678u) st16(cpi, packed[h]); }      // (lab: epilogue math without the stores)
-#if defined(P5_GEMM5_NT) && !defined(P5_EMU)
-              else __builtin_nontemporal_store(packed[h], (u32x4*)cpi);      // (lab build: streaming stores)
+#if !defined(P5_GEMM5_NO_NT) && !defined(P5_EMU)
+              // streaming stores: a 33 MB output passes through once and is next read by another kernel from the Infinity Cache / HBM, not from
+              // this XCD's 4 MB L2 -- in the C2 step 4.237 vs 4.251 ms with plain stores (profiles/r06_call2_option_ab.txt)
+              else __builtin_nontemporal_store(packed[h], (u32x4*)cpi);
 #else
               else st16(cpi, packed[h]);
 #endif

@@ -25,7 +25,6 @@ int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;         
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
 int g_opt_split_pipe = getenv("P5_SPLIT_PIPE") ? atoi(getenv("P5_SPLIT_PIPE")) : 1;    // split-f16 fp32 GEMMs: the three-deep pipelined kernel (0 = p5_gemm_kernel<MM = 1>)
 int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 0;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them (0 = the fp32 rule: from 512; measured on the verification pass, 64x64 tiles win below that: 5.05 vs 5.30 ms per batch)
-int g_opt_gemm5_stagger = getenv("P5_GEMM5_STAGGER") ? atoi(getenv("P5_GEMM5_STAGGER")) : 0;   // KC instance: odd workgroups start their compute waves this many x ~0.4 us late
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -147,7 +146,6 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   }
   grp.unit_begin[grp.nprob] = units;
   grp.total_units = units;
-  grp.stagger = (!KS && units > g_opt_g4_wgs) ? g_opt_gemm5_stagger : 0;      // (only where every workgroup has at least two tiles)
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
   {
@@ -161,14 +159,21 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   P5_LAUNCH((p5_gemm5_kernel<KS, KS ? 0 : P5_GEMM5_ABL>), dim3(nwg), dim3(512), 0, s, grp);
 #else
   // (spelled out so that the in-run profiler's stringified kernel name says which instance ran, not "<KS>")
-  bool gate = false;
-  for (int i = 0; i < grp.nprob; ++i) gate = gate || grp.p[i].epi == P5_EPI_GELU_GATE || grp.p[i].epi == P5_EPI_GELU_GATE_BWD;
+  bool gate = false, ce = false;
+  for (int i = 0; i < grp.nprob; ++i) {
+    gate = gate || grp.p[i].epi == P5_EPI_GELU_GATE || grp.p[i].epi == P5_EPI_GELU_GATE_BWD;
+    ce = ce || grp.p[i].epi == P5_EPI_CE_STATS || grp.p[i].epi == P5_EPI_CE_GRAD;
+  }
   if constexpr (KS) {
-    P5_REQUIRE(!gate, "gemm5: the gated-GELU epilogues belong to the K-contiguous instance");
+    P5_REQUIRE(!gate && !ce, "gemm5: the gated-GELU / cross-entropy epilogues belong to the K-contiguous instance");
     P5_LAUNCH((p5_gemm5_kernel<true>), dim3(nwg), dim3(512), 0, s, grp);
+  } else if (ce) {
+    P5_REQUIRE(grp.nprob == 1 && !gate, "gemm5: a cross-entropy launch carries one problem");
+    P5_PROF_TAG("KC + logit-free cross-entropy epilogue");
+    P5_LAUNCH((p5_gemm5_kernel<false, 0, 2>), dim3(nwg), dim3(512), 0, s, grp);
   } else if (gate) {
     P5_PROF_TAG("KC + gated-GELU epilogue");
-    P5_LAUNCH((p5_gemm5_kernel<false, 0, true>), dim3(nwg), dim3(512), 0, s, grp);
+    P5_LAUNCH((p5_gemm5_kernel<false, 0, 1>), dim3(nwg), dim3(512), 0, s, grp);
   } else {
     P5_LAUNCH((p5_gemm5_kernel<false>), dim3(nwg), dim3(512), 0, s, grp);
   }
@@ -201,9 +206,28 @@ bool p5l_gemm_gate_ok(int M, int N, int K, int lda, int ldb) {
          (ldb % 64) == 0 && (long)(M / 256) * (N / 128) >= g_opt_gemm_wide_min_tiles;
 }
 
+bool p5l_gemm_ce_ok(int M, int N, int K, int lda, int ldb) {
+  return g_opt_gemm_wide && (g_opt_gemm_ws & 1) && !g_opt_gemm_tile && !g_opt_gemm_v2 && (K % 64) == 0 && (lda % 64) == 0 && (ldb % 64) == 0 &&
+         (long)((M + 255) / 256) * ((N + 127) / 128) >= g_opt_gemm_wide_min_tiles;
+}
+
 template <class T>
 static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
   constexpr int EPF = TT<T>::EPF;
+  if (g.epi == P5_EPI_CE_STATS || g.epi == P5_EPI_CE_GRAD) {
+    // logit-free cross-entropy: the epilogue guards rows and columns itself, so any M, N go -- but only the wave-specialised kernel has it
+    P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && p5l_gemm_ce_ok(g.M, g.N, g.K, g.lda, g.ldb), "gemm: the cross-entropy epilogues run on the wide bf16 kernel (caller: check p5l_gemm_ce_ok)");
+    P5_REQUIRE(g.ce_labels && (g.epi == P5_EPI_CE_STATS ? (g.ce_part && g.ce_lab && g.ce_np == (g.N + 63) / 64) : (g.ce_lse && g.ce_g && g.C && !g.c_f32 && (g.ldc % 8) == 0 && ((uintptr_t)g.C % 16) == 0)),
+               "gemm: cross-entropy epilogue arguments");
+    g.C2 = nullptr; g.ldc2 = 0; g.gate_F = 0;
+    P5GemmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.nprob = 1;
+    grp.p[0] = g;
+    grp.p[0].splitk = 1;
+    return launch_gemm4(P5_G4_256x128, false, grp, s);
+  }
+  g.ce_labels = nullptr; g.ce_part = nullptr; g.ce_lab = nullptr; g.ce_lse = nullptr; g.ce_g = nullptr; g.ce_np = 0;
   if (g.epi == P5_EPI_GELU_GATE || g.epi == P5_EPI_GELU_GATE_BWD) {
     P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && !g.c_f32 && p5l_gemm_gate_ok(g.M, g.N, g.K, g.lda, g.ldb),
                "gemm: the gated-GELU epilogues need the whole-tile path of the wide bf16 kernel (caller: check p5l_gemm_gate_ok)");

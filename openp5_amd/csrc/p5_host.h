@@ -51,7 +51,6 @@ extern int g_opt_gemm_ring128_min_tiles;
 extern int g_opt_g4_nst;
 extern int g_opt_g4_wgs;
 extern int g_opt_gemm_ws;
-extern int g_opt_gemm5_stagger;
 extern int g_opt_attn_fwd_wg;
 extern int g_opt_attn_fwd_head;
 extern int g_opt_attn_bwd_head;
@@ -65,6 +64,7 @@ enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2, P5_G5_256x128 = 
 int p5l_gemm_bf16(P5GemmArgs g, hipStream_t s);
 int p5l_gemm_f32(P5GemmArgs g, hipStream_t s);
 bool p5l_gemm_gate_ok(int M, int N, int K, int lda, int ldb);
+bool p5l_gemm_ce_ok(int M, int N, int K, int lda, int ldb);
 int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s);
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);
 int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);

@@ -134,6 +134,8 @@ struct P5Engine {
   void *enc_x0 = nullptr, *enc_xf = nullptr, *enc_out = nullptr; float* enc_rstd_f = nullptr;
   int64_t* dec_ids = nullptr; void *dec_x0 = nullptr, *dec_xf = nullptr, *dec_hn = nullptr; float* dec_rstd_f = nullptr;
   float *logits = nullptr, *lse_tok = nullptr, *ssq_scratch = nullptr;
+  float *ce_part = nullptr, *ce_lab = nullptr, *ce_g = nullptr;      // logit-free cross-entropy: per-row partial (max, sum exp) pairs, label logits, NLL gradients
+  bool ce_free_fwd = false;       // the last training forward took the logit-free head (the backward recomputes the logits tile by tile)
   void* Sf = nullptr;              // folded bf16 weight copy W diag(ln) for q/k/v, wi, cross-attention q (same arena offsets; behind St)
   float *dres_a = nullptr, *dres_b = nullptr, *d_enc = nullptr, *Dvec = nullptr, *dres_cur = nullptr, *rel_partial = nullptr;
   void *dy = nullptr, *dn = nullptr, *dqkv = nullptr, *dO = nullptr, *dh = nullptr, *du = nullptr, *dlogits = nullptr, *dkv = nullptr;
@@ -180,6 +182,7 @@ struct P5Engine {
   struct TrDesc { int64_t off; int rows, cols, tile0; int64_t ln_off; };
   std::vector<TrDesc> tr_list;
   int tr_tiles = 0;
+  int adam_tiles = 0;             // 64 x 256 tiles of p5_adamw_tiles_kernel over the same blocks
   bool tr_pending = false;
   bool zg_pending = false;        // p5_engine_clear_grads(): the clear runs on the side stream; the next backward waits for zg_ev
 #ifndef P5_EMU
@@ -666,6 +669,9 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->dec_hn = b.take(Md * d * sz);
     e->logits = (float*)b.take(Md * Vp * 4);
     e->lse_tok = (float*)b.take(Md * 4);
+    e->ce_part = (float*)b.take(Md * (size_t)(Vp / 64) * 2 * 4);
+    e->ce_lab = (float*)b.take(Md * 4);
+    e->ce_g = (float*)b.take(Md * 4);
   }
   if (with_bwd) {
     const size_t Mx = M > Md ? M : Md;
@@ -787,8 +793,16 @@ static int encoder_fwd(P5Engine* e, hipStream_t s) {
   return rmsnorm_fwd<T>(s, e->enc_out, e->enc_rstd_f, e->enc_xf, e->P + e->off_enc_fln, M, d, c.eps, mk_drop(e, 0, 0, 7));
 }
 
+// Logit-free cross-entropy: in bf16 training the tied head's [B*T, V] logits (66 MB fp32 at C2) are never written -- the head
+// GEMM's epilogue reduces every 64 columns of a row to (max, sum exp) and picks the label's logit, p5_ce_finish_kernel merges them into the
+// row's log-sum-exp and NLL; the backward recomputes the same GEMM and its epilogue writes dlogits directly.  Option "ce_free" 0 = the
+// materialised path (fp32 parity mode and shapes the wide kernel does not take always use it).
+static int g_opt_ce_free = getenv("P5_CE_FREE") ? atoi(getenv("P5_CE_FREE")) : 1;
+template <class T> static bool ce_free(const P5Engine* e) {
+  return sizeof(T) == 2 && g_opt_ce_free != 0 && p5l_gemm_ce_ok(e->Md, e->c.vocab_size, e->c.d_model, e->c.d_model, e->c.d_model);
+}
 template <class T>
-static int decoder_fwd(P5Engine* e, hipStream_t s) {
+static int decoder_fwd(P5Engine* e, hipStream_t s, float* nll_out = nullptr) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads, M = e->M, Md = e->Md;
   const int nd_ = c.n_dec_layers, ldkv = nd_ * 2 * in;
@@ -858,6 +872,19 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
   P5_TRY(rmsnorm_fwd<T>(s, e->dec_hn, e->dec_rstd_f, e->dec_xf, e->P + e->off_dec_fln, Md, d, c.eps, mk_drop(e, 1, 0, 7)));
   // tied head, d^-0.5 rescale folded into alpha (P5_T5.py:352-361)
   const float alpha = 1.0f / sqrtf((float)d);
+  e->ce_free_fwd = false;
+  if (nll_out && ce_free<T>(e)) {
+    P5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = e->dec_hn; g.B = Wc<T>(e, e->off_E); g.M = Md; g.N = c.vocab_size; g.K = d; g.lda = d; g.ldb = d;
+    g.epi = P5_EPI_CE_STATS; g.alpha = alpha; g.drop = no_drop();
+    g.ce_labels = e->labels; g.ce_part = e->ce_part; g.ce_lab = e->ce_lab; g.ce_np = (c.vocab_size + 63) / 64;
+    P5_TRY(launch_gemm<T>(g, s));
+    P5_LAUNCH((p5_ce_finish_kernel<T>), dim3((Md + 3) / 4), dim3(256), 0, s, nll_out, e->lse_tok, (const float*)e->ce_part, (const float*)e->ce_lab, e->labels, Md, g.ce_np);
+    P5_TRY(P5_KCHECK());
+    e->ce_free_fwd = true;
+    return 0;
+  }
   P5_TRY(linear_fwd<T>(s, e->dec_hn, d, Wc<T>(e, e->off_E), e->logits, e->Vp, Md, c.vocab_size, d, P5_EPI_STORE, nullptr, 0, alpha, 1));
   return 0;
 }
@@ -865,7 +892,8 @@ static int decoder_fwd(P5Engine* e, hipStream_t s) {
 template <class T>
 static int forward_impl(P5Engine* e, float* nll_out, hipStream_t s) {
   P5_TRY(encoder_fwd<T>(e, s));
-  P5_TRY(decoder_fwd<T>(e, s));
+  P5_TRY(decoder_fwd<T>(e, s, nll_out));
+  if (e->ce_free_fwd) return 0;       // (the head's epilogue + p5_ce_finish_kernel have written nll_out and the rows' log-sum-exp)
   P5_LAUNCH((p5_ce_fwd_kernel<T>), dim3(e->Md), dim3(256), 0, s, nll_out, e->lse_tok, (const float*)e->logits, e->labels, e->c.vocab_size, e->Vp);
   return P5_KCHECK();
 }
@@ -1003,10 +1031,22 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
 #endif
     e->zg_pending = false;
     if (!dnll) P5_REQUIRE(e->out_attn, "backward without dnll needs p5_forward_loss (output_attention mask)");
-    P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
-              e->labels, dnll, c.vocab_size, e->Vp, e->Vp, e->out_attn, e->T, 1.0f / (float)e->B);
-    P5_TRY(P5_KCHECK());
     const float alpha = 1.0f / sqrtf((float)d);
+    if (e->ce_free_fwd) {
+      // dlogits = (softmax - onehot) * g straight out of the recomputed head GEMM (same operands, same accumulation order: the same logits)
+      P5_LAUNCH(p5_ce_gscale_kernel, dim3((Md + 255) / 256), dim3(256), 0, s, e->ce_g, e->labels, dnll, e->out_attn, e->T, 1.0f / (float)e->B, Md);
+      P5_TRY(P5_KCHECK());
+      P5GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = e->dec_hn; g.B = Wc<T>(e, e->off_E); g.C = e->dlogits; g.M = Md; g.N = c.vocab_size; g.K = d; g.lda = d; g.ldb = d; g.ldc = e->Vp;
+      g.epi = P5_EPI_CE_GRAD; g.alpha = alpha; g.drop = no_drop();
+      g.ce_labels = e->labels; g.ce_lse = e->lse_tok; g.ce_g = e->ce_g; g.ce_np = (c.vocab_size + 63) / 64;
+      P5_TRY(launch_gemm<T>(g, s));
+    } else {
+      P5_LAUNCH((p5_ce_bwd_kernel<T>), dim3(Md, Md >= 2048 ? 1 : (Md >= 512 ? 4 : 8)), dim3(256), 0, s, (T*)e->dlogits, (const float*)e->logits, (const float*)e->lse_tok,
+                e->labels, dnll, c.vocab_size, e->Vp, e->Vp, e->out_attn, e->T, 1.0f / (float)e->B);
+      P5_TRY(P5_KCHECK());
+    }
     // dE += alpha * dlogits^T hn ;  dhn = alpha * dlogits E
     P5_TRY(linear_wgrad<T>(e, s, e->dlogits, e->Vp, e->dec_hn, d, e->G + e->off_E, Md, c.vocab_size, d, alpha));
     P5_TRY(wgrad_flush(e, s, true, (g_opt_wgrad_side & 1) != 0));
@@ -1886,7 +1926,7 @@ __global__ __launch_bounds__(256) void p5_fold_rows_kernel(bf16* __restrict__ ou
 }
 
 // out[c, r] = in[r, c] for every [rows, cols] block of the descriptor table (64 x 64 tiles through LDS, 16-byte row accesses)
-struct P5TrDesc { int64_t off; int rows, cols, tile0; int64_t ln_off; };      // ln_off >= 0: the T5LayerNorm weight folded into this block's copy (W diag(ln)), else -1
+struct P5TrDesc { int64_t off; int rows, cols, tile0; int64_t ln_off; int atile0, pad_; };      // ln_off >= 0: the T5LayerNorm weight folded into this block's copy (W diag(ln)), else -1; atile0: first 64 x 256 tile of p5_adamw_tiles_kernel
 __global__ __launch_bounds__(256) void p5_transpose_blocks_kernel(bf16* __restrict__ out, const bf16* __restrict__ in, const P5TrDesc* __restrict__ tab,
                                                                  int ndesc) {
   __shared__ unsigned short tile[64][66];
@@ -1962,9 +2002,11 @@ __device__ static __forceinline__ float p5_adam_update(const P5AdamArgs& a, floa
   p = p - a.decay * p;
   return p;
 }
+#define P5_ADAM_TW 256        // columns of an AdamW tile: 64 rows x 256 columns = 1 KiB contiguous per row and fp32 array (64 x 64 tiles ran at
+                              // 0.6 of the flat kernel's bandwidth: 256-byte pieces on a 2-8 KiB stride, profiles/r06_call2_*.txt)
 __global__ __launch_bounds__(256) void p5_adamw_tiles_kernel(P5AdamTileArgs t) {
   __shared__ float sp[256];
-  __shared__ unsigned short tile[64][66];
+  __shared__ unsigned short tile[64][P5_ADAM_TW + 2];
   const P5AdamArgs& a = t.a;
   const float coef = p5_adam_clip_coef(a, sp);
   const int b = blockIdx.x;
@@ -1978,53 +2020,60 @@ __global__ __launch_bounds__(256) void p5_adamw_tiles_kernel(P5AdamTileArgs t) {
     }
     return;
   }
-  int lo = 0, hi = t.ndesc - 1;              // last descriptor with tile0 <= b
+  int lo = 0, hi = t.ndesc - 1;              // last descriptor with atile0 <= b
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (t.tab[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    if (t.tab[mid].atile0 <= b) lo = mid; else hi = mid - 1;
   }
   const P5TrDesc dsc = t.tab[lo];
-  const int tc = (dsc.cols + 63) / 64;
-  const int lt = b - dsc.tile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
-  const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;       // 4 threads per row, 16 columns each (cols % 8 == 0)
+  const int tc = (dsc.cols + P5_ADAM_TW - 1) / P5_ADAM_TW;
+  const int lt = b - dsc.atile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * P5_ADAM_TW;
+  const int rq = threadIdx.x >> 5, cl = (threadIdx.x & 31) * 8;      // 32 threads x 8 columns = one 1-KiB row piece; 8 rows per pass
+  const int c = c0 + cl;
+  const bool col_ok = c < dsc.cols;                                    // (cols % 8 == 0)
+  const bool fold = t.Sf != nullptr && dsc.ln_off >= 0 && col_ok;
+  float ln_new[8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = c0 + cq + h * 8;
-    const bool ok = r0 + r < dsc.rows && c < dsc.cols;
-    float o[8];
+  for (int e = 0; e < 8; ++e) ln_new[e] = 0.f;
+  if (fold) {
+    // the norm weight AFTER this step, from its state before it (the launch that updates it runs behind this one)
+    const size_t l0 = (size_t)dsc.ln_off + c;
+    float lp[8], lg[8], lm[8], lv[8];
+    ldf<8>(a.p + l0, lp); ldf<8>(a.g + l0, lg); ldf<8>(a.m + l0, lm); ldf<8>(a.v + l0, lv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    if (ok) {
+    for (int e = 0; e < 8; ++e) ln_new[e] = p5_adam_update(a, coef, lp[e], lg[e], lm[e], lv[e]);
+  }
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 8 + rq;
+    if (col_ok && r0 + r < dsc.rows) {
       const size_t i0 = (size_t)dsc.off + (size_t)(r0 + r) * dsc.cols + c;
-      float p[8], g[8], m[8], v[8];
+      float p[8], g[8], m[8], v[8], o[8];
       ldf<8>(a.p + i0, p); ldf<8>(a.g + i0, g); ldf<8>(a.m + i0, m); ldf<8>(a.v + i0, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = p5_adam_update(a, coef, p[e], g[e], m[e], v[e]);
       stf<8>(a.p + i0, o); stf<8>(a.m + i0, m); stf<8>(a.v + i0, v);
       const u32x4 pk = pack16<bf16>(o);
       if (a.shadow) st16((bf16*)a.shadow + i0, pk);
-      if (t.Sf && dsc.ln_off >= 0) {
-        // the norm weight AFTER this step, from its state before it (the launch that updates it runs behind this one)
-        const size_t l0 = (size_t)dsc.ln_off + c;
-        float lp[8], lg[8], lm[8], lv[8], f[8];
-        ldf<8>(a.p + l0, lp); ldf<8>(a.g + l0, lg); ldf<8>(a.m + l0, lm); ldf<8>(a.v + l0, lv);
+      if (fold) {
+        float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = o[e] * p5_adam_update(a, coef, lp[e], lg[e], lm[e], lv[e]);
+        for (int e = 0; e < 8; ++e) f[e] = o[e] * ln_new[e];
         st16(t.Sf + i0, pack16<bf16>(f));
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { tile[r][cq + h * 8 + 2 * q] = (unsigned short)(pk[q] & 0xFFFF); tile[r][cq + h * 8 + 2 * q + 1] = (unsigned short)(pk[q] >> 16); }
+      for (int q = 0; q < 4; ++q) { tile[r][cl + 2 * q] = (unsigned short)(pk[q] & 0xFFFF); tile[r][cl + 2 * q + 1] = (unsigned short)(pk[q] >> 16); }
     }
   }
   __syncthreads();
   unsigned short* dst = (unsigned short*)t.St + dsc.off;
-  for (int i = threadIdx.x; i < 64 * 8; i += 256) {        // 64 output rows (= input columns) x 8 pieces, as p5_transpose_blocks_kernel
-    const int c = i >> 3, p8 = (i & 7) * 8;
-    if (c0 + c < dsc.cols && r0 + p8 < dsc.rows) {
+  for (int i = threadIdx.x; i < P5_ADAM_TW * 8; i += 256) {        // TW output rows (= input columns) x 8 pieces of 8 input rows
+    const int cc = i >> 3, p8 = (i & 7) * 8;
+    if (c0 + cc < dsc.cols && r0 + p8 < dsc.rows) {                  // (rows % 8 == 0)
       u32x4 v;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = (unsigned)tile[p8 + 2 * q][c] | ((unsigned)tile[p8 + 2 * q + 1][c] << 16);
-      st16(dst + (size_t)(c0 + c) * dsc.rows + r0 + p8, v);
+      for (int q = 0; q < 4; ++q) v[q] = (unsigned)tile[p8 + 2 * q][cc] | ((unsigned)tile[p8 + 2 * q + 1][cc] << 16);
+      st16(dst + (size_t)(c0 + cc) * dsc.rows + r0 + p8, v);
     }
   }
 }
@@ -2088,9 +2137,9 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
-  else if (!strcmp(name, "gemm5_stagger")) g_opt_gemm5_stagger = value;
   else if (!strcmp(name, "gate_fuse")) g_opt_gate_fuse = value;
   else if (!strcmp(name, "adam_tiles")) g_opt_adam_tiles = value;
+  else if (!strcmp(name, "ce_free")) g_opt_ce_free = value;
   else if (!strcmp(name, "gemm_wide_min_tiles")) g_opt_gemm_wide_min_tiles = value;
   else if (!strcmp(name, "gemm_ring128_min_k")) g_opt_gemm_ring128_min_k = value;
   else if (!strcmp(name, "gemm_ring128_min_tiles")) g_opt_gemm_ring128_min_tiles = value;
@@ -2231,7 +2280,15 @@ int p5_engine_bind_transposed(P5Engine* e, void* buf, void* stream) {
   P5_REQUIRE(e->c.dtype == 1, "the transposed weight copy serves the bf16 mode only");
   // the descriptor table lives behind the copy itself (the library allocates nothing)
   std::vector<P5TrDesc> tab;
-  for (auto& t : e->tr_list) tab.push_back({t.off, t.rows, t.cols, t.tile0, t.ln_off});
+  int at0 = 0;
+  for (auto& t : e->tr_list) {
+    P5TrDesc q;
+    memset(&q, 0, sizeof(q));
+    q.off = t.off; q.rows = t.rows; q.cols = t.cols; q.tile0 = t.tile0; q.ln_off = t.ln_off; q.atile0 = at0;
+    at0 += ((t.rows + 63) / 64) * ((t.cols + 255) / 256);
+    tab.push_back(q);
+  }
+  e->adam_tiles = at0;
   char* at = (char*)buf + tr_table_off(e);
   e->Sf = (char*)buf + tr_fold_off(e);
 #ifndef P5_EMU
@@ -2260,11 +2317,11 @@ int p5_engine_adamw_step(P5Engine* e, float* m, float* v, const float* sumsq, do
   a.step_size = (float)(lr * sqrt(bc2) / bc1);
   a.decay = (float)(lr * weight_decay);
   t.tab = (const P5TrDesc*)((char*)e->St + tr_table_off(e));
-  t.ndesc = (int)e->tr_list.size(); t.ntiles = e->tr_tiles;
+  t.ndesc = (int)e->tr_list.size(); t.ntiles = e->adam_tiles;
   t.St = (bf16*)e->St; t.Sf = (bf16*)e->Sf;
   t.flat_n = (size_t)e->off_small_end;
   hipStream_t s = (hipStream_t)stream;
-  P5_LAUNCH(p5_adamw_tiles_kernel, dim3(e->tr_tiles + 1024), dim3(256), 0, s, t);
+  P5_LAUNCH(p5_adamw_tiles_kernel, dim3(e->adam_tiles + 1024), dim3(256), 0, s, t);
   P5_TRY(P5_KCHECK());
   {
     const P5Config& c = e->c;

@@ -174,6 +174,8 @@ class P5T5Native(nn.Module):
         self._ddp_sync = True       # False on all but the last micro-batch of a gradient-accumulation group
         self.ddp_bucket_dtype = "fp32"   # "bf16": gradient buckets travel as bf16 (half the bytes on the xGMI links)
         self.staged_backward = False     # run the stage-by-stage backward (the data-parallel code path) even at world size 1, without collectives
+        self.ddp_lazy_wait = True        # gradient buckets are waited for at their first use (the optimizer step), not at the end of the backward
+        self._pending_half = False
         self.ddp_timing = False          # record device time the main stream spends waiting for the gradient exchange (bench.py)
         self.ddp_wait_ms = []
         self._pending = []
@@ -511,6 +513,7 @@ class P5T5Native(nn.Module):
         the backward with the gradient of the runner's masked-mean loss itself."""
         if dnll is not None:
             dnll = dnll.to(torch.float32).contiguous()
+        self.finish_exchange()          # (an exchange nobody consumed: its buckets must land before this backward rewrites the arena)
         lib, eng, sp = self._lib, self._engine, self._be.stream_ptr()
         exchange = self.ddp_world > 1 and self._ddp_sync
         if exchange or self.staged_backward:
@@ -548,23 +551,13 @@ class P5T5Native(nn.Module):
                         else:
                             buf = seg
                         self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.ddp_group, async_op=True), buf, seg))
-            timing = self.ddp_timing and exchange and self._flat.is_cuda
-            if timing:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            for w, buf, seg in self._pending:
-                w.wait()
-                if half:
-                    seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
-            self._pending = []
-            for cs in (self._side, self._comm):
-                if cs is not None and exchange:
-                    # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
-                    # stream they were issued from (gloo on device tensors) need the explicit edge comm -> main
-                    torch.cuda.current_stream().wait_stream(cs)
-            if timing:
-                ev1.record()
-                self.ddp_wait_ms.append((ev0, ev1))     # (read by bench.py after a synchronize: main-stream time between the end of the backward and the last bucket)
+            self._pending_half = half
+            # the buckets are waited for where the gradients are first READ (FusedAdamW.step -> finish_exchange), bucket by bucket, not here:
+            # with a host-blocking backend (gloo) the host goes on to the next batch's collation while the last buckets travel, and nothing
+            # between the end of the backward and the optimizer step touches the gradient arena.  `ddp_lazy_wait = False` restores the wait
+            # at the end of the backward (a caller that reads .grad before stepping must call finish_exchange() itself).
+            if not (exchange and self.ddp_lazy_wait):
+                self.finish_exchange()
         else:
             self._be.check(lib.p5_backward(eng, _ptr(dnll), sp), "p5_backward")
         self._grads_dead = False
@@ -572,6 +565,30 @@ class P5T5Native(nn.Module):
             if p.grad is None:
                 off, n, shape = self._views[name]
                 p.grad = self._grads[off:off + n].view(shape)
+
+    def finish_exchange(self):
+        """Wait (bucket by bucket, in issue order) for the gradient all-reduces the last backward enqueued; a no-op when none is pending.
+        Called by FusedAdamW.step before the gradient norm is taken; call it yourself before reading `.grad` of a data-parallel model."""
+        if not self._pending:
+            return
+        exchange = True
+        timing = self.ddp_timing and self._flat.is_cuda
+        if timing:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for w, buf, seg in self._pending:
+            w.wait()
+            if self._pending_half:
+                seg.copy_(buf)      # every rank holds the same bf16 sums -> identical fp32 gradients -> identical updates
+        self._pending = []
+        for cs in (self._side, self._comm):
+            if cs is not None and exchange and self._flat.is_cuda:
+                # NCCL/RCCL's wait() already orders the CURRENT stream after the collective; backends that complete on the
+                # stream they were issued from (gloo on device tensors) need the explicit edge comm -> main
+                torch.cuda.current_stream().wait_stream(cs)
+        if timing:
+            ev1.record()
+            self.ddp_wait_ms.append((ev0, ev1))     # (read by bench.py after a synchronize: main-stream time spent waiting for the buckets)
 
     def loss_and_backward(self, input_ids, whole_word_ids, attention_mask, labels, output_attention):
         """Fused form of the reference loop body DistributedRunner.py:63-80: forward, masked-mean loss

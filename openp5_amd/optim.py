@@ -48,6 +48,8 @@ class FusedAdamW:
             # scheduler.step() (DistributedRunner.py:85-86).  Same here: the dead arena is never re-applied.
             self.sched_steps += 1
             return
+        if hasattr(mdl, "finish_exchange"):
+            mdl.finish_exchange()        # data parallel: the all-reduced buckets are first read here (model._engine_backward)
         be, lib = mdl._be, mdl._lib
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         sp = be.stream_ptr()

@@ -980,6 +980,32 @@ def adamw_golden_case(be, tol=2e-6):
     return worst
 
 
+def ce_free_case(be, ocfg, B, L, T, dropout=0.0, min_tiles=None, seed=3):
+    """Logit-free cross-entropy (csrc p5_gemm5.h P5_EPI_CE_STATS / _GRAD): the bf16 training step whose head never writes the
+    [B*T, V] logits against the same step with the materialised logits (option ce_free 0): per-token NLL and every gradient agree to the
+    rounding of the log-sum-exp's summation order.  min_tiles: lowers the wide kernel's tile threshold so that toy shapes take that path."""
+    out = {}
+    for free in (1, 0):
+        be.check(be.lib.p5_set_option(b"ce_free", free), "opt")
+        if min_tiles is not None:
+            be.check(be.lib.p5_set_option(b"gemm_wide_min_tiles", min_tiles), "opt")
+        try:
+            m = build_model(be, ocfg, O.init_params(ocfg, 7), "bf16", dropout=dropout)
+            m.train()
+            ids, ww, mask, labels, out_attn = synth_batch(ocfg, B, L, T, seed)
+            loss = m.loss_and_backward(ids, ww, mask, labels, out_attn)
+            sync(be)
+            out[free] = (float(loss), m._grads.detach().float().cpu().clone())
+        finally:
+            be.lib.p5_set_option(b"ce_free", 1)
+            be.lib.p5_set_option(b"gemm_wide_min_tiles", 160)
+    (l1, g1), (l0, g0) = out[1], out[0]
+    assert abs(l1 - l0) <= 2e-5 * max(1.0, abs(l0)), (l1, l0)
+    rel = float((g1 - g0).norm() / g0.norm().clamp(min=1e-30))
+    assert rel <= 2e-3, f"logit-free vs materialised gradients differ by {rel}"
+    return l1, l0, rel
+
+
 def adamw_tiles_case(be, ocfg, steps=3, seed=11):
     """p5_engine_adamw_step's tile-wise update (the AdamW pass writes the transposed copy W^T and the norm-folded copy W diag(ln) itself,
     csrc p5_adamw_tiles_kernel) against the flat update followed by p5_refresh_transposed: parameters, both moments, the bf16 shadow and the

@@ -335,6 +335,25 @@ def test_adamw_tiles_write_every_copy(emu, act):
     cases.adamw_tiles_case(emu, O.T5Cfg.named("tiny", ff_act=act))
 
 
+def test_logit_free_cross_entropy(emu):
+    """the head GEMM's epilogue reduces the logits to per-row statistics (forward) / writes dlogits (backward): same loss, same gradients as the
+    materialised path; ragged shapes (rows and vocabulary not multiples of the tile) included."""
+    print("[ce free]", cases.ce_free_case(emu, O.T5Cfg.named("tiny"), 3, 20, 6, min_tiles=1))
+    print("[ce free]", cases.ce_free_case(emu, O.T5Cfg.named("tiny", vocab_size=333), 4, 16, 5, dropout=0.1, min_tiles=1))
+
+
+def test_model_bf16_wide_path_epilogues_against_oracle(emu):
+    """toy models pushed onto the wide kernel (tile threshold 1): logit-free cross-entropy + gated-GELU epilogues + folded norms inside a whole
+    training step, against the fp32 oracle."""
+    emu.check(emu.lib.p5_set_option(b"gemm_wide_min_tiles", 1), "opt")
+    try:
+        for act in ("relu", "gated-gelu"):
+            r = cases.bf16_gradient_case(emu, O.T5Cfg.named("tiny", ff_act=act), 4, 64, 5)
+            assert r["nll_max"] <= 0.08 and r["worst_rel"][0] <= 0.15 and r["whole_rel"] <= 0.05 and r["whole_cos"] >= 0.999, r
+    finally:
+        emu.lib.p5_set_option(b"gemm_wide_min_tiles", 160)
+
+
 def test_adamw_kernel_matches_published_426_fixture(emu):
     print("[adamw golden] worst relative error", cases.adamw_golden_case(emu))
 

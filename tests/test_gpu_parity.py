@@ -283,6 +283,13 @@ def test_adamw_tiles_write_every_copy(hip):
     cases.adamw_tiles_case(hip, O.T5Cfg.named("t5-small", num_layers=2, num_decoder_layers=2, vocab_size=1000))
 
 
+def test_logit_free_cross_entropy(hip):
+    """SURVEY 2.4 K9 at the benchmark shape (T5-small dims 2+2, B=64, L=128, T=8, V=32100, dropout on) and on a ragged toy: the training step
+    that never writes the [B*T, V] logits equals the one that does."""
+    print("[ce free C2 shape]", cases.ce_free_case(hip, O.T5Cfg.named("t5-small", num_layers=2, num_decoder_layers=2), 64, 128, 8, dropout=0.1))
+    print("[ce free ragged]", cases.ce_free_case(hip, O.T5Cfg.named("tiny", vocab_size=333), 4, 16, 5, min_tiles=1))
+
+
 def test_adamw_kernel_matches_published_426_fixture(hip):
     """a11 pinned (round-5 verdict): p5_grad_sumsq + p5_adamw_kernel against the fp64 run of the published 4.26 algorithm."""
     print("[adamw golden] worst relative error", cases.adamw_golden_case(hip))
