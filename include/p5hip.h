@@ -255,7 +255,7 @@ int p5_op_gemm(int dtype, const void* A, const void* Bm, void* C, const void* au
 /* Persistent ring GEMM (openp5_amd/csrc/p5_gemm4.h), bf16 operands: up to 8 problems C[M,N] (+)= A B^T in ONE launch (the weight
  * gradients of a layer; nn.Linear autograd, DistributedRunner.py:80).  ks = 0: A [M, lda], B [N, ldb] (reduction dim contiguous);
  * ks = 1: A [K, lda], B [K, ldb] (reduction dim strided: dW = dy^T x).  epi as p5_op_gemm (0 store, 1 relu(+dropout), 2 residual +
- * dropout, 3 mask by aux > 0, 4 fp32 atomic add, 6 fp32 C += without split-K, 5 / 7 gated-GELU forward / backward, below).  tile_cfg 0 = 128x128, 1 = 256x128, 2 = 128x256.
+ * dropout, 3 mask by aux > 0, 4 fp32 atomic add, 6 fp32 C += without split-K, 5 / 7 gated-GELU forward / backward, below).  tile_cfg 0 = 128x128, 1 = 256x128, 2 = 128x256, 3 = 256x128 loader / compute waves, 4 = 128x128 loader / compute waves.
  * rowss / ssq_out: optional T5LayerNorm statistics carried through the epilogue (row sum of squares in, sum of squares of the stored
  * row out), NULL = off.  `probs` is a HOST array. */
 typedef struct P5GemmProblem {
@@ -269,6 +269,16 @@ typedef struct P5GemmProblem {
    * [u0 | u1] [M, 2F] (ldc2) kept for the backward, gate_F = F;  epi 7 = backward: B = Wo^T [F, K], N = F, aux = u [M, 2F] (ldaux),
    * C = du = [dh u1 gelu'(u0) | dh gelu(u0)] [M, 2F] (ldc), dh = the product with the dropout mask of h re-applied; gate_F = 0 */
   void* C2; int ldc2, gate_F;
+  /* epi 10 = T5LayerNorm backward (HF modeling_t5.py:59-72 under autograd) in the epilogue of the data-gradient GEMM that produces the
+   * norm's input gradient (tile_cfg 4, ks 0, M % 128 == 0, N % 128 == 0, N = d_model): acc = dn = dOut W; aux = x [M, N] (ldaux) the
+   * sub-layer's input rows, rowss / rowss_nt their partial sums of squares, nb_w [N] the norm weight, nb_dot [M, nb_dot_nt] partial sums
+   * of <dOut, Out> per row (= sum_j (dn w)_j xh_j), nb_rin [M, N] fp32 incoming residual gradient.  Outputs: nb_rout [M, N] fp32 =
+   * rstd (dn w - xh mean_j(dn w xh)) + nb_rin; C (ldc) = dropout(nb_rout) in bf16; C2 (ldc2, may be NULL) = w * round(x rstd);
+   * nb_dw [M / 64, N] partial rows of the norm-weight gradient sum_rows dn xh.
+   * epi 3 with ssq_out (tile_cfg 1): ssq_out[row][64-column group] = sum of C * aux / alpha (row sums of <d pre, pre>). */
+  const float* nb_dot; int nb_dot_nt;
+  const float* nb_rin; float* nb_rout;
+  const float* nb_w; float* nb_dw;
 } P5GemmProblem;
 int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs, const uint32_t* rng_state, uint32_t site, float drop_p,
                      void* stream);
@@ -287,6 +297,14 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
                    int rel_buckets, const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
                    int ldv, int ldo, int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
                    void* stream);
+/* the same, and dot_out [B * Lq, H] = <dQ, Q> + <dK, K> + <dV, V> per token and head from the values as stored: the row sums the
+ * T5LayerNorm-backward epilogue of the qkv data-gradient GEMM consumes (P5GemmProblem epi 10).  bf16 self-attention with
+ * 16 < Lq == Lk <= 128 (the fused backward kernel) only; NULL = p5_op_attn_bwd. */
+int p5_op_attn_bwd_dot(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                       float* Dvec, void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch,
+                       int rel_buckets, const int* lut, int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk,
+                       int ldv, int ldo, int lddq, int lddk, int lddv, int causal, const uint32_t* rng_state, uint32_t site, float drop_p,
+                       float* dot_out, void* stream);
 int p5_op_ce_fwd(float* nll, float* lse, const float* logits, const int64_t* labels, int rows, int V, int ldl, void* stream);
 /* decode-step projection over a few hundred rows (p5_decode2.h): C = A W^T, W = T [N, ldw].  amode 0: A = T [M, lda];
  * amode 1: A = fp32 residual stream [M, K], normalised with T5LayerNorm weight `ln` by the kernel itself.

@@ -18,7 +18,8 @@ class P5Config(C.Structure):
 class P5GemmProblem(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("aux", vp), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
                 ("ldaux", i32), ("epi", i32), ("c_f32", i32), ("splitk", i32), ("alpha", f32), ("rowss", vp), ("rowss_eps", f32), ("ssq_out", vp), ("rowss_nt", i32), ("ssq_nt", i32),
-                ("C2", vp), ("ldc2", i32), ("gate_F", i32)]
+                ("C2", vp), ("ldc2", i32), ("gate_F", i32),
+                ("nb_dot", vp), ("nb_dot_nt", i32), ("nb_rin", vp), ("nb_rout", vp), ("nb_w", vp), ("nb_dw", vp)]
 
 
 # name -> (restype, argtypes)
@@ -86,6 +87,8 @@ PROTOTYPES = {
     "p5_op_attn_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u32, f32, vp]),
     "p5_op_attn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                             i32, i32, i32, i32, vp, u32, f32, vp]),
+    "p5_op_attn_bwd_dot": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                                i32, i32, i32, i32, vp, u32, f32, vp, vp]),
     "p5_op_ce_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "p5_op_dec_cross_attn": (i32, [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "p5_op_skinny_gemm": (i32, [i32, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp]),

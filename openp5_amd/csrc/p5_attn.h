@@ -42,6 +42,10 @@ struct P5AttnArgs {
   // 128 < L <= 512) instead of being re-hashed twice: per (batch, head, 16-query block) 256 words -- word [half * 128 + n], n = t * 4 + r,
   // is the lane mask (lanes 32 half .. 32 half + 31; lane = 16 g + li) of keep(query 16 block + li, key 16 t + 4 g + r).  nullptr: hash.
   uint32_t* keep_bits;
+  // self-attention backward (fused kernel, bf16, Lq == Lk <= 128): dot_out[(b * Lq + token) * H + h] = <dq, q> + <dk, k> + <dv, v> of the
+  // token's 64 head columns, from the values as stored (bf16) -- the H partial sums of <d qkv, qkv> per row that the T5LayerNorm backward in
+  // the epilogue of the qkv data-gradient GEMM needs (P5_EPI_NORM_BWD, p5_gemm.h).  nullptr: not written.
+  float* dot_out;
 };
 
 
@@ -83,6 +87,36 @@ __device__ static __forceinline__ void wave_store_16x64(T* __restrict__ out, siz
   for (int p = 0; p < 16 / RPP; ++p) {
     const int lr = p * RPP + lane / C::PPR, piece = lane % C::PPR;
     if (row0 + lr < row_end) st16(out + (size_t)(row0 + lr) * ld + piece * C::EPF, ld16(pw + lr * C::TS + piece * 16));
+  }
+}
+
+// The same store for a bf16 [16][64] result whose row-wise inner product with the FORWARD values of the same rows is wanted as well
+// (P5AttnArgs::dot_out): fw[p] = this lane's 16-byte piece (row p * 8 + lane / 8, piece lane % 8) of the forward tile; dot[p] accumulates
+// the lane's eight products of the values AS STORED.  Vector path only (the caller checks ld % 8 == 0 and the alignment).
+template <class T>
+__device__ static __forceinline__ void wave_store_16x64_dot(T* __restrict__ out, size_t ld, int row0, int row_end, const f32x4 (&acc)[4], char* pw,
+                                                            int lane, const u32x4 (&fw)[2], float (&dot)[2]) {
+  using C = AttnC<T>;
+  static_assert(sizeof(T) == 2, "bf16 tiles: eight 16-byte pieces per row");
+  const int g = lane >> 4, li = lane & 15;
+  P5_WAVE_SYNC();
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(T*)(pw + (g * 4 + r) * C::TS + (dt * 16 + li) * C::SZ) = from_f<T>(acc[dt][r]);
+  P5_WAVE_SYNC();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int lr = p * 8 + (lane >> 3), piece = lane & 7;
+    const u32x4 v = ld16(pw + lr * C::TS + piece * 16);
+    if (row0 + lr < row_end) {
+      st16(out + (size_t)(row0 + lr) * ld + piece * 8, v);
+      float x[8], y[8];
+      unpack16<T>(v, x);
+      unpack16<T>(fw[p], y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot[p] += x[e] * y[e];
+    }
   }
 }
 
@@ -1718,7 +1752,23 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
   }
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   char* scratch = tK + wave * 16 * C::TS;     // (8 waves x 16 rows = exactly the K tile)
-  wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, scratch, lane);
+  // row sums of <d qkv, qkv> (P5AttnArgs::dot_out): a wave's queries and keys are the same 16 tokens, so the three inner products of a token
+  // meet in one lane group.  Its K rows are this wave's store scratch: read them first.
+  const bool want_dot = a.dot_out != nullptr;
+  float dot[2] = {0.f, 0.f};
+  u32x4 fwk[2], fwq[2], fwv[2];
+  if (want_dot) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int off = (wave * 16 + p * 8 + (lane >> 3)) * C::TS + (lane & 7) * 16;
+      fwk[p] = ld16(tK + off);
+      fwq[p] = ld16(tQ + off);
+      fwv[p] = ld16(tV + off);
+    }
+    wave_store_16x64_dot<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, scratch, lane, fwq, dot);
+  } else {
+    wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, scratch, lane);
+  }
 
   // ---- phase B ----
   const int k0 = wave * 16;
@@ -1734,6 +1784,20 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
       mma16<T>(dv[dt], pa, tile_frag_ks<T>(tDO, dt * 16, kc, lane));
       mma16<T>(dk[dt], sa, tile_frag_ks<T>(tQ, dt * 16, kc, lane));
     }
+  }
+  if (want_dot) {
+    wave_store_16x64_dot<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, scratch, lane, fwk, dot);
+    wave_store_16x64_dot<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, scratch, lane, fwv, dot);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float t = dot[p];
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      t += __shfl_xor(t, 4);
+      const int tok = wave * 16 + p * 8 + (lane >> 3);
+      if ((lane & 7) == 0 && tok < a.Lq) a.dot_out[((size_t)b * a.Lq + tok) * a.H + h] = t;
+    }
+    return;
   }
   wave_store_16x64<T>((T*)a.dK + (size_t)b * a.Lk * a.lddk + h * 64, a.lddk, k0, a.Lk, dk, one, scratch, lane);
   wave_store_16x64<T>((T*)a.dV + (size_t)b * a.Lk * a.lddv + h * 64, a.lddv, k0, a.Lk, dv, one, scratch, lane);

@@ -51,6 +51,7 @@ static int launch_attn_bwd_impl(const P5AttnArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // one workgroup per (batch, head) that reads Q, K, V, dO once (p5_attn.h)
     if (g_opt_attn_fused && a.Lq <= 128 && a.Lk <= 128 && a.Lq > 16 && a.Lk > 16) {
+      P5_REQUIRE(a.dot_out == nullptr || p5l_attn_bwd_dot_ok(1, a), "attention backward: dot_out needs self-attention shapes and 16-byte-aligned gradient rows");
       P5_LAUNCH((p5_attn_bwd_fused_kernel<T>), dim3(a.B * a.H), dim3(512), 0, s, a);
       return P5_KCHECK();
     }
@@ -80,6 +81,11 @@ int p5l_attn_bwd_slots(int bf16_mode, int B, int Lq, int Lk) {
   if (bf16_mode && g_opt_attn_fused && Lq <= 128 && Lk <= 128 && Lq > 16 && Lk > 16) return B;
   if (bf16_mode && g_opt_attn_bwd_head && (Lq > 128 || Lk > 128)) return B;
   return B * ((Lq + 63) / 64);
+}
+// P5AttnArgs::dot_out (row sums of <d qkv, qkv>) is written by the fused kernel only: self-attention (Lq == Lk), vector stores
+bool p5l_attn_bwd_dot_ok(int bf16_mode, const P5AttnArgs& a) {
+  return bf16_mode && g_opt_attn_fused && a.Lq == a.Lk && a.Lq <= 128 && a.Lq > 16 && (a.lddq % 8) == 0 && (a.lddk % 8) == 0 && (a.lddv % 8) == 0 &&
+         ((uintptr_t)a.dQ % 16) == 0 && ((uintptr_t)a.dK % 16) == 0 && ((uintptr_t)a.dV % 16) == 0;
 }
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_fwd_impl<bf16>(a, s) : launch_attn_fwd_impl<float>(a, s); }
 int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s) { return bf16_mode ? launch_attn_bwd_impl<bf16>(a, s) : launch_attn_bwd_impl<float>(a, s); }

@@ -25,6 +25,8 @@ enum P5Epi : int {
   P5_EPI_RELU_DROP = 1,   // C = drop(relu(acc))
   P5_EPI_RESID_DROP = 2,  // C = aux + drop(acc)            (aux: residual stream, same dtype as C)
   P5_EPI_MASK_POS = 3,    // C = aux > 0 ? acc * alpha : 0  (relu/dropout backward through saved hidden)
+                          // with ssq_out (p5_gemm5.h only): ssq_out[row][64-column group] = sum of stored C * aux / alpha = the row's share of
+                          // <d pre, pre> -- what the T5LayerNorm backward of the sub-layer's input needs (P5_EPI_NORM_BWD below)
   P5_EPI_ATOMIC = 4,      // C += acc * alpha  (fp32 atomics; split-K wgrad)
   P5_EPI_GELU_GATE = 5,   // gated-GELU forward (T5 v1.1 FFN, HF modeling_t5.py:97-123) fused into the wi GEMM: B = [wi_0; wi_1] read gate-interleaved
                           // (P5GemmArgs::gate_F), C = h = drop(gelu_new(u0) * u1) [M, F], C2 = u = [u0 | u1] [M, 2F] kept for the backward
@@ -33,6 +35,13 @@ enum P5Epi : int {
   P5_EPI_CE_STATS = 8,    // logit-free cross-entropy, forward (P5_T5.py:361-369): nothing is stored but, per row and 64-column group,
                           // (max, sum of exp) of acc * alpha, and the logit at the row's label -> P5GemmArgs::ce_part / ce_lab (p5_gemm5.h)
   P5_EPI_CE_GRAD = 9,     // ... backward: the same GEMM recomputed, C = dlogits = (exp(acc * alpha - lse[row]) - [col == label]) * g[row]
+  P5_EPI_NORM_BWD = 10,   // T5LayerNorm backward (HF modeling_t5.py:59-72 under autograd) in the epilogue of the data-gradient GEMM that produces its
+                          // input gradient (round 6; p5_gemm5.h, 128-row tiles, whole tiles only): acc = dn = dOut W (unfolded W^T copy).  With x = aux
+                          // (the sub-layer's input rows), rstd from `rowss`, w = nb_w (the norm weight) and m = sum(nb_dot[row][:]) / N:
+                          //   xh = x rstd;  v = rstd (acc w - xh m) + nb_rin;  nb_rout = v (fp32);  C = dropout_next(v);  C2 = w * round(xh) (the forward
+                          //   norm's output, which the folded forward never wrote);  nb_dw[row / 64][col] = sum over the 64 rows of acc xh (norm-weight
+                          //   gradient partials).  m needs no pass over the row: sum_j (acc w)_j xh_j = <dOut, Out> over the projection's OUTPUT columns,
+                          //   which the producer of dOut leaves as partial sums (MASK_POS + ssq_out above; P5AttnArgs::dot_out)
   P5_EPI_GELU_GATE_BWD = 7,   // gated-GELU backward fused into the wo data-gradient GEMM: acc = dh [M, F], aux = u [M, 2F] (ldaux), C = du =
                               // [dh u1 gelu'(u0) | dh gelu(u0)] [M, 2F] (ldc); the dropout mask of h is re-hashed (same conditions as above, N = F)
 };
@@ -77,6 +86,11 @@ struct P5GemmArgs {
   float* ce_part; float* ce_lab;
   const float* ce_lse; const float* ce_g;
   int ce_np;
+  // T5LayerNorm backward epilogue (P5_EPI_NORM_BWD): nb_dot [M, nb_dot_nt] partial sums of <dOut, Out> per row, nb_rin / nb_rout the fp32
+  // residual-stream gradient in / out [M, N] (leading dimension N), nb_w [N] the norm weight, nb_dw [M / 64, N] its gradient's partial rows
+  const float* nb_dot; int nb_dot_nt;
+  const float* nb_rin; float* nb_rout;
+  const float* nb_w; float* nb_dw;
 };
 
 // XCD-aware tile order (MI355X: workgroup b runs on XCD b % 8, each XCD has a private 4 MiB L2).  Default: every XCD gets

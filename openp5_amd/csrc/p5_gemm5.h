@@ -19,14 +19,21 @@
 #include "p5_gemm4.h"
 
 // VAR: 0 = the product instances; 1 = the instance that carries the gated-GELU epilogues (P5_EPI_GELU_GATE / _BWD); 2 = the logit-free
-// cross-entropy epilogues (P5_EPI_CE_STATS / _GRAD) -- the product instances do not pay for their registers
-template <bool KS, int ABL = 0, int VAR = 0>
+// cross-entropy epilogues (P5_EPI_CE_STATS / _GRAD); 3 = the T5LayerNorm-backward epilogue (P5_EPI_NORM_BWD, 128-row tiles) -- the product
+// instances do not pay for their registers
+// BMT: rows of a tile.  256 = the product shape above.  128 (round 6) = the N = d_model outputs of the encoder (8192 x 512 is 256 tiles of
+// 128 x 128 but only 128 of 256 x 128 -- half the chip): 2 x 2 compute waves on 64 x 64 wave tiles, four-slot ring of 32 KiB K-steps, the
+// same loader / compute split, so the copies' issue cost stays out of the MFMA stream (p5_gemm2_kernel<128,128,4>, whose four waves do both,
+// moves 8 TB/s into LDS on these shapes).
+template <bool KS, int ABL = 0, int VAR = 0, int BMT = 256>
 __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   constexpr bool GATE = VAR == 1;
   using T = bf16;
-  constexpr int BM = 256, BN = 128, NST = 3;
+  static_assert(BMT == 256 || BMT == 128, "tile rows");
+  constexpr int BM = BMT, BN = 128, NST = BMT == 256 ? 3 : 4;
   constexpr int NWC = 4, NWL = 4;                          // compute waves (2 x 2), loader waves
-  constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
+  constexpr int WTM = BM / 2, WTN = 64, TM = WTM / 16, TN = 4;
+  constexpr int RPG = TM / 4;                              // row blocks whose statistics a lane group fetches in the whole-tile epilogue
   constexpr int ASZ = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int NDA = BM / (8 * NWL), NDB = BN / (8 * NWL), NDMA = NDA + NDB;   // copy instructions per loader wave per K-step
   constexpr int PFD = NST - 1;
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   };
 
   f32x4 acc[TM][TN];
+#define P5_G5_ROWBLOCKS(F) do { F(0); F(1); F(2); F(3); if constexpr (TM > 4) { F(4); F(5); F(6); F(7); } } while (0)
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -247,10 +255,10 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         if (row_ok && col < g.N) {
           const size_t ci = (size_t)row * g.ldc + col;
           const bool full = vec_ok && col + 8 <= g.N;
-          if (g.epi != P5_EPI_STORE && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
-            float av[8];
+          float av[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = 0.f;
+          for (int e = 0; e < 8; ++e) av[e] = 0.f;
+          if (g.epi != P5_EPI_STORE && g.epi != P5_EPI_ATOMIC && g.epi != P5_EPI_ACCUM) {
             if (g.aux) {
               const T* ap = (const T*)g.aux + (size_t)row * g.ldaux + col;
               if (full) unpack16<T>(ld16(ap), av);
@@ -290,12 +298,13 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
               float w[8];
               unpack16<T>(packed, w);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) if (col + e < g.N) ss += w[e] * w[e];
+              for (int e = 0; e < 8; ++e) if (col + e < g.N) ss += g.epi == P5_EPI_MASK_POS ? w[e] * av[e] : w[e] * w[e];
             }
           }
         }
       }
       if (g.ssq_out) {          // (uniform) this wave is the only writer of the row's partial for its 64-column group
+        if (g.epi == P5_EPI_MASK_POS) ss *= 1.f / g.alpha;      // <d pre, pre>: the saved hidden is pre * alpha where it is positive
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         if (g.ssq_nt > 0) {
@@ -337,6 +346,32 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     }
     if constexpr (KS) c.fast32 = false;
     return c;
+  };
+  // P5_EPI_NORM_BWD: the row scalars of a tile, formed BEFORE its K loop -- the accumulators are dead there, so the partial sums may pass
+  // through as many registers as they like, and the first K-step is still on its way.  Lane group gl holds the rows of row blocks
+  // RPG gl .. RPG gl + RPG - 1 (the epilogue fetches them by shuffle): rstd from the d/64 partial sums of squares the producer of x left
+  // behind, and the mean of <dn w, xh> from the partial sums of <dOut, Out> (index order, as everywhere: the same bits every run).
+  float nb_rstd[2] = {0.f, 0.f}, nb_dotm[2] = {0.f, 0.f};
+  auto nb_stats = [&](const Unit& u) {
+    const P5GemmArgs& g = grp.p[u.pi];
+    const int gl = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int q = 0; q < RPG; ++q) {
+      const int row = u.m0 + wm * WTM + (gl * RPG + q) * 16 + li;
+      nb_rstd[q] = gemm_row_rstd(g, row < g.M ? row : g.M - 1);
+      const float* p = g.nb_dot + (size_t)(row < g.M ? row : g.M - 1) * g.nb_dot_nt;
+      float sm = 0.f;
+      int t = 0;
+      if ((g.nb_dot_nt & 3) == 0) {
+#pragma unroll 8
+        for (; t < g.nb_dot_nt; t += 4) {
+          const f32x4 v = *(const f32x4*)(p + t);
+          sm = (((sm + v[0]) + v[1]) + v[2]) + v[3];
+        }
+      }
+      for (; t < g.nb_dot_nt; ++t) sm += p[t];
+      nb_dotm[q] = sm * g.rowss_invd;          // (rowss_invd = 1 / d_model = 1 / N)
+    }
   };
   auto epilogue = [&](const Unit& u, const EpiCtx& cx) {
     if constexpr ((ABL & 8) != 0) {
@@ -408,6 +443,128 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       }
       return;
     }
+    if constexpr (VAR == 3 && !KS) {
+      const P5GemmArgs& g = grp.p[u.pi];
+      {   // (a launch of this instance carries P5_EPI_NORM_BWD problems only: the launcher checks)
+        // ---- T5LayerNorm backward of the sub-layer's input (P5_EPI_NORM_BWD, p5_gemm.h): whole tiles only (the launcher checks).  The row
+        // scalars (rstd, mean of <dn w, xh>) were formed before the K loop (nb_stats); a lane holds, per row block, 2 x 8 consecutive columns.
+        // every [M, N] operand has leading dimension N (the launcher checks): ONE 32-bit element offset per lane, uniform bases and row-block
+        // strides -- five 64-bit lane pointers x four row blocks cost the registers this epilogue does not have
+        const int N = g.N;
+        const int gl = le >> 4, li = le & 15;
+        const int row = u.m0 + wm * WTM + li;
+        const int col0 = u.n0 + wn * WTN + gl * 8;
+        const uint32_t eo = (uint32_t)row * (uint32_t)N + (uint32_t)col0, bs = 16u * (uint32_t)N;
+        const T* const xb = (const T*)g.aux;
+        const float* const rib = g.nb_rin;
+        float* const rob = g.nb_rout;
+        T* const yb = (T*)g.C;
+        T* const nb = (T*)g.C2;
+        const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
+        const uint32_t thr = g.drop.thr, hseed = p5_mix32(p5_seed(g.drop) + g.drop.site_key);
+        const float dscale = g.drop.scale;
+        float wv[2][8], dwv[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 w0 = *(const f32x4*)(g.nb_w + col0 + h * 32), w1 = *(const f32x4*)(g.nb_w + col0 + h * 32 + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { wv[h][r] = w0[r]; wv[h][4 + r] = w1[r]; dwv[h][r] = 0.f; dwv[h][4 + r] = 0.f; }
+        }
+        // loads of the tile: the x rows and the fp32 residual gradient run two row blocks ahead (the next unit's first fragments stay in their
+        // registers across the epilogue: what is left holds two blocks of loads and one of results)
+        constexpr int AD = 2, RD = 2;
+        u32x4 xv[AD][2];
+        f32x4 rv[RD][2][2];
+        auto x_load = [&](int i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) xv[i % AD][h] = ld16(xb + (eo + (uint32_t)i * bs + (uint32_t)h * 32u));
+        };
+        auto r_load = [&](int i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            rv[i % RD][h][0] = *(const f32x4*)(rib + (eo + (uint32_t)i * bs + (uint32_t)h * 32u));
+            rv[i % RD][h][1] = *(const f32x4*)(rib + (eo + (uint32_t)i * bs + (uint32_t)h * 32u + 4u));
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < AD && i < TM; ++i) x_load(i);
+#pragma unroll
+        for (int i = 0; i < RD && i < TM; ++i) r_load(i);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float rs = __shfl(nb_rstd[i % RPG], li + 16 * (i / RPG)), dm = __shfl(nb_dotm[i % RPG], li + 16 * (i / RPG));
+          u32x4 po[2], pn[2];
+          f32x4 ro[2][2];
+          // the keep decisions of the block's 16 elements first, as two bit masks: the hash chains need a dozen temporaries each, and
+          // left to itself the compiler interleaves them with the arithmetic below (46 spilled registers)
+          uint32_t km[2] = {0xFFu, 0xFFu};
+          if (do_drop) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t idx0 = (uint32_t)((row + i * 16) * N + col0 + h * 32);
+              uint32_t m = 0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) m |= ((p5_mix32((idx0 + e) ^ hseed) >> 8) >= thr ? 1u : 0u) << e;
+              km[h] = m;
+            }
+          }
+#ifndef P5_EMU
+          asm volatile("" : "+v"(km[0]), "+v"(km[1]));
+#endif
+          const float ds = do_drop ? dscale : 1.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float x[8], o[8], nr[8];
+            unpack16<T>(xv[i % AD][h], x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float dy = acc[i][2 * h + (e >> 2)][e & 3];
+              const float xh = x[e] * rs;
+              dwv[h][e] += dy * xh;
+              const float v = rs * (dy * wv[h][e] - xh * dm) + rv[i % RD][h][e >> 2][e & 3];
+              ro[h][e >> 2][e & 3] = v;
+              o[e] = ((km[h] >> e) & 1u) ? v * ds : 0.f;
+              nr[e] = wv[h][e] * to_f<T>(from_f<T>(xh));
+            }
+            po[h] = pack16<T>(o);
+            pn[h] = pack16<T>(nr);
+          }
+          if (i + AD < TM) x_load(i + AD);
+          if (i + RD < TM) r_load(i + RD);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t o = eo + (uint32_t)i * bs + (uint32_t)h * 32u;
+            *(f32x4*)(rob + o) = ro[h][0];
+            *(f32x4*)(rob + (o + 4u)) = ro[h][1];
+            st16(yb + o, po[h]);
+            if (nb) st16(nb + o, pn[h]);
+          }
+        }
+        // norm-weight gradient: this wave's 64 rows summed per column (16 lanes of a lane group hold the same columns), one partial row
+        // per wave row block of 64, reduced later in row order (p5_reduce_rows_multi_kernel) -- no atomics
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = dwv[h][e];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            dwv[h][e] = t;
+          }
+        if (li == 0) {
+          float* const dp = g.nb_dw + (size_t)((u.m0 + wm * WTM) >> 6) * N + col0;
+          static_assert(WTM == 64 || VAR != 3, "norm-backward epilogue: one partial row per 64-row wave tile");
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            *(f32x4*)(dp + h * 32) = (f32x4){dwv[h][0], dwv[h][1], dwv[h][2], dwv[h][3]};
+            *(f32x4*)(dp + h * 32 + 4) = (f32x4){dwv[h][4], dwv[h][5], dwv[h][6], dwv[h][7]};
+          }
+        }
+        return;
+      }
+    }
     // Fast path: a whole tile inside the output, 16-byte stores.  Everything the eight row blocks need from the problem descriptor
     // was read ONCE into scalars (EpiCtx): the general code below reads descriptor
     // fields where it uses them, and with the accumulators holding the scalar registers' spill space hipcc re-issues those kernarg
@@ -426,7 +583,9 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           }
           cp += step;
         };
-        rows32(acc[0]); rows32(acc[1]); rows32(acc[2]); rows32(acc[3]); rows32(acc[4]); rows32(acc[5]); rows32(acc[6]); rows32(acc[7]);
+#define P5_G5_R32(i) rows32(acc[i])
+        P5_G5_ROWBLOCKS(P5_G5_R32);
+#undef P5_G5_R32
         return;
       }
     }
@@ -436,7 +595,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         float* const ssq = cx.ssq;
         const int ssq_nt = cx.ssq_nt;
         const uint32_t thr = cx.thr, hseed = cx.hseed;
-        const float dscale = cx.dscale, alpha = cx.alpha;
+        const float dscale = cx.dscale, alpha = cx.alpha, inv_alpha = 1.f / cx.alpha;
         const float* const rowss = cx.rowss;
         const int rowss_nt = cx.rowss_nt;
         const float invd = cx.invd, eps = cx.eps;
@@ -453,22 +612,23 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         // 16 us of the 41 us of an 8192x2048x512 launch into "epilogue arithmetic": the eight row blocks each loaded their row statistics
         // and aux rows, waited, computed and stored -- and because vmcnt counts stores as well as loads on this part, the wait for row
         // block i+1's loads was also a wait for row block i's stores to be acknowledged: eight dependent memory round trips per tile.
-        // Now: lane group gl fetches the statistics of row blocks 2gl, 2gl+1 (16-byte loads, summed in index order as everywhere else)
-        // and the scale reaches the other lane groups by a shuffle; the aux rows run through a four-block ring (below).
+        // Now: lane group gl fetches the statistics of row blocks RPG gl .. RPG gl + RPG - 1 (RPG = 2 on 256-row tiles; 16-byte loads, summed
+        // in index order as everywhere else) and the scale reaches the other lane groups by a shuffle; the aux rows run through a
+        // four-block ring (below).
         float sc2[2] = {alpha, alpha};
         if (rowss) {
-          const int rb = row + gl * 32;                       // row of block 2gl for this lane
+          const int rb = row + gl * 16 * RPG;                 // row of block RPG gl for this lane
           if (rowss_nt > 0 && (rowss_nt & 3) == 0 && rowss_nt <= 16) {
             f32x4 pv[2][4];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < RPG; ++q) {
               const float* p = rowss + (size_t)(rb + q * 16) * rowss_nt;
 #pragma unroll
               for (int t = 0; t < 4; ++t)
                 if (t * 4 < rowss_nt) pv[q][t] = *(const f32x4*)(p + t * 4);
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < RPG; ++q) {
               float ss = 0.f;
 #pragma unroll
               for (int t = 0; t < 4; ++t)
@@ -477,7 +637,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
             }
           } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < RPG; ++q) {
               float ss = 0.f;
               if (rowss_nt > 0) {
                 const float* p = rowss + (size_t)(rb + q * 16) * rowss_nt;
@@ -507,8 +667,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           }
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            // scale of row block i: held by lane group i / 2 (same row-in-block)
-            const float sc = rowss ? __shfl((i & 1) ? sc2[1] : sc2[0], (le & 15) + 16 * (i >> 1)) : alpha;
+            // scale of row block i: held by lane group i / RPG (same row-in-block)
+            const float sc = rowss ? __shfl(sc2[i % RPG], (le & 15) + 16 * (i / RPG)) : alpha;
             float sq = 0.f;
             u32x4 packed[TN / 2];
 #pragma unroll
@@ -516,8 +676,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
               float v[8];
 #pragma unroll
               for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * h][r] * sc; v[4 + r] = acc[i][2 * h + 1][r] * sc; }
+              float av[8];
               if constexpr (EK != 0) {
-                float av[8];
                 if constexpr (EK >= 3) unpack16<T>(auxv[i % AD][h], av);
                 const uint32_t idx0 = (uint32_t)((row + i * 16) * N + col0 + h * 32);
 #pragma unroll
@@ -535,7 +695,10 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
                 float w[8];
                 unpack16<T>(packed[h], w);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sq += w[e] * w[e];
+                for (int e = 0; e < 8; ++e) {
+                  if constexpr (EK == 5) sq += w[e] * av[e];      // (MASK_POS + ssq_out: <d pre, pre> * alpha, see P5_EPI_MASK_POS)
+                  else sq += w[e] * w[e];
+                }
               }
             }
             if constexpr (EK >= 3) {
@@ -554,6 +717,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
 #endif
             }
             if (ssq) {
+              if constexpr (EK == 5) sq *= inv_alpha;
               sq += __shfl_xor(sq, 16);
               sq += __shfl_xor(sq, 32);
               const int cg = (u.n0 + wn * WTN) >> 6;
@@ -572,7 +736,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           T* const up = (T*)cx.C2 + (size_t)row * ldc2 + hc;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const float sc = rowss ? __shfl((i & 1) ? sc2[1] : sc2[0], (le & 15) + 16 * (i >> 1)) : alpha;
+            const float sc = rowss ? __shfl(sc2[i % RPG], (le & 15) + 16 * (i / RPG)) : alpha;
             float a[8], b[8], hv[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = acc[i][0][r] * sc; a[4 + r] = acc[i][1][r] * sc; b[r] = acc[i][2][r] * sc; b[4 + r] = acc[i][3][r] * sc; }
@@ -672,7 +836,9 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           }
           cp += (size_t)16 * ldc;
         };
-        rows(acc[0]); rows(acc[1]); rows(acc[2]); rows(acc[3]); rows(acc[4]); rows(acc[5]); rows(acc[6]); rows(acc[7]);
+#define P5_G5_R(i) rows(acc[i])
+        P5_G5_ROWBLOCKS(P5_G5_R);
+#undef P5_G5_R
       }
       return;
     }
@@ -680,14 +846,9 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     const uint32_t seed = p5_seed(g.drop);
     const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
     const bool vec_ok = (g.ldc & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.aux == nullptr || ((g.ldaux & 7) == 0 && ((uintptr_t)g.aux & 15) == 0));
-    epi_rows(acc[0], 0, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[1], 1, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[2], 2, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[3], 3, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[4], 4, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[5], 5, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[6], 6, u, g, seed, do_drop, vec_ok, le);
-    epi_rows(acc[7], 7, u, g, seed, do_drop, vec_ok, le);
+#define P5_G5_ER(i) epi_rows(acc[i], i, u, g, seed, do_drop, vec_ok, le)
+    P5_G5_ROWBLOCKS(P5_G5_ER);
+#undef P5_G5_ER
   };
 
   // Both operands' fragments double-buffered (96 registers): the 12 reads of the next K-chunk go out under the first 24 of a
@@ -726,6 +887,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
   int buf = 0;
   for (int it = 0; it < nmy; ++it) {
     const Unit u = decode(it);
+    if constexpr (VAR == 3 && !KS) nb_stats(u);
     int k = 0;
     do {
       const int nb1 = buf == NST - 1 ? 0 : buf + 1;
@@ -736,5 +898,16 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     //  the 24 live scalars spill through a vector register's lanes and the main loop slows from 14.8 to 20 us on 8192x2048x512)
     epilogue(u, load_ctx(u));
     zero_acc();
+    if constexpr (VAR == 3 && !KS) {
+      // the norm-backward epilogue needs the registers the next unit's first fragments were prefetched into: read them again (their K-step
+      // stays in slot `buf` until this wave has passed the next barrier)
+      if (it + 1 < nmy) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb0[j] = frag(buf, true, j, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa0[i] = frag(buf, false, i, 0);
+      }
+    }
   }
 }
+#undef P5_G5_ROWBLOCKS

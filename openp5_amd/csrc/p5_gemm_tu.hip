@@ -25,6 +25,8 @@ int g_opt_g4_nst = getenv("P5_G4_NST") ? atoi(getenv("P5_G4_NST")) : 3;         
 int g_opt_g4_wgs = getenv("P5_G4_WGS") ? atoi(getenv("P5_G4_WGS")) : 256;        // workgroups per launch (one per CU)
 int g_opt_split_pipe = getenv("P5_SPLIT_PIPE") ? atoi(getenv("P5_SPLIT_PIPE")) : 1;    // split-f16 fp32 GEMMs: the three-deep pipelined kernel (0 = p5_gemm_kernel<MM = 1>)
 int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 0;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them (0 = the fp32 rule: from 512; measured on the verification pass, 64x64 tiles win below that: 5.05 vs 5.30 ms per batch)
+int g_opt_gemm_ws128 = getenv("P5_GEMM_WS128") ? atoi(getenv("P5_GEMM_WS128")) : 1;    // N = d_model outputs (128..256 tiles of 128x128) on the wave-specialised 128x128 instance, from K = gemm_ws128_min_k
+int g_opt_gemm_ws128_min_k = getenv("P5_GEMM_WS128_MIN_K") ? atoi(getenv("P5_GEMM_WS128_MIN_K")) : 512;
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -129,8 +131,8 @@ static int launch_gemm4_cfg(P5GemmGroup& grp, hipStream_t s) {
   P5_LAUNCH((p5_gemm4_kernel<BM, BN, WMW, WNW, NST, KS, 0, OCC>), dim3(nwg), dim3(WMW * WNW * 64), 0, s, grp);
   return P5_KCHECK();
 }
-template <bool KS>
-static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit bookkeeping as launch_gemm4_cfg<256, 128, ...>, 4 loader + 4 compute waves
+template <bool KS, int BM = 256>
+static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit bookkeeping as launch_gemm4_cfg<BM, 128, ...>, 4 loader + 4 compute waves
   int units = 0;
   for (int i = 0; i < grp.nprob; ++i) {
     P5GemmArgs& g = grp.p[i];
@@ -142,7 +144,7 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
     g.g4_tiles_n = (g.N + 127) / 128;
     g.g4_nk = g.K / 64 / g.splitk;
     grp.unit_begin[i] = units;
-    units += ((g.M + 255) / 256) * g.g4_tiles_n * g.splitk;
+    units += ((g.M + BM - 1) / BM) * g.g4_tiles_n * g.splitk;
   }
   grp.unit_begin[grp.nprob] = units;
   grp.total_units = units;
@@ -152,8 +154,33 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
     double fl = 0.0;
     for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;
     P5_PROF_FLOPS(fl);
-    P5_PROF_TAG(KS ? "KS: grouped weight gradients" : "KC: forward / data-gradient GEMMs");
+    P5_PROF_TAG(KS ? "KS: grouped weight gradients" : (BM == 128 ? "KC 128x128: N = d_model outputs" : "KC: forward / data-gradient GEMMs"));
     if (grp.nprob == 1) P5_PROF_SHAPE(grp.p[0].M, grp.p[0].N, grp.p[0].K);
+  }
+  if constexpr (BM == 128) {
+    bool special = false;
+    for (int i = 0; i < grp.nprob; ++i)
+      special = special || grp.p[i].epi == P5_EPI_GELU_GATE || grp.p[i].epi == P5_EPI_GELU_GATE_BWD || grp.p[i].epi == P5_EPI_CE_STATS || grp.p[i].epi == P5_EPI_CE_GRAD;
+    P5_REQUIRE(!KS && !special, "gemm5: the 128-row tile carries the plain K-contiguous epilogues only");
+    bool nbw = false;
+    for (int i = 0; i < grp.nprob; ++i) nbw = nbw || grp.p[i].epi == P5_EPI_NORM_BWD;
+    for (int i = 0; i < grp.nprob && nbw; ++i) {
+      const P5GemmArgs& g = grp.p[i];
+      P5_REQUIRE(g.epi == P5_EPI_NORM_BWD, "gemm5: a T5LayerNorm-backward launch carries problems of that kind only");
+      P5_REQUIRE((g.M % 128) == 0 && (g.N % 128) == 0 && !g.c_f32 && g.splitk == 1, "gemm5: the T5LayerNorm-backward epilogue writes whole 128x128 tiles");
+      P5_REQUIRE(g.ldc == g.N && g.ldaux == g.N && (g.C2 == nullptr || g.ldc2 == g.N) && (long long)g.M * g.N < (1ll << 30), "gemm5: T5LayerNorm-backward operands are [M, N] with leading dimension N");
+      P5_REQUIRE(g.C && g.aux && g.rowss && g.rowss_nt > 0 && g.nb_dot && g.nb_dot_nt > 0 && g.nb_rin && g.nb_rout && g.nb_w && g.nb_dw, "gemm5: T5LayerNorm-backward epilogue arguments");
+      P5_REQUIRE((g.ldc % 8) == 0 && (g.ldaux % 8) == 0 && ((uintptr_t)g.C % 16) == 0 && ((uintptr_t)g.aux % 16) == 0 && ((uintptr_t)g.nb_rin % 16) == 0 &&
+                 ((uintptr_t)g.nb_rout % 16) == 0 && ((uintptr_t)g.nb_w % 16) == 0 && ((uintptr_t)g.nb_dw % 16) == 0 &&
+                 (g.C2 == nullptr || ((g.ldc2 % 8) == 0 && ((uintptr_t)g.C2 % 16) == 0)), "gemm5: T5LayerNorm-backward epilogue alignment");
+    }
+    if (nbw) {
+      P5_PROF_TAG("KC 128x128 + T5LayerNorm-backward epilogue");
+      P5_LAUNCH((p5_gemm5_kernel<false, 0, 3, 128>), dim3(nwg), dim3(512), 0, s, grp);
+    } else {
+      P5_LAUNCH((p5_gemm5_kernel<false, 0, 0, 128>), dim3(nwg), dim3(512), 0, s, grp);
+    }
+    return P5_KCHECK();
   }
 #ifdef P5_GEMM5_ABL      // lab builds only (tools/lab/build_ablations.sh): the forward / data-gradient instance with parts of it removed, timed INSIDE the step
   P5_LAUNCH((p5_gemm5_kernel<KS, KS ? 0 : P5_GEMM5_ABL>), dim3(nwg), dim3(512), 0, s, grp);
@@ -182,6 +209,10 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
 }
 int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s) {
   P5_REQUIRE(grp.nprob >= 1 && grp.nprob <= P5_MAX_GROUP, "gemm4: 1..8 problems per launch");
+  if (cfg == P5_G5_128x128) {
+    P5_REQUIRE(!ks, "gemm5: the 128-row tile is K-contiguous only");
+    return launch_gemm5<false, 128>(grp, s);
+  }
   if (cfg == P5_G5_256x128 || (cfg == P5_G4_256x128 && (g_opt_gemm_ws & (ks ? 2 : 1)))) return ks ? launch_gemm5<true>(grp, s) : launch_gemm5<false>(grp, s);
   if (ks) {
     if (cfg == P5_G4_256x128) return launch_gemm4_cfg<256, 128, 4, 2, 3, true>(grp, s);
@@ -206,6 +237,11 @@ bool p5l_gemm_gate_ok(int M, int N, int K, int lda, int ldb) {
          (ldb % 64) == 0 && (long)(M / 256) * (N / 128) >= g_opt_gemm_wide_min_tiles;
 }
 
+// the T5LayerNorm-backward epilogue (P5_EPI_NORM_BWD): whole 128x128 tiles of the wave-specialised kernel, any number of them
+bool p5l_gemm_normbwd_ok(int M, int N, int K, int lda, int ldb) {
+  return (g_opt_gemm_ws & 1) && !g_opt_gemm_tile && !g_opt_gemm_v2 && (M % 128) == 0 && (N % 128) == 0 && (K % 64) == 0 && (lda % 64) == 0 && (ldb % 64) == 0;
+}
+
 bool p5l_gemm_ce_ok(int M, int N, int K, int lda, int ldb) {
   return g_opt_gemm_wide && (g_opt_gemm_ws & 1) && !g_opt_gemm_tile && !g_opt_gemm_v2 && (K % 64) == 0 && (lda % 64) == 0 && (ldb % 64) == 0 &&
          (long)((M + 255) / 256) * ((N + 127) / 128) >= g_opt_gemm_wide_min_tiles;
@@ -228,6 +264,21 @@ static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
     return launch_gemm4(P5_G4_256x128, false, grp, s);
   }
   g.ce_labels = nullptr; g.ce_part = nullptr; g.ce_lab = nullptr; g.ce_lse = nullptr; g.ce_g = nullptr; g.ce_np = 0;
+  if (g.epi == P5_EPI_NORM_BWD) {
+    P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && p5l_gemm_normbwd_ok(g.M, g.N, g.K, g.lda, g.ldb),
+               "gemm: the T5LayerNorm-backward epilogue runs on 128-row tiles of the wave-specialised bf16 kernel (caller: check p5l_gemm_normbwd_ok)");
+    P5GemmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.nprob = 1;
+    grp.p[0] = g;
+    grp.p[0].splitk = 1;
+    grp.p[0].gate_F = 0;
+    return launch_gemm4(P5_G5_128x128, false, grp, s);
+  }
+  g.nb_dot = nullptr; g.nb_rin = nullptr; g.nb_rout = nullptr; g.nb_w = nullptr; g.nb_dw = nullptr; g.nb_dot_nt = 0;
+  if (g.epi == P5_EPI_MASK_POS && g.ssq_out)
+    P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && !g.c_f32 && g.ssq_nt > 0 && p5l_gemm_gate_ok(g.M, g.N, g.K, g.lda, g.ldb),
+               "gemm: row sums of <d pre, pre> (MASK_POS + ssq_out) exist in the wide bf16 kernel only (caller: check p5l_gemm_gate_ok)");
   if (g.epi == P5_EPI_GELU_GATE || g.epi == P5_EPI_GELU_GATE_BWD) {
     P5_REQUIRE(sizeof(T) == 2 && !g.a_ks && !g.b_ks && g.splitk <= 1 && !g.c_f32 && p5l_gemm_gate_ok(g.M, g.N, g.K, g.lda, g.ldb),
                "gemm: the gated-GELU epilogues need the whole-tile path of the wide bf16 kernel (caller: check p5l_gemm_gate_ok)");
@@ -260,6 +311,16 @@ static int launch_gemm_impl(P5GemmArgs g, hipStream_t s) {
       grp.p[0] = g;
       grp.p[0].splitk = 1;
       return launch_gemm4(P5_G4_256x128, false, grp, s);
+    }
+    // narrow outputs (N = d_model): one 128x128 tile per CU, loader waves + compute waves (round 6)
+    if (kc && g_opt_gemm_ws128 && (g_opt_gemm_ws & 1) && t128 >= g_opt_gemm_ring128_min_tiles && t128 <= 256 && g.K >= g_opt_gemm_ws128_min_k && g.epi != P5_EPI_ATOMIC &&
+        g.epi != P5_EPI_ACCUM) {
+      P5GemmGroup grp;
+      memset(&grp, 0, sizeof(grp));
+      grp.nprob = 1;
+      grp.p[0] = g;
+      grp.p[0].splitk = 1;
+      return launch_gemm4(P5_G5_128x128, false, grp, s);
     }
     // narrow outputs (N = d_model) with a long reduction: one 128x128 tile per CU on the four-slot ring instead of 64x64 tiles
     if (kc && g_opt_gemm_ring_n512 && t128 >= g_opt_gemm_ring128_min_tiles && t128 <= 256 && g.K >= g_opt_gemm_ring128_min_k && g.epi != P5_EPI_ATOMIC) {

@@ -51,6 +51,8 @@ extern int g_opt_gemm_ring128_min_tiles;
 extern int g_opt_g4_nst;
 extern int g_opt_g4_wgs;
 extern int g_opt_gemm_ws;
+extern int g_opt_gemm_ws128;
+extern int g_opt_gemm_ws128_min_k;
 extern int g_opt_attn_fwd_wg;
 extern int g_opt_attn_fwd_head;
 extern int g_opt_attn_bwd_head;
@@ -59,16 +61,18 @@ extern int g_opt_attn_op_keep_bits;
 extern int g_opt_attn_fused;
 extern int g_opt_attn_small;
 
-enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2, P5_G5_256x128 = 3 };
+enum { P5_G4_128x128 = 0, P5_G4_256x128 = 1, P5_G4_128x256 = 2, P5_G5_256x128 = 3, P5_G5_128x128 = 4 };
 // ---- launchers ----
 int p5l_gemm_bf16(P5GemmArgs g, hipStream_t s);
 int p5l_gemm_f32(P5GemmArgs g, hipStream_t s);
 bool p5l_gemm_gate_ok(int M, int N, int K, int lda, int ldb);
 bool p5l_gemm_ce_ok(int M, int N, int K, int lda, int ldb);
+bool p5l_gemm_normbwd_ok(int M, int N, int K, int lda, int ldb);
 int launch_gemm4(int cfg, bool ks, P5GemmGroup& grp, hipStream_t s);
 int p5l_attn_fwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);
 int p5l_attn_bwd(int bf16_mode, const P5AttnArgs& a, hipStream_t s);
 int p5l_attn_bwd_slots(int bf16_mode, int B, int Lq, int Lk);
+bool p5l_attn_bwd_dot_ok(int bf16_mode, const P5AttnArgs& a);
 template <class T> static inline int launch_gemm(const P5GemmArgs& g, hipStream_t s) { return sizeof(T) == 2 ? p5l_gemm_bf16(g, s) : p5l_gemm_f32(g, s); }
 template <class T> static inline int launch_attn_fwd(const P5AttnArgs& a, hipStream_t s) { return p5l_attn_fwd(sizeof(T) == 2, a, s); }
 template <class T> static inline int launch_attn_bwd(const P5AttnArgs& a, hipStream_t s) { return p5l_attn_bwd(sizeof(T) == 2, a, s); }

@@ -160,6 +160,8 @@ struct P5Engine {
   float* emb_part[P5_EMB_MAXSETS] = {};
   float* dres_dec0 = nullptr;            // [Md, d] gradient of the decoder's embedding rows (kept until the last stage)
   float* dres_out_override = nullptr;    // the next swap_norm_bwd writes its residual gradient here
+  float* nb_dotbuf = nullptr;            // [rows, max(d_ff / 64, n_heads)] partial sums of <dOut, Out> per row: producer = the kernel that writes dOut, consumer = the P5_EPI_NORM_BWD GEMM that follows it
+  bool nb_done = false;                  // the sub-layer's norm backward ran in the epilogue of its data-gradient GEMM: the caller skips swap_norm_bwd
   int norm_slot = 0;
   int sub = -1;
   bool d_enc_started = false;
@@ -543,13 +545,17 @@ static int rmsnorm_fwd(hipStream_t s, void* y, float* rstd, const void* x, const
   P5_LAUNCH((p5_rmsnorm_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, (T*)y, rstd, (const T*)x, w, rows, d, eps, drop);
   return P5_KCHECK();
 }
+// workgroups of the norm backward (4 rows per workgroup and pass): with fewer than rows / 8 of them a wave makes several passes and its
+// stores of one pass overlap its loads of the next
+static int g_opt_norm_bwd_blocks = getenv("P5_NORM_BWD_BLOCKS") ? atoi(getenv("P5_NORM_BWD_BLOCKS")) : 1024;
 template <class T>
 static int rmsnorm_bwd(hipStream_t s, float* dres_out, void* dy_next, float* dw, const void* dy, const void* x, const float* w,
                        const float* rstd, const float* dres_in, int rows, int d, P5Drop din, P5Drop dnext, float* dw_partial = nullptr,
                        int* nblocks_out = nullptr, const float* ssq_part = nullptr, void* n_out = nullptr, float eps = 0.f) {
   P5_REQUIRE(d % TT<T>::EPF == 0 && d <= 1024, "rmsnorm: d_model must be <= 1024 and a multiple of 8");
   int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  const int cap = g_opt_norm_bwd_blocks < 64 ? 64 : (g_opt_norm_bwd_blocks > 1024 ? 1024 : g_opt_norm_bwd_blocks);     // (the partial-sum scratch holds 1024 rows per norm)
+  if (blocks > cap) blocks = cap;
   if (nblocks_out) *nblocks_out = blocks;
   const int nch = (d / TT<T>::EPF + 63) / 64;          // 16-byte pieces per lane
 #define P5_NBWD(N) P5_LAUNCH((p5_rmsnorm_bwd_kernel<T, N>), dim3(blocks), dim3(256), 0, s, dres_out, (T*)dy_next, dw, (const T*)dy, (const T*)x, w, rstd, \
@@ -684,6 +690,7 @@ static int64_t layout_ws(P5Engine* e, char* base, int B, int L, int T, bool with
     e->Dvec = (float*)b.take((size_t)B * H * (L > T ? L : T) * 4);
     e->rel_partial = (float*)b.take(((size_t)c.n_enc_layers * rel_slots(B, L) + (size_t)c.n_dec_layers * rel_slots(B, T > 0 ? T : 1)) * c.rel_buckets * H * 4);
     e->dw_scratch = (float*)b.take((size_t)(2 * c.n_enc_layers + 3 * c.n_dec_layers + 2) * 1024 * d * 4);
+    e->nb_dotbuf = (float*)b.take(Mx * (size_t)((F / 64 > H ? F / 64 : H) + 4) * 4);
     {
       const size_t n0 = M + Md, n1 = M;
       e->emb_idx[0] = (int*)b.take(4 * n0 * 4); e->emb_idx[1] = (int*)b.take(4 * n1 * 4);
@@ -899,11 +906,61 @@ static int forward_impl(P5Engine* e, float* nll_out, hipStream_t s) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
+static int norm_flush(P5Engine* e, hipStream_t main);
+// T5LayerNorm backward in the epilogue of the data-gradient GEMM that produces the norm's input gradient (P5_EPI_NORM_BWD, p5_gemm.h;
+// round 6): no `dn` round trip, no stand-alone launch.  Needs the folded-norm forward (statistics as partial sums, n written by the
+// backward), the transposed weight copy (K-contiguous operands), whole 128-row tiles, and a producer of dOut that leaves the row sums of
+// <dOut, Out> in e->nb_dotbuf: the wide wo data-gradient GEMM (ReLU FFN) or the fused attention backward (encoder self-attention).
+static int g_opt_norm_bwd_fuse = getenv("P5_NORM_BWD_FUSE") ? atoi(getenv("P5_NORM_BWD_FUSE")) : 1;
+// (option 1: only where the N = d_model data gradient runs on 128-row tiles anyway -- at most one tile per CU, T5-small at the benchmark
+//  batch; beyond that the 256x128 kernel's K loop is worth more than the saved pass: a T5-large FFN data gradient is 312 us there against 423.
+//  2: wherever the shapes allow)
+template <class T> static bool nb_fused(const P5Engine* e, int rows, int K) {
+  const int d = e->c.d_model;
+  return sizeof(T) == 2 && g_opt_norm_bwd_fuse != 0 && norm_fused<T>(e) && e->St != nullptr && g_opt_dgrad_t && e->nb_dotbuf != nullptr && (K % 64) == 0 &&
+         p5l_gemm_normbwd_ok(rows, d, K, K, K) && (g_opt_norm_bwd_fuse >= 2 || (long)(rows / 128) * (d / 128) <= 256);
+}
+// dOut [rows, K] (T) x W^T copy -> residual gradient out (fp32), dy_next (T, dropout of the preceding sub-layer re-applied), n (T), norm-weight
+// gradient partials; everything swap_norm_bwd does around its kernel, around the GEMM instead
 template <class T>
-static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int stack, int li) {
+static int norm_bwd_gemm(P5Engine* e, hipStream_t s, const void* dOut, int K, int64_t w_off, int rows, const void* x, const float* ssq, void* n_out,
+                         int64_t ln_off, P5Drop dnext, int dot_nt) {
+  const int d = e->c.d_model;
+  float* out = (e->dres_cur == e->dres_a) ? e->dres_b : e->dres_a;
+  if (e->dres_out_override) { out = e->dres_out_override; e->dres_out_override = nullptr; }
+  end_sublayer_sync(e, s);             // (the epilogue writes dy_next and n: the set they live in must have been read out)
+  float* part = e->dw_scratch + (size_t)(e->norm_slot++) * 1024 * d;
+  P5_REQUIRE(rows / 64 <= 1024, "norm backward epilogue: more than 1024 partial rows of the norm-weight gradient");
+  P5GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dOut; g.B = (const T*)e->St + w_off; g.C = e->dy_next; g.C2 = n_out; g.aux = x;
+  g.M = rows; g.N = d; g.K = K; g.lda = K; g.ldb = K; g.ldc = d; g.ldc2 = d; g.ldaux = d;
+  g.epi = P5_EPI_NORM_BWD; g.alpha = 1.f; g.drop = dnext; g.splitk = 1;
+  g.rowss = ssq; g.rowss_nt = d / 64; g.rowss_invd = 1.0f / (float)d; g.rowss_eps = e->c.eps;
+  g.nb_dot = e->nb_dotbuf; g.nb_dot_nt = dot_nt; g.nb_rin = e->dres_cur; g.nb_rout = out; g.nb_w = e->P + ln_off; g.nb_dw = part;
+  P5_TRY(launch_gemm<T>(g, s));
+  {
+    P5ReduceMulti& r = e->nr_pending;
+    if (r.n == P5_REDUCE_MULTI_MAX) P5_TRY(norm_flush(e, s));
+    r.d = d;
+    r.nrows[r.n] = rows / 64;
+    r.dst_off[r.n] = ln_off;
+    r.part_off[r.n] = part - e->dw_scratch;
+    r.n++;
+  }
+  e->dres_cur = out;
+  e->nb_done = true;
+  return 0;
+}
+
+// nb_*: the T5LayerNorm in front of the sub-layer (its input rows, their statistics, where n goes, the norm weight, the dropout of the
+// sub-layer BEFORE it) -- used when the norm backward runs inside the wi data-gradient GEMM; e->nb_done then tells the caller
+template <class T>
+static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int stack, int li, P5Drop nb_dnext = no_drop()) {
   // in: e->dy = masked grad wrt the wo output (T), e->dres_cur = grad wrt the sub-layer output (fp32)
   const P5Config& c = e->c;
   const int d = c.d_model, F = c.d_ff;
+  e->nb_done = false;
   const float hscale = (e->training && c.dropout > 0.f) ? 1.f / (1.f - c.dropout) : 1.f;
   P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.h_ff, F, e->G + lo.wo, rows, d, F));
   if (c.gated_gelu) {
@@ -924,6 +981,18 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
     }
     P5_TRY(linear_wgrad<T>(e, s, e->du, 2 * F, l.n_ff, d, e->G + lo.wi, rows, 2 * F, d));
     P5_TRY(dgrad_w<T>(e, s, e->du, 2 * F, lo.wi, e->dn, d, rows, 2 * F, d));
+  } else if (nb_fused<T>(e, rows, F) && p5l_gemm_gate_ok(rows, F, d, d, d) && l.ssq_ff && l.n_ff) {
+    // dh = mask(dy Wo) leaves the row sums of <dh, pre> behind (32 partial sums per row at d_ff = 2048) ...
+    P5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = e->dy; g.B = (const T*)e->St + lo.wo; g.C = e->dh; g.aux = l.h_ff;
+    g.M = rows; g.N = F; g.K = d; g.lda = d; g.ldb = d; g.ldc = F; g.ldaux = F;
+    g.epi = P5_EPI_MASK_POS; g.alpha = hscale; g.drop = no_drop();
+    g.ssq_out = e->nb_dotbuf; g.ssq_nt = F / 64;
+    P5_TRY(launch_gemm<T>(g, s));
+    P5_TRY(linear_wgrad<T>(e, s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
+    // ... and the wi data-gradient GEMM finishes the sub-layer: norm backward, residual add, next dy, n for the deferred weight gradient
+    P5_TRY(norm_bwd_gemm<T>(e, s, e->dh, F, lo.wi, rows, l.x_ff, l.ssq_ff, l.n_ff, lo.ff_ln, nb_dnext, F / 64));
   } else {
     P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.wo, e->dh, F, rows, d, F, P5_EPI_MASK_POS, l.h_ff, F, hscale));
     P5_TRY(linear_wgrad<T>(e, s, e->dh, F, l.n_ff, d, e->G + lo.wi, rows, F, d));
@@ -932,7 +1001,7 @@ static int ffn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l,
   return 0;
 }
 
-static int norm_flush(P5Engine* e, hipStream_t main) {
+int norm_flush(P5Engine* e, hipStream_t main) {
   P5ReduceMulti& r = e->nr_pending;
   if (r.n == 0) return 0;
   P5_LAUNCH(p5_reduce_rows_multi_kernel, dim3((r.d + 15) / 16, r.n), dim3(256), 0, wgrad_stream(e, main), r, e->G, (const float*)e->dw_scratch);
@@ -966,9 +1035,10 @@ static int swap_norm_bwd(P5Engine* e, hipStream_t s, const void* x, int64_t ln_o
 }
 
 template <class T>
-static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int Lq, bool is_dec, int li) {
+static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSave& l, int rows, int Lq, bool is_dec, int li, P5Drop nb_dnext = no_drop()) {
   const P5Config& c = e->c;
   const int d = c.d_model, in = e->inner, H = c.n_heads;
+  e->nb_done = false;
   P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_sa, in, e->G + lo.sa.o, rows, d, in));
   P5_TRY(dgrad_w<T>(e, s, e->dy, d, lo.sa.o, e->dO, in, rows, d, in));
   P5AttnArgs a;
@@ -988,8 +1058,13 @@ static int self_attn_bwd(P5Engine* e, hipStream_t s, const LayerOff& lo, LayerSa
   a.lddq = a.lddk = a.lddv = 3 * in; a.causal = is_dec ? 1 : 0;
   a.drop = mk_drop(e, is_dec ? 1 : 0, li, 1);
   a.keep_bits = (!is_dec && g_opt_attn_fwd_head && g_opt_attn_bwd_head && g_opt_attn_keep_bits) ? l.keep_sa : nullptr;
+  // the attention backward leaves <dq, q> + <dk, k> + <dv, v> per token and head behind, and the qkv data-gradient GEMM runs the T5LayerNorm
+  // backward of the sub-layer's input in its epilogue (norm_bwd_gemm above)
+  const bool fuse = nb_fused<T>(e, rows, 3 * in) && p5l_attn_bwd_dot_ok(sizeof(T) == 2, a) && l.ssq_sa && l.n_sa;
+  if (fuse) a.dot_out = e->nb_dotbuf;
   P5_TRY(launch_attn_bwd<T>(a, s));
   P5_TRY(linear_wgrad<T>(e, s, e->dqkv, 3 * in, l.n_sa, d, e->G + lo.sa.q, rows, 3 * in, d));
+  if (fuse) return norm_bwd_gemm<T>(e, s, e->dqkv, 3 * in, lo.sa.q, rows, l.x_sa, l.ssq_sa, l.n_sa, lo.sa.ln, nb_dnext, H);
   P5_TRY(dgrad_w<T>(e, s, e->dqkv, 3 * in, lo.sa.q, e->dn, d, rows, 3 * in, d));
   return 0;
 }
@@ -1088,9 +1163,10 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const LayerOff& lo = e->dec[i];
     LayerSave& l = e->ds[i];
     begin_sublayer(e);
-    P5_TRY(ffn_bwd<T>(e, s, lo, l, Md, 1, i));
+    P5_TRY(ffn_bwd<T>(e, s, lo, l, Md, 1, i, mk_drop(e, 1, i, 4)));
     const bool nf = norm_fused<T>(e);
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
+    if (!e->nb_done) P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, Md, no_drop(), mk_drop(e, 1, i, 4), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
+    e->nb_done = false;
     // cross attention
     begin_sublayer(e);
     P5_TRY(linear_wgrad<T>(e, s, e->dy, d, l.o_ca, in, e->G + lo.ca.o, Md, d, in));
@@ -1109,10 +1185,11 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     P5_TRY(swap_norm_bwd<T>(e, s, l.x_ca, lo.ca.ln, l.rstd_ca, Md, no_drop(), mk_drop(e, 1, i, 2), true, nf ? l.ssq_ca : nullptr, nf ? l.n_ca : nullptr));
     // self attention
     begin_sublayer(e);
-    P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i));
     if (i == 0 && g_opt_embed_det) e->dres_out_override = e->dres_dec0;      // gradient of the decoder's embedding rows: consumed by the last stage
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
+    P5_TRY(self_attn_bwd<T>(e, s, lo, l, Md, e->T, true, i, i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop()));
+    if (!e->nb_done) P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, Md, no_drop(), i > 0 ? mk_drop(e, 1, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
                             nf ? l.n_sa : nullptr));
+    e->nb_done = false;
     return wgrad_flush(e, s, false, (g_opt_wgrad_side & 1) != 0);     // the six weight gradients of the layer: one launch
   }
   if (stage == nd + 1) {
@@ -1158,13 +1235,15 @@ static int backward_stage_impl(P5Engine* e, const float* dnll, int stage, hipStr
     const LayerOff& lo = e->enc[i];
     LayerSave& l = e->es[i];
     begin_sublayer(e);
-    P5_TRY(ffn_bwd<T>(e, s, lo, l, M, 0, i));
+    P5_TRY(ffn_bwd<T>(e, s, lo, l, M, 0, i, mk_drop(e, 0, i, 2)));
     const bool nf = norm_fused<T>(e);
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
+    if (!e->nb_done) P5_TRY(swap_norm_bwd<T>(e, s, l.x_ff, lo.ff_ln, l.rstd_ff, M, no_drop(), mk_drop(e, 0, i, 2), true, nf ? l.ssq_ff : nullptr, nf ? l.n_ff : nullptr));
+    e->nb_done = false;
     begin_sublayer(e);
-    P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i));
-    P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
+    P5_TRY(self_attn_bwd<T>(e, s, lo, l, M, e->L, false, i, i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop()));
+    if (!e->nb_done) P5_TRY(swap_norm_bwd<T>(e, s, l.x_sa, lo.sa.ln, l.rstd_sa, M, no_drop(), i > 0 ? mk_drop(e, 0, i - 1, 6) : no_drop(), true, nf ? l.ssq_sa : nullptr,
                             nf ? l.n_sa : nullptr));
+    e->nb_done = false;
     // the four weight gradients of the layer: one launch of 192 tiles over all 8192 tokens (or of 2 layers = 384 tiles when the
     // whole backward runs in one call and nobody waits for per-layer gradient ranges)
     // (the top layer's group also carries the cross-attention K/V block queued in the previous stage: 5 problems; then pairs of layers)
@@ -2137,7 +2216,11 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_ring_n512")) g_opt_gemm_ring_n512 = value;
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
+  else if (!strcmp(name, "gemm_ws128")) g_opt_gemm_ws128 = value;
+  else if (!strcmp(name, "gemm_ws128_min_k")) g_opt_gemm_ws128_min_k = value;
   else if (!strcmp(name, "gate_fuse")) g_opt_gate_fuse = value;
+  else if (!strcmp(name, "norm_bwd_blocks")) g_opt_norm_bwd_blocks = value;
+  else if (!strcmp(name, "norm_bwd_fuse")) g_opt_norm_bwd_fuse = value;
   else if (!strcmp(name, "adam_tiles")) g_opt_adam_tiles = value;
   else if (!strcmp(name, "ce_free")) g_opt_ce_free = value;
   else if (!strcmp(name, "gemm_wide_min_tiles")) g_opt_gemm_wide_min_tiles = value;
@@ -2151,7 +2234,7 @@ int p5_set_option(const char* name, int value) {
   else return fail("p5_set_option: unknown option");
   return 0;
 }
-int p5_abi_version(void) { return 4; }    // 2: p5_op_attn_bwd gained d_rel_scratch / rel_buckets (round 4); 3: p5_generate_verified, p5_backward_staged (round 5); 4: p5_allreduce_range / _sum, p5_verify_row_capacity, range flag in p5_verify_run (round 6)
+int p5_abi_version(void) { return 5; }    // 2: p5_op_attn_bwd gained d_rel_scratch / rel_buckets (round 4); 3: p5_generate_verified, p5_backward_staged (round 5); 4: p5_allreduce_range / _sum, p5_verify_row_capacity, range flag in p5_verify_run (round 6); 5: P5GemmProblem gained the T5LayerNorm-backward epilogue fields, p5_op_attn_bwd gained dot_out (round 6)
 // ---- in-run kernel profiler (p5_device.h P5Prof) ----
 int p5_profile_begin(void) {
 #ifndef P5_EMU
@@ -2811,6 +2894,14 @@ int p5_op_gemm_group(int tile_cfg, int ks, int nprob, const P5GemmProblem* probs
     g.rowss = q.rowss; g.rowss_invd = q.rowss ? 1.0f / (float)q.K : 0.f; g.rowss_eps = q.rowss_eps; g.ssq_out = q.ssq_out;
     g.rowss_nt = q.rowss_nt; g.ssq_nt = q.ssq_nt;
     g.C2 = q.C2; g.ldc2 = q.ldc2; g.gate_F = q.gate_F;
+    g.nb_dot = q.nb_dot; g.nb_dot_nt = q.nb_dot_nt; g.nb_rin = q.nb_rin; g.nb_rout = q.nb_rout; g.nb_w = q.nb_w; g.nb_dw = q.nb_dw;
+    if (q.epi == P5_EPI_NORM_BWD) {
+      P5_REQUIRE(tile_cfg == P5_G5_128x128 && !ks, "gemm_group: the T5LayerNorm-backward epilogue runs on tile_cfg 4, ks 0");
+      g.rowss_invd = 1.0f / (float)q.N;      // (the statistics are those of the d_model-wide rows of x = aux, not of the reduction dimension)
+    }
+    if (q.epi == P5_EPI_MASK_POS && q.ssq_out)
+      P5_REQUIRE((tile_cfg == P5_G4_256x128 || tile_cfg == P5_G5_256x128 || tile_cfg == P5_G5_128x128) && !ks && (g_opt_gemm_ws & 1) && q.ssq_nt > 0 && !q.c_f32,
+                 "gemm_group: row sums of <d pre, pre> (epi 3 + ssq_out) exist in the wave-specialised kernel only (tile_cfg 1, 3 or 4)");
     if (q.epi == P5_EPI_GELU_GATE || q.epi == P5_EPI_GELU_GATE_BWD)
       P5_REQUIRE(tile_cfg == P5_G4_256x128 && !ks && (g_opt_gemm_ws & 1) && (q.M % 256) == 0 && (q.N % 128) == 0 && !q.c_f32 &&
                  (q.epi == P5_EPI_GELU_GATE ? (q.C2 && q.gate_F * 2 == q.N) : (q.aux && q.gate_F == 0)),
@@ -2870,14 +2961,23 @@ int p5_op_attn_bwd(int dtype, const void* Q, const void* K, const void* V, const
                    void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch, int rel_buckets, const int* lut,
                    int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
                    int causal, const uint32_t* rng_state, uint32_t site, float drop_p, void* stream) {
+  return p5_op_attn_bwd_dot(dtype, Q, K, V, O, dO, lse, Dvec, dQ, dK, dV, rel_table, d_rel_table, d_rel_scratch, rel_buckets, lut, lut_half, kmask, B, H, Lq, Lk,
+                            ldq, ldk, ldv, ldo, lddq, lddk, lddv, causal, rng_state, site, drop_p, nullptr, stream);
+}
+int p5_op_attn_bwd_dot(int dtype, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse, float* Dvec,
+                       void* dQ, void* dK, void* dV, const float* rel_table, float* d_rel_table, float* d_rel_scratch, int rel_buckets, const int* lut,
+                       int lut_half, const int64_t* kmask, int B, int H, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                       int causal, const uint32_t* rng_state, uint32_t site, float drop_p, float* dot_out, void* stream) {
   P5AttnArgs a;
   memset(&a, 0, sizeof(a));
+  a.dot_out = dot_out;
   a.Q = Q; a.K = K; a.V = V; a.O = (void*)O; a.dO = dO; a.lse = (float*)lse; a.Dvec = Dvec; a.dQ = dQ; a.dK = dK; a.dV = dV;
   a.rel_table = rel_table; a.d_rel_table = nullptr; a.bucket_lut = lut; a.lut_half = lut_half; a.kmask = kmask;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = ldo; a.lddq = lddq; a.lddk = lddk;
   a.lddv = lddv; a.causal = causal; a.rel_copies = rel_buckets; a.rel_stride = rel_buckets * H; a.drop = op_drop(rng_state, site, drop_p);
   a.keep_bits = op_keep_bits(dtype, B, H, Lq, Lk, a.drop);
   hipStream_t s = (hipStream_t)stream;
+  if (dot_out) P5_REQUIRE(p5l_attn_bwd_dot_ok(dtype == 1, a), "attn_bwd: dot_out is written by the fused bf16 self-attention backward only (Lq == Lk in 17..128)");
   if (d_rel_table) {
     P5_REQUIRE(d_rel_scratch && rel_buckets >= 1 && rel_buckets <= 64, "attn_bwd: d_rel_table needs d_rel_scratch [B * ceil(Lq / 64)][rel_buckets * H] and rel_buckets <= 64");
     a.d_rel_table = d_rel_scratch;

@@ -181,7 +181,7 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0,
             keep += [partd, ssq_d]
             q.rowss, q.rowss_eps, q.rowss_nt = partd.data_ptr(), eps, stats_nt
             q.ssq_out, q.ssq_nt = ssq_d.data_ptr(), nt_out
-        checks.append((Cd, ref, c_f32, K, (M, N, K, epi), ssq_d))
+        checks.append((Cd, ref, c_f32, K, (M, N, K, epi), ssq_d, aux, alpha))
     lib = be.lib
     try:
         be.check(lib.p5_set_option(b"g4_nst", nst), "opt")
@@ -192,7 +192,7 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0,
         lib.p5_set_option(b"g4_nst", 3)
         lib.p5_set_option(b"g4_wgs", 256)
     worst = 0.0
-    for Cd, ref, c_f32, K, tag, ssq_d in checks:
+    for Cd, ref, c_f32, K, tag, ssq_d, aux, alpha in checks:
         got = Cd.cpu().float()
         tol = 1e-3 * max(1.0, K ** 0.5) if c_f32 else 2e-2 * max(1.0, float(ref.abs().max()))
         err = (got - ref).abs().max().item()
@@ -201,9 +201,157 @@ def gemm_group_case(be, tile_cfg, ks, probs, nst=5, wgs=256, seed=0, drop_p=0.0,
         if ssq_d is not None:            # the output rows' partial sums of squares: of the bf16 values actually stored, per 64 columns
             N = got.shape[1]
             want = torch.stack([(got[:, c:c + 64] ** 2).sum(1) for c in range(0, N, 64)], 1)
+            if tag[3] == 3:              # MASK_POS: the row sums of <d pre, pre> instead (C * aux / alpha, cases.gemm_rowdot_case)
+                want = torch.stack([(got[:, c:c + 64] * aux.float()[:, c:c + 64]).sum(1) for c in range(0, N, 64)], 1) / alpha
             e2 = ((ssq_d.cpu() - want).abs() / want.abs().clamp(min=1.0)).max().item()
             assert e2 <= 1e-4, f"gemm_group {tag}: output row statistics off by {e2}"
     return worst
+
+
+def _gemm_problem(arr, i, **kw):
+    """one P5GemmProblem with everything optional nulled"""
+    q = arr[i]
+    for f in ("aux", "rowss", "ssq_out", "C2", "nb_dot", "nb_rin", "nb_rout", "nb_w", "nb_dw"):
+        setattr(q, f, None)
+    q.rowss_eps, q.rowss_nt, q.ssq_nt, q.ldc2, q.gate_F, q.nb_dot_nt, q.ldaux, q.c_f32, q.splitk, q.alpha = 0.0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0
+    for k, v in kw.items():
+        setattr(q, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return q
+
+
+def gemm_rowdot_case(be, M, N, K, alpha=1.0, seed=0, wgs=256):
+    """P5_EPI_MASK_POS with ssq_out (p5_gemm5.h, 256x128 tiles): besides C = aux > 0 ? acc * alpha : 0 the epilogue leaves, per row and
+    64-column group, sum(C * aux) / alpha with C as stored -- the row sums of <d pre, pre> that the T5LayerNorm-backward epilogue of the
+    NEXT data-gradient GEMM consumes (HF modeling_t5.py:59-72, 83-94 under autograd)."""
+    from openp5_amd._abi import P5GemmProblem
+    g = torch.Generator().manual_seed(seed)
+    tt = torch.bfloat16
+    A = torch.randn(M, K, generator=g).to(tt)
+    Bm = torch.randn(N, K, generator=g).to(tt)
+    aux = (torch.randn(M, N, generator=g).clamp(min=0) * alpha).to(tt)       # a saved hidden: relu(pre) * alpha
+    Ad, Bd, auxd = dev(be, A), dev(be, Bm), dev(be, aux)
+    Cd = dev(be, torch.zeros(M, N, dtype=tt))
+    nt = (N + 63) // 64
+    dotd = dev(be, torch.full((M, nt), float("nan")))
+    arr = (P5GemmProblem * 1)()
+    _gemm_problem(arr, 0, A=Ad, B=Bd, C=Cd, aux=auxd, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldaux=N, epi=3, alpha=alpha, ssq_out=dotd, ssq_nt=nt)
+    try:
+        be.check(be.lib.p5_set_option(b"g4_wgs", wgs), "opt")
+        be.check(be.lib.p5_op_gemm_group(3, 0, 1, arr, None, 0, 0.0, be.stream_ptr()), "gemm_group")
+        sync(be)
+    finally:
+        be.lib.p5_set_option(b"g4_wgs", 256)
+    ref = torch.where(aux.float() > 0, (A.float() @ Bm.float().t()) * alpha, torch.zeros(M, N))
+    got = Cd.cpu().float()
+    assert (got - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max()))
+    want = torch.stack([(got[:, c:c + 64] * aux.float()[:, c:c + 64]).sum(1) for c in range(0, N, 64)], 1) / alpha
+    err = ((dotd.cpu() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+    assert err <= 1e-4, f"row sums of <d pre, pre> off by {err}"
+    return err
+
+
+def gemm_norm_bwd_case(be, M, N, K, dot_nt, drop_p=0.0, seed=0, wgs=256, with_n=True):
+    """P5_EPI_NORM_BWD (p5_gemm5.h, 128x128 tiles): the T5LayerNorm backward (HF modeling_t5.py:59-72 under autograd) in the epilogue of the
+    data-gradient GEMM that produces the norm's input gradient.  Against the formulas of the stand-alone kernel in plain torch fp32:
+    residual gradient out, the next dy with dropout, n = w * round(x rstd), partial rows of the norm-weight gradient."""
+    from openp5_amd._abi import P5GemmProblem
+    g = torch.Generator().manual_seed(seed)
+    tt = torch.bfloat16
+    eps = 1e-6
+    A = torch.randn(M, K, generator=g).to(tt)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(tt)
+    x = (torch.randn(M, N, generator=g) * 2.0).to(tt)
+    w = torch.rand(N, generator=g) + 0.5
+    rin = torch.randn(M, N, generator=g)
+    ssq = torch.stack([(x.float()[:, c:c + 64] ** 2).sum(1) for c in range(0, N, 64)], 1).contiguous()
+    dotp = torch.randn(M, dot_nt, generator=g)
+    Ad, Bd, xd, wd, rind, ssqd, dotd = (dev(be, t) for t in (A, Bm, x, w, rin, ssq, dotp))
+    Cd = dev(be, torch.zeros(M, N, dtype=tt))
+    C2d = dev(be, torch.zeros(M, N, dtype=tt)) if with_n else None
+    routd = dev(be, torch.full((M, N), float("nan")))
+    dwd = dev(be, torch.full((M // 64, N), float("nan")))
+    rng = dev(be, torch.tensor([77, 3], dtype=torch.int32)) if drop_p > 0 else None
+    arr = (P5GemmProblem * 1)()
+    _gemm_problem(arr, 0, A=Ad, B=Bd, C=Cd, aux=xd, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ldaux=N, epi=10, rowss=ssqd, rowss_eps=eps, rowss_nt=N // 64,
+                  C2=C2d, ldc2=N, nb_dot=dotd, nb_dot_nt=dot_nt, nb_rin=rind, nb_rout=routd, nb_w=wd, nb_dw=dwd)
+    try:
+        be.check(be.lib.p5_set_option(b"g4_wgs", wgs), "opt")
+        be.check(be.lib.p5_op_gemm_group(4, 0, 1, arr, P(rng), 5, drop_p, be.stream_ptr()), "gemm_group")
+        sync(be)
+    finally:
+        be.lib.p5_set_option(b"g4_wgs", 256)
+    dn = A.float() @ Bm.float().t()
+    ssum = torch.zeros(M)
+    for t in range(N // 64):
+        ssum = ssum + ssq[:, t]
+    rstd = torch.rsqrt(ssum / N + eps)
+    dsum = torch.zeros(M)
+    for t in range(dot_nt):
+        dsum = dsum + dotp[:, t]
+    m = dsum / N
+    xh = x.float() * rstd[:, None]
+    v = rstd[:, None] * (dn * w[None, :] - xh * m[:, None]) + rin
+    scale = float(v.abs().max())
+    e_r = (routd.cpu() - v).abs().max().item() / scale
+    assert e_r <= 2e-3, f"norm-backward epilogue: residual gradient off by {e_r}"
+    out = routd.cpu()
+    if drop_p > 0:
+        keepm = O.dropout_keep_mask((77 + 3 * 0x632BE5AB) & 0xFFFFFFFF, 5, M * N, drop_p).view(M, N)
+        dscale = torch.ones(()) / (torch.ones(()) - torch.tensor(drop_p, dtype=torch.float32))      # (the kernels multiply by the fp32 reciprocal)
+        out = torch.where(keepm, out * dscale, torch.zeros_like(out))
+    assert torch.equal(Cd.cpu(), out.to(tt)), "norm-backward epilogue: dy_next is not dropout(residual gradient) rounded once"
+    if with_n:
+        n_ref = (w[None, :] * xh.to(tt).float()).to(tt)
+        e_n = (C2d.cpu().float() - n_ref.float()).abs().max().item() / float(n_ref.float().abs().max())
+        assert e_n <= 1e-2, f"norm-backward epilogue: n off by {e_n}"
+    dw_ref = (dn * xh).view(M // 64, 64, N).sum(1)
+    e_w = (dwd.cpu() - dw_ref).abs().max().item() / float(dw_ref.abs().max())
+    assert e_w <= 2e-3, f"norm-backward epilogue: norm-weight gradient partials off by {e_w}"
+    return e_r, e_w
+
+
+def attn_rowdot_case(be, B, H, L, mode="enc", drop_p=0.1, seed=3):
+    """P5AttnArgs::dot_out of the fused attention backward (bf16, self-attention, 16 < L <= 128): <dQ, Q> + <dK, K> + <dV, V> per token and
+    head from the gradients as stored; the gradients themselves are bit-identical to the call without it."""
+    g = torch.Generator().manual_seed(seed)
+    tt = torch.bfloat16
+    inner = H * 64
+    qkv = (torch.randn(B * L, 3 * inner, generator=g) * 0.5).to(tt)
+    qkvd = dev(be, qkv)
+    Qd, Kd, Vd = qkvd, qkvd[:, inner:], qkvd[:, 2 * inner:]
+    table_d = dev(be, torch.randn(32, H, generator=g) * 0.5)
+    lut_half = 512
+    lut_d = dev(be, relative_position_bucket_lut(lut_half, mode == "enc", 32, 128))
+    kmask = torch.ones(B, L, dtype=torch.long)
+    if mode == "enc":
+        for b in range(B):
+            kmask[b, int(torch.randint(max(1, L // 2), L + 1, (1,), generator=g)):] = 0
+    km_d = dev(be, kmask) if mode == "enc" else None
+    causal = 1 if mode == "dec" else 0
+    dOd = dev(be, torch.randn(B * L, inner, generator=g).to(tt))
+    rng = dev(be, torch.tensor([1234, 7], dtype=torch.int32))
+    Od = dev(be, torch.zeros(B * L, inner, dtype=tt))
+    lse = dev(be, torch.zeros(B * H * L))
+    be.check(be.lib.p5_op_attn_fwd(1, P(Qd), P(Kd), P(Vd), P(Od), P(lse), P(table_d), P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner,
+                                   3 * inner, 3 * inner, inner, causal, P(rng), 11, drop_p, be.stream_ptr()), "attn_fwd")
+    res = []
+    for want_dot in (True, False):
+        dqkv = dev(be, torch.zeros(B * L, 3 * inner, dtype=tt))
+        dtab = dev(be, torch.zeros(32, H))
+        dscr = dev(be, torch.zeros(B * ((L + 63) // 64), 32 * H))
+        Dv = dev(be, torch.zeros(B * H * L))
+        dot = dev(be, torch.full((B * L, H), float("nan"))) if want_dot else None
+        be.check(be.lib.p5_op_attn_bwd_dot(1, P(Qd), P(Kd), P(Vd), P(Od), P(dOd), P(lse), P(Dv), P(dqkv), P(dqkv[:, inner:]), P(dqkv[:, 2 * inner:]),
+                                           P(table_d), P(dtab), P(dscr), 32, P(lut_d), lut_half, P(km_d), B, H, L, L, 3 * inner, 3 * inner, 3 * inner, inner,
+                                           3 * inner, 3 * inner, 3 * inner, causal, P(rng), 11, drop_p, P(dot), be.stream_ptr()), "attn_bwd_dot")
+        sync(be)
+        res.append((dqkv.cpu(), dtab.cpu().clone(), dot.cpu() if want_dot else None))
+    (ga, ta, dot), (gb, tb, _) = res
+    assert torch.equal(ga, gb) and torch.equal(ta, tb), "attention backward changed by dot_out"
+    prod = (ga.float() * qkv.float()).view(B * L, 3, H, 64).sum(3).sum(1)
+    err = ((dot - prod).abs() / prod.abs().clamp(min=1.0)).max().item()
+    assert err <= 1e-4 and bool(torch.isfinite(dot).all()), f"row sums of <d qkv, qkv> off by {err}"
+    return err
 
 
 def _gelu_new(a):

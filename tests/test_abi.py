@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib_path):
     for name in declared:
         assert hasattr(lib, name), name
     _abi.bind(lib)
-    assert lib.p5_is_emulator() == 0 and lib.p5_abi_version() == 4
+    assert lib.p5_is_emulator() == 0 and lib.p5_abi_version() == 5
 
 
 def test_engine_layout_without_gpu(lib_path):

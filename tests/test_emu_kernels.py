@@ -91,6 +91,37 @@ def test_gemm_wave_specialised(emu, wgs):
         cases.gemm_group_case(emu, 3, 0, whole_tiles[:4] + [(300, 200, 64, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=2, stats_nt=nt)
 
 
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_wave_specialised_128_row_tiles(emu, wgs):
+    """p5_gemm5.h on 128 x 128 tiles (2 x 2 compute waves of 64 x 64, four-slot ring; the N = d_model outputs of the encoder): the same
+    cases as the 256-row instance -- grouped problems, ragged M / N, one to ten K-steps, every K-contiguous epilogue incl. dropout, whole
+    tiles through the descriptor-hoisted epilogue with the folded T5LayerNorm's row scales (one row block per lane group) and output sums."""
+    probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1), (40, 72, 192, 3, 0, 1), (72, 100, 128, 0, 1, 1), (136, 64, 256, 1, 1, 1)]
+    cases.gemm_group_case(emu, 4, 0, probs, wgs=wgs, drop_p=0.1)
+    whole_tiles = [(384, 256, 128, 1, 0, 1), (128, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (384, 128, 640, 0, 0, 1), (300, 256, 64, 2, 0, 1),
+                   (384, 300, 128, 0, 1, 1)]
+    cases.gemm_group_case(emu, 4, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=1)
+    for nt in (8, 12, 3):
+        cases.gemm_group_case(emu, 4, 0, whole_tiles[:4] + [(300, 200, 64, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=2, stats_nt=nt)
+
+
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_norm_backward_epilogue(emu, wgs):
+    """north_star "fused RMSNorm": the T5LayerNorm backward inside the data-gradient GEMM (P5_EPI_NORM_BWD), its producer-side row sums
+    (MASK_POS + ssq_out), one to six 128-row tiles per workgroup, with and without dropout / the n output."""
+    cases.gemm_norm_bwd_case(emu, 256, 128, 192, 8, wgs=wgs)
+    cases.gemm_norm_bwd_case(emu, 384, 256, 64, 5, drop_p=0.1, seed=1, wgs=wgs)
+    cases.gemm_norm_bwd_case(emu, 128, 384, 128, 32, drop_p=0.1, seed=2, wgs=wgs, with_n=False)
+    cases.gemm_rowdot_case(emu, 256, 256, 64, alpha=1.0 / 0.9, wgs=wgs)
+    cases.gemm_rowdot_case(emu, 512, 128, 192, alpha=1.0, seed=1, wgs=wgs)
+
+
+@pytest.mark.parametrize("L,mode", [(128, "enc"), (40, "enc"), (100, "dec")])
+def test_attention_backward_row_sums(emu, L, mode):
+    """row sums of <d qkv, qkv> out of the fused attention backward (P5AttnArgs::dot_out)"""
+    cases.attn_rowdot_case(emu, 2, 2, L, mode=mode)
+
+
 def test_gemm_wave_specialised_wgrad(emu):
     """p5_gemm5.h on two K-strided operands (grouped weight gradients): C +=, split-K atomics, plain store; ragged outputs."""
     probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1), (8, 8, 64, 4, 1, 1)]
@@ -432,6 +463,31 @@ def test_model_bf16_norm_folded_into_gemms(emu, dropout):
     finally:
         emu.lib.p5_set_option(b"norm_fuse", 1)
     assert abs(res[1]["whole_rel"] - res[0]["whole_rel"]) <= 0.02, res
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_model_bf16_norm_backward_in_gemm_epilogues(emu, dropout):
+    """Whole training step with the T5LayerNorm backward of the encoder's sub-layer inputs inside the data-gradient GEMMs (round 6): 256
+    encoder rows of d_model 128 put the FFN's wo data gradient on the wide kernel (row sums of <dh, pre>), the self-attention backward on the
+    fused kernel (row sums of <d qkv, qkv>) and both wi / qkv data gradients on the P5_EPI_NORM_BWD epilogue.  Against the fp32 oracle, and
+    against the engine's own stand-alone norm backward (same bounds; different roundings, so not bit-equal -- which also shows that the
+    option switches paths)."""
+    cfg = O.T5Cfg.named("tiny")
+    res = {}
+    try:
+        emu.check(emu.lib.p5_set_option(b"gemm_wide_min_tiles", 1), "opt")
+        for fuse in (1, 0):
+            emu.check(emu.lib.p5_set_option(b"norm_bwd_fuse", fuse), "opt")
+            r = cases.bf16_gradient_case(emu, cfg, 2, 128, 32, dropout=dropout)
+            res[fuse] = r
+            assert r["nll_max"] <= 0.08 and r["loss_err"] <= 0.03, (fuse, r)
+            assert r["worst_rel"][0] <= 0.15 and r["worst_cos"][0] >= 0.99, (fuse, r)
+            assert r["whole_rel"] <= 0.06 and r["whole_cos"] >= 0.998, (fuse, r)
+    finally:
+        emu.lib.p5_set_option(b"norm_bwd_fuse", 1)
+        emu.lib.p5_set_option(b"gemm_wide_min_tiles", 160)
+    print("[norm backward in the GEMM epilogues]", res)
+    assert res[1]["whole_rel"] != res[0]["whole_rel"] and abs(res[1]["whole_rel"] - res[0]["whole_rel"]) <= 0.01, res
 
 
 def test_gradients_stored_not_accumulated_on_a_first_micro_batch(emu):

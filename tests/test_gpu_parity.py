@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_native_library_loaded(hip):
     assert hip.lib.p5_is_emulator() == 0
-    assert hip.lib.p5_abi_version() == 4
+    assert hip.lib.p5_abi_version() == 5
 
 
 def test_tr_probe(hip):
@@ -431,6 +431,46 @@ def test_bf16_gradients_at_benchmark_shape(hip):
     assert r["whole_rel"] <= 0.03 and r["whole_cos"] >= 0.9995, r
 
 
+def test_bf16_gradients_norm_backward_in_gemm_epilogues(hip):
+    """The benchmark step with the T5LayerNorm backward of the encoder's sub-layer inputs inside the qkv / wi data-gradient GEMMs (round 6,
+    the default) and with the stand-alone norm-backward kernel: both against the fp32 oracle under the bounds above, and within 2e-3 of
+    each other in whole-gradient relative error (they round at different places, so they are not bit-equal)."""
+    res = {}
+    try:
+        for fuse in (1, 0):
+            hip.check(hip.lib.p5_set_option(b"norm_bwd_fuse", fuse), "opt")
+            r = cases.bf16_c2_gradient_case(hip)
+            res[fuse] = r
+            assert r["nll_max"] <= 0.08 and r["nll_mean"] <= 0.02 and r["loss_err"] <= 0.02, (fuse, r)
+            assert r["worst_rel"][0] <= 0.12 and r["worst_cos"][0] >= 0.995, (fuse, r)
+            assert r["whole_rel"] <= 0.03 and r["whole_cos"] >= 0.9995, (fuse, r)
+    finally:
+        hip.lib.p5_set_option(b"norm_bwd_fuse", 1)
+    print("[bf16 C2, norm backward fused / stand-alone]", res[1]["whole_rel"], res[0]["whole_rel"], res[1]["worst_rel"], res[0]["worst_rel"])
+    assert res[1]["whole_rel"] != res[0]["whole_rel"] and abs(res[1]["whole_rel"] - res[0]["whole_rel"]) <= 2e-3, res
+
+
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_norm_backward_epilogue(hip, wgs):
+    """P5_EPI_NORM_BWD and its producer-side row sums on the hardware: small whole-tile problems, then the benchmark step's shapes (wi data
+    gradient K = 2048 with 32 partial sums per row, qkv data gradient K = 1536 with 8; the wide wo data gradient 8192 x 2048 x 512)."""
+    for rep in range(2):
+        cases.gemm_norm_bwd_case(hip, 256, 128, 192, 8, wgs=wgs, seed=rep)
+        cases.gemm_norm_bwd_case(hip, 384, 256, 64, 5, drop_p=0.1, seed=1 + rep, wgs=wgs)
+        cases.gemm_norm_bwd_case(hip, 128, 384, 128, 32, drop_p=0.1, seed=2 + rep, wgs=wgs, with_n=False)
+        cases.gemm_rowdot_case(hip, 256, 256, 64, alpha=1.0 / 0.9, wgs=wgs, seed=rep)
+    cases.gemm_norm_bwd_case(hip, 8192, 512, 2048, 32, drop_p=0.1, seed=5, wgs=wgs)
+    cases.gemm_norm_bwd_case(hip, 8192, 512, 1536, 8, drop_p=0.1, seed=6, wgs=wgs)
+    cases.gemm_rowdot_case(hip, 8192, 2048, 512, alpha=1.0 / 0.9, wgs=wgs, seed=7)
+
+
+@pytest.mark.parametrize("B,H,L,mode", [(2, 2, 128, "enc"), (3, 8, 40, "enc"), (2, 4, 100, "dec"), (64, 8, 128, "enc")])
+def test_attention_backward_row_sums(hip, B, H, L, mode):
+    """row sums of <d qkv, qkv> out of the fused attention backward (P5AttnArgs::dot_out), gradients unchanged by it"""
+    for rep in range(2):
+        cases.attn_rowdot_case(hip, B, H, L, mode=mode, seed=3 + rep)
+
+
 def test_generate_base_beam20_collaborative_vocab(hip):
     """BASELINE.json configs[3]: T5-base dims, beam 20, vocabulary grown by 500 <CIk> tokens (collaborative indexing,
     main.py:190-193) -> V = 32600; ids drawn from the added-token range."""
@@ -533,6 +573,23 @@ def test_gemm_wave_specialised(hip, wgs):
     for rep in range(2):
         cases.gemm_group_case(hip, 3, 0, [(8192, 2048, 512, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
         cases.gemm_group_case(hip, 3, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 1536, 512, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
+
+
+@pytest.mark.parametrize("wgs", [8, 256])
+def test_gemm_wave_specialised_128_row_tiles(hip, wgs):
+    """p5_gemm5.h on 128 x 128 tiles (the N = d_model outputs of the encoder: loader waves + 2 x 2 compute waves of 64 x 64, four-slot ring):
+    grouped ragged problems with every K-contiguous epilogue, whole tiles with the folded T5LayerNorm's row scales and output sums, then the
+    benchmark step's N = 512 shapes (output projection K = 512, FFN output K = 2048 with residual + dropout + row sums, qkv data gradient)."""
+    probs = [(300, 200, 128, 0, 0, 1), (256, 256, 320, 2, 0, 1), (520, 136, 64, 1, 0, 1), (40, 72, 192, 3, 0, 1), (72, 100, 128, 0, 1, 1), (136, 64, 256, 1, 1, 1)]
+    whole_tiles = [(384, 256, 128, 1, 0, 1), (128, 128, 192, 2, 0, 1), (256, 256, 64, 3, 0, 1), (384, 128, 640, 0, 0, 1), (300, 256, 64, 2, 0, 1),
+                   (384, 300, 128, 0, 1, 1)]
+    for rep in range(3):
+        cases.gemm_group_case(hip, 4, 0, probs, wgs=wgs, drop_p=0.1, seed=rep)
+        cases.gemm_group_case(hip, 4, 0, whole_tiles, wgs=wgs, drop_p=0.1, seed=rep)
+        cases.gemm_group_case(hip, 4, 0, whole_tiles[:4] + [(300, 200, 64, 1, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep, stats_nt=8)
+    for rep in range(2):
+        cases.gemm_group_case(hip, 4, 0, [(8192, 512, 512, 2, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep, stats_nt=8)
+        cases.gemm_group_case(hip, 4, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 512, 1536, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
 
 
 def test_backward_writes_every_gradient_after_zero_grad(hip):
