@@ -161,6 +161,38 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       buf = buf == NST - 1 ? 0 : buf + 1;
     }
     P5_WAIT_VM(0);
+    if constexpr (VAR == 3 && !KS) {
+      // P5_EPI_NORM_BWD: n = w * round(x rstd) needs nothing from the accumulators -- the loader waves, idle from here on, write it (x read +
+      // n written = 64 of the 224 KiB a tile's epilogue moves) while the compute waves run the rest.  A 128 x 128 tile is 2048 16-byte
+      // pieces: eight per loader lane, all loads of a tile before its first store.
+      static_assert(BM == 128 || VAR != 3, "n tiles of 128 rows");
+      for (int it = 0; it < nmy; ++it) {
+        const Unit u = decode(it);
+        const P5GemmArgs& g = grp.p[u.pi];
+        if (g.C2 == nullptr) continue;
+        const int N = g.N, col = u.n0 + (lane & 15) * 8;
+        const T* const xb = (const T*)g.aux;
+        T* const nb = (T*)g.C2;
+        const f32x4 w0 = *(const f32x4*)(g.nb_w + col), w1 = *(const f32x4*)(g.nb_w + col + 4);
+        u32x4 xv[8];
+        float rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = u.m0 + j * 16 + lw * 4 + (lane >> 4);
+          xv[j] = ld16(xb + ((uint32_t)row * (uint32_t)N + (uint32_t)col));
+          rs[j] = gemm_row_rstd(g, row);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = u.m0 + j * 16 + lw * 4 + (lane >> 4);
+          float x[8], nr[8];
+          unpack16<T>(xv[j], x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) nr[e] = (e < 4 ? w0[e & 3] : w1[e & 3]) * to_f<T>(from_f<T>(x[e] * rs[j]));
+          st16(nb + ((uint32_t)row * (uint32_t)N + (uint32_t)col), pack16<T>(nr));
+        }
+      }
+    }
     return;
   }
 
@@ -448,6 +480,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
       {   // (a launch of this instance carries P5_EPI_NORM_BWD problems only: the launcher checks)
         // ---- T5LayerNorm backward of the sub-layer's input (P5_EPI_NORM_BWD, p5_gemm.h): whole tiles only (the launcher checks).  The row
         // scalars (rstd, mean of <dn w, xh>) were formed before the K loop (nb_stats); a lane holds, per row block, 2 x 8 consecutive columns.
+        // (n = w * round(x rstd) is written by the loader waves, above)
         // every [M, N] operand has leading dimension N (the launcher checks): ONE 32-bit element offset per lane, uniform bases and row-block
         // strides -- five 64-bit lane pointers x four row blocks cost the registers this epilogue does not have
         const int N = g.N;
@@ -459,7 +492,6 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
         const float* const rib = g.nb_rin;
         float* const rob = g.nb_rout;
         T* const yb = (T*)g.C;
-        T* const nb = (T*)g.C2;
         const bool do_drop = g.drop.state != nullptr && g.drop.thr != 0;
         const uint32_t thr = g.drop.thr, hseed = p5_mix32(p5_seed(g.drop) + g.drop.site_key);
         const float dscale = g.drop.scale;
@@ -493,7 +525,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float rs = __shfl(nb_rstd[i % RPG], li + 16 * (i / RPG)), dm = __shfl(nb_dotm[i % RPG], li + 16 * (i / RPG));
-          u32x4 po[2], pn[2];
+          u32x4 po[2];
           f32x4 ro[2][2];
           // the keep decisions of the block's 16 elements first, as two bit masks: the hash chains need a dozen temporaries each, and
           // left to itself the compiler interleaves them with the arithmetic below (46 spilled registers)
@@ -514,7 +546,7 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
           const float ds = do_drop ? dscale : 1.f;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            float x[8], o[8], nr[8];
+            float x[8], o[8];
             unpack16<T>(xv[i % AD][h], x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -524,10 +556,8 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
               const float v = rs * (dy * wv[h][e] - xh * dm) + rv[i % RD][h][e >> 2][e & 3];
               ro[h][e >> 2][e & 3] = v;
               o[e] = ((km[h] >> e) & 1u) ? v * ds : 0.f;
-              nr[e] = wv[h][e] * to_f<T>(from_f<T>(xh));
             }
             po[h] = pack16<T>(o);
-            pn[h] = pack16<T>(nr);
           }
           if (i + AD < TM) x_load(i + AD);
           if (i + RD < TM) r_load(i + RD);
@@ -537,7 +567,6 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
             *(f32x4*)(rob + o) = ro[h][0];
             *(f32x4*)(rob + (o + 4u)) = ro[h][1];
             st16(yb + o, po[h]);
-            if (nb) st16(nb + o, pn[h]);
           }
         }
         // norm-weight gradient: this wave's 64 rows summed per column (16 lanes of a lane group hold the same columns), one partial row
