@@ -39,7 +39,7 @@ def main():
     lines.append(f"dispatches: {len(rows)}; sum of kernel time {total/1e6:.3f} ms; first-start to last-end {span/1e6:.3f} ms")
     if "--in-step" in sys.argv:
         path = sys.argv[sys.argv.index("--in-step") + 1]
-        adam = [i for i, r in enumerate(rows) if "p5_adamw_kernel" in r[0]]
+        adam = [i for i, r in enumerate(rows) if "p5_adamw" in r[0] and "segments" not in r[0]]      # (flat kernel or the tile-wise one: one per optimizer step)
         res = {}
         if adam:
             inside = rows[:adam[-1] + 1]
