@@ -49,6 +49,8 @@ struct P5AttnArgs {
 };
 
 
+template <bool B> struct AttnBool { static constexpr bool value = B; };
+template <int V> struct P5EpiTagA { static constexpr int value = V; };
 template <class T> struct AttnC {
   static constexpr int SZ = (int)sizeof(T);
   static constexpr int KCH = TT<T>::KCH;
@@ -1034,8 +1036,10 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
       rv[i] = row < a.Lk ? ld16(V + (size_t)row * a.ldv + pc * 8) : zero16();
     }
+    // (round 6, as in the dK / dV pass below: log2(e) folded into the bias table and the row's log-sum-exp, the key mask ADDED to the
+    //  exponent as 0 / -inf -- a probability is two adds, one fma and one v_exp_f32, no compare, no branch)
     for (int i = tid; i < LK + a.Lq - 1; i += NT)       // (every position the blocks read, key slots past Lk included)
-      sbias[i] = (a.rel_table && i < nrel) ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+      sbias[i] = (a.rel_table && i < nrel) ? P5_LOG2E * a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
     for (int j = tid; j < LK; j += NT) skneg[j] = (j < a.Lk && (!a.kmask || a.kmask[(size_t)b * a.Lk + j] != 0)) ? 0.f : P5_NEG_INF;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -1080,7 +1084,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
   int nblk = 0;
   for (int q0 = wave * 16; q0 < a.Lq; q0 += 128, ++nblk) {
     const u32x4 qf0 = qn[0], qf1 = qn[1], dof0 = don[0], dof1 = don[1];
-    const float lse_q = lse_n;
+    const float lse_q = lse_n * P5_LOG2E;
     const int qi = q0 + li;
     const bool qok = qi < a.Lq;
     const int qic = qok ? qi : a.Lq - 1;
@@ -1124,33 +1128,45 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
 #pragma unroll
           for (int t = 0; t < 4; ++t) kw[t] = ld16(kp + (lane >> 5) * 128 + ch * 16 + t * 4);
         }
+        // a block whose 16 queries all exist, without a causal mask (every block of the encoder at L % 16 == 0): the key mask is the only
+        // condition left, and it is part of the exponent
+        const bool plain = !causal && q0 + 16 <= a.Lq;
+        const uint32_t lanebit = 1u << (lane & 31);
+        auto tiles = [&](auto plain_c, auto mode_c) {
+          constexpr bool PLAIN = decltype(plain_c)::value;
+          constexpr int MODE = decltype(mode_c)::value;        // dropout of the probabilities: 0 none, 1 the forward's stored keep masks, 2 re-hashed
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
-          mma16<T>(sacc, ld16(cK + t * 2048 + koff0), qf0);
-          mma16<T>(sacc, ld16(cK + t * 2048 + koff1), qf1);
-          mma16<T>(dpacc, ld16(cV + t * 2048 + koff0), dof0);
-          mma16<T>(dpacc, ld16(cV + t * 2048 + koff1), dof1);
-          const int kb = ch * 64 + t * 16 + g * 4;
-          const f32x4 kn = *(const f32x4*)(skneg + kb);
-          const float* pb = sbias + (kb - qic + a.Lq - 1);
-          float mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (use_bits) {
+          for (int t = 0; t < 4; ++t) {
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+            mma16<T>(sacc, ld16(cK + t * 2048 + koff0), qf0);
+            mma16<T>(sacc, ld16(cK + t * 2048 + koff1), qf1);
+            mma16<T>(dpacc, ld16(cV + t * 2048 + koff0), dof0);
+            mma16<T>(dpacc, ld16(cV + t * 2048 + koff1), dof1);
+            const int kb = ch * 64 + t * 16 + g * 4;
+            const f32x4 kn = *(const f32x4*)(skneg + kb);
+            const float* pb = sbias + (kb - qic + a.Lq - 1);
+            float mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (MODE == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mk[r] = ((kw[t][r] >> (lane & 31)) & 1u) ? a.drop.scale : 0.f;
-          } else if (do_drop) {
+              for (int r = 0; r < 4; ++r) mk[r] = (kw[t][r] & lanebit) ? a.drop.scale : 0.f;
+            } else if constexpr (MODE == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+              for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, rowbase + (uint32_t)(kb + r), a.drop.thr) ? a.drop.scale : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kj = kb + r;
+              float ex = fmaf(sacc[r], P5_LOG2E, pb[r] + (kn[r] - lse_q));     // (key slots past Lk and masked keys carry -inf in skneg)
+              if constexpr (!PLAIN) ex = (qok & !(causal & (kj > qi))) ? ex : P5_NEG_INF;
+              const float p = p5_exp2(ex);
+              dsv[t][r] = p * (dpacc[r] * mk[r] - D_q);
+            }
+            if (do_rel) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kj = kb + r;
-            const bool ok = qok & !(causal & (kj > qi)) & (kn[r] == 0.f);     // (key slots past Lk carry -inf in skneg)
-            const float p = p5_exp<T>((sacc[r] + pb[r]) - lse_q);
-            dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
-          }
-          if (do_rel) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
-        }
+        };
+        if (use_bits) { if (plain) tiles(AttnBool<true>(), P5EpiTagA<1>()); else tiles(AttnBool<false>(), P5EpiTagA<1>()); }
+        else if (do_drop) { if (plain) tiles(AttnBool<true>(), P5EpiTagA<2>()); else tiles(AttnBool<false>(), P5EpiTagA<2>()); }
+        else { if (plain) tiles(AttnBool<true>(), P5EpiTagA<0>()); else tiles(AttnBool<false>(), P5EpiTagA<0>()); }
         if (do_rel) {
           // sums of dS (as the MFMA sees it: bf16) along the 79 diagonals of this wave's [16 q][64 keys] tile: lane = diagonal for the
           // first 64, lanes 0..14 the rest; every read unconditional (clamped column, the value selected away) so that the sixteen of them
@@ -1234,7 +1250,13 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
   __shared__ __attribute__((aligned(16))) char tQ[LQ * 128];
   __shared__ __attribute__((aligned(16))) char tDO[LQ * 128];
   __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * C::TS];
-  __shared__ float sbias[1024];
+  // Element arithmetic of this pass (round 6; 36 vector instructions per score before, counted with SQ_INSTS_VALU): log2(e) is folded into
+  // the bias table and the log-sum-exp rows, so a probability is one subtract, one fma and one v_exp_f32; the four bias entries of a lane's
+  // (key, four consecutive queries) are four reads at constant offsets from one address -- the table carries PADB entries of slack in front
+  // instead of a clamp per score (query slots past Lq are masked anyway); a masked score is a select on the exponent (-inf), never a
+  // branch around the exp: hipcc sank the exp into `ok ? ... : 0` and emitted a compare + exec-mask branch per score.
+  constexpr int PADB = 64;
+  __shared__ float sbias[PADB + 1024];
   __shared__ __attribute__((aligned(16))) float slse[LQ];
   __shared__ __attribute__((aligned(16))) float sD[LQ];
 
@@ -1257,10 +1279,12 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
       const int p = tid + i * NT, row = p >> 3, pc = p & 7;
       rd[i] = row < a.Lq ? ld16(dO + (size_t)row * a.lddo + pc * 8) : zero16();
     }
-    for (int i = tid; i < 1023; i += NT)                // (every position the blocks read, key slots past Lk included)
-      sbias[i] = (a.rel_table && i < nrel) ? a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    for (int i = tid; i < PADB + 1023; i += NT) {       // (every position the blocks read, key slots past Lk and query slots past Lq included)
+      const int j = i - PADB;
+      sbias[i] = (a.rel_table && j >= 0 && j < nrel) ? P5_LOG2E * a.rel_table[a.bucket_lut[j - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+    }
     for (int i = tid; i < LQ; i += NT) {
-      slse[i] = i < a.Lq ? a.lse[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
+      slse[i] = i < a.Lq ? P5_LOG2E * a.lse[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
       sD[i] = i < a.Lq ? a.Dvec[((size_t)b * a.H + h) * a.Lq + i] : 0.f;
     }
 #pragma unroll
@@ -1326,40 +1350,49 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dkv_head_kernel(P5AttnArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) pcn[t] = ((qc + 1) * 4 + t) * 16 < a.Lq ? *(const unsigned short*)(kpk + (size_t)((qc + 1) * 4 + t) * 1024) : 0u;
       }
+      // a chunk whose 64 query slots all exist, without a causal mask (every chunk of the encoder at L % 64 == 0): the only per-score
+      // condition left is the lane's own key
+      const bool plain = !causal && (qc + 1) * 64 <= a.Lq;
+      auto tiles = [&](auto plain_c, auto mode_c) {
+        constexpr bool PLAIN = decltype(plain_c)::value;
+        constexpr int MODE = decltype(mode_c)::value;        // dropout of the probabilities: 0 none, 1 the forward's stored keep masks, 2 re-hashed
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
-        mma16<T>(sacc, ld16(cQ + t * 2048 + koff0), kf0);
-        mma16<T>(sacc, ld16(cQ + t * 2048 + koff1), kf1);
-        mma16<T>(dpacc, ld16(cD + t * 2048 + koff0), vf0);
-        mma16<T>(dpacc, ld16(cD + t * 2048 + koff1), vf1);
-        const int qb = qc * 64 + t * 16 + g * 4;
-        const f32x4 ls = *(const f32x4*)(slse + qb), dd = *(const f32x4*)(sD + qb);
-        float bias[4];
+        for (int t = 0; t < 4; ++t) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+          mma16<T>(sacc, ld16(cQ + t * 2048 + koff0), kf0);
+          mma16<T>(sacc, ld16(cQ + t * 2048 + koff1), kf1);
+          mma16<T>(dpacc, ld16(cD + t * 2048 + koff0), vf0);
+          mma16<T>(dpacc, ld16(cD + t * 2048 + koff1), vf1);
+          const int qb = qc * 64 + t * 16 + g * 4;
+          const f32x4 ls = *(const f32x4*)(slse + qb), dd = *(const f32x4*)(sD + qb);
+          const float* pbq = sbias + (PADB + kj - qb + a.Lq - 4);      // entries of queries qb + 3 .. qb (relative position key - query, descending)
+          const float bias[4] = {pbq[3], pbq[2], pbq[1], pbq[0]};
+          const uint32_t tbase = headbase + (uint32_t)qb * (uint32_t)a.Lk;
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if constexpr (MODE == 1) {
+            const unsigned piece = pcc[t] >> (g * 4);       // 16 queries of block qc * 4 + t: this lane group's four
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = qb + r;
-          bias[r] = sbias[kj - (qi < a.Lq ? qi : a.Lq - 1) + a.Lq - 1];
+            for (int r = 0; r < 4; ++r) mk[r] = ((piece >> r) & 1u) ? a.drop.scale : 0.f;
+          } else if constexpr (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, tbase + (uint32_t)r * (uint32_t)a.Lk, a.drop.thr) ? a.drop.scale : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qb + r;
+            const bool ok = PLAIN ? kok : (kok & (qi < a.Lq) & !(causal & (kj > qi)));
+            float ex = fmaf(sacc[r], P5_LOG2E, bias[r] - ls[r]);
+            ex = ok ? ex : P5_NEG_INF;
+            const float p = p5_exp2(ex);
+            pv[t][r] = p * mk[r];
+            dsv[t][r] = p * (dpacc[r] * mk[r] - dd[r]);
+          }
         }
-        const uint32_t tbase = headbase + (uint32_t)qb * (uint32_t)a.Lk;
-        float mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (use_bits) {
-          const unsigned piece = pcc[t];                // 16 queries of block qc * 4 + t
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mk[r] = ((piece >> (g * 4 + r)) & 1u) ? a.drop.scale : 0.f;
-        } else if (do_drop) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mk[r] = p5_keep(seed, a.drop.site_key, tbase + (uint32_t)r * (uint32_t)a.Lk, a.drop.thr) ? a.drop.scale : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = qb + r;
-          const bool ok = kok & (qi < a.Lq) & !(causal & (kj > qi));
-          const float p = p5_exp<T>((sacc[r] + bias[r]) - ls[r]);
-          pv[t][r] = ok ? p * mk[r] : 0.f;
-          dsv[t][r] = ok ? p * (dpacc[r] * mk[r] - dd[r]) : 0.f;
-        }
-      }
+      };
+      // (every condition that is uniform over the launch decided here, once per chunk -- not per tile)
+      if (use_bits) { if (plain) tiles(AttnBool<true>(), P5EpiTagA<1>()); else tiles(AttnBool<false>(), P5EpiTagA<1>()); }
+      else if (do_drop) { if (plain) tiles(AttnBool<true>(), P5EpiTagA<2>()); else tiles(AttnBool<false>(), P5EpiTagA<2>()); }
+      else { if (plain) tiles(AttnBool<true>(), P5EpiTagA<0>()); else tiles(AttnBool<false>(), P5EpiTagA<0>()); }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const float p8[8] = {pv[2 * u][0], pv[2 * u][1], pv[2 * u][2], pv[2 * u][3], pv[2 * u + 1][0], pv[2 * u + 1][1], pv[2 * u + 1][2], pv[2 * u + 1][3]};

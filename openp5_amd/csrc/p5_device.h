@@ -284,6 +284,17 @@ template <class T> __device__ static __forceinline__ float p5_exp(float x);
 template <> __device__ __forceinline__ float p5_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float p5_exp<bf16>(float x) { return __expf(x); }
 
+// 2^x on the transcendental unit (v_exp_f32): the long-sequence attention backward folds log2(e) into the terms it adds to the score, so
+// a probability costs one fma + one v_exp_f32 instead of add, sub, mul, v_exp_f32
+#define P5_LOG2E 1.4426950408889634f
+__device__ static __forceinline__ float p5_exp2(float x) {
+#ifdef P5_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
 // ---- wave reductions (all 64 lanes) -----------------------------------------------------------------
 __device__ static __forceinline__ float wave_sum(float v) {
 #pragma unroll
