@@ -175,10 +175,15 @@ __device__ static __forceinline__ u32x4 tile_frag_ks(const char* lds, int e0, in
 
 
 // stage per-head relative bias (index = k - q + Lq - 1) and the additive key mask into LDS
+// (scale != 1, nfill > 0: the backward kernels that fold log2(e) into the exponent's terms -- every one of the first `nfill` entries is
+//  written, zeros where there is no table or no such relative position, so that a score needs no "is there a bias" test)
 __device__ static __forceinline__ void stage_bias_mask(const P5AttnArgs& a, int b, int h, float* sbias, float* skneg,
-                                                       int nkeys_padded, int tid) {
+                                                       int nkeys_padded, int tid, float scale = 1.f, int nfill = 0) {
   const int nrel = a.Lq + a.Lk - 1;
-  if (a.rel_table) {
+  if (nfill > 0) {
+    for (int i = tid; i < nfill; i += 256)
+      sbias[i] = (a.rel_table && i < nrel) ? scale * a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h] : 0.f;
+  } else if (a.rel_table) {
     for (int i = tid; i < nrel; i += 256) sbias[i] = a.rel_table[a.bucket_lut[i - (a.Lq - 1) + a.lut_half] * a.H + h];
   }
   for (int j = tid; j < nkeys_padded; j += 256)
@@ -1009,7 +1014,12 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
   static_assert(NKT == 16 || NKT == 32, "whole-head attention backward: 256 or 512 key slots");
   static_assert(2 * LK * 128 >= 8 * 1024 * 4, "the per-wave rows of diagonal sums reuse the K and V images");
   __shared__ __attribute__((aligned(16))) char tKV[2 * LK * 128];
-  __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * C::TS];
+  // the wave's [16 queries][64 keys] tile of dS, for the diagonal sums of the relative-bias gradient: rows of DSTR bytes with 16 zero
+  // columns in front of the 64 keys and 15 behind them, so that a diagonal's 16 elements are 16 reads at constant offsets from one lane
+  // address with no clamp and no select (round 6: the clamped / selected form cost 14 of this pass's 23 vector instructions per score).
+  // The same bytes are the staging tile of the dQ store, which overwrites the zero columns: they are cleared again per query block.
+  constexpr int DSTR = 192, DPAD = 16;
+  __shared__ __attribute__((aligned(16))) char pbuf[8 * 16 * DSTR];
   __shared__ __attribute__((aligned(16))) float sbias[1024];
   __shared__ __attribute__((aligned(16))) float skneg[LK];
   char* tK = tKV;
@@ -1071,7 +1081,17 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
   const int ksw = (li >> 1) & 7;
   const int koff0 = li * 128 + (((0 + g) ^ ksw) << 4), koff1 = li * 128 + (((4 + g) ^ ksw) << 4);
   const int trow = g * 4 + (li >> 2), tsw = (g * 2 + (li >> 3)) & 7;
-  char* pw = pbuf + wave * 16 * C::TS;
+  char* pw = pbuf + wave * 16 * DSTR;
+  static_assert(16 * DSTR >= 16 * C::TS && (DPAD + 64 + 15) * 2 <= DSTR, "diagonal tile: store staging fits, zero columns fit");
+  auto clear_diag_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 16 * DSTR / (64 * 16); ++i) st16(pw + (i * 64 + lane) * 16, zero16());
+  };
+  if (a.d_rel_table != nullptr) clear_diag_tile();
+  // this lane's diagonal dd = lane (and 64 + lane for lanes 0 .. 14) starts at column DPAD + dd - 15 of row 0 and moves one row down, one
+  // column right per element: byte offset qr * (DSTR + 2)
+  const char* dg1 = pw + (DPAD + lane - 15) * 2;
+  const char* dg2 = pw + (DPAD + (lane < 15 ? lane : 14) + 49) * 2;
   // diagonal sums: relative position (key - query + Lq - 1) + 16 = 64 (ch - 2 i + cw) + rot + dd for the dd-th diagonal (0 .. 78) of
   // chunk ch of this wave's i-th block (q0 = 16 wave + 128 i)
   const int cwf = a.Lq - 16 * wave;                  // > 0 for a wave that has a block
@@ -1161,7 +1181,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
               const float p = p5_exp2(ex);
               dsv[t][r] = p * (dpacc[r] * mk[r] - D_q);
             }
-            if (do_rel) st4<T>(pw + li * C::TS + (t * 16 + g * 4) * C::SZ, dsv[t]);
+            if (do_rel) st4<T>(pw + li * DSTR + (DPAD + t * 16 + g * 4) * C::SZ, dsv[t]);
           }
         };
         if (use_bits) { if (plain) tiles(AttnBool<true>(), P5EpiTagA<1>()); else tiles(AttnBool<false>(), P5EpiTagA<1>()); }
@@ -1175,13 +1195,10 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
           float x1 = 0.f, x2 = 0.f;
 #pragma unroll
           for (int qr = 0; qr < 16; ++qr) {
-            const int k1 = lane - 15 + qr, k2 = lane + 49 + qr;
-            const int c1 = k1 < 0 ? 0 : k1, c2 = k2 > 63 ? 63 : k2;
-            const float v1 = to_f<T>(*(const T*)(pw + qr * C::TS + c1 * C::SZ));
-            const float v2 = to_f<T>(*(const T*)(pw + qr * C::TS + c2 * C::SZ));
-            x1 += k1 >= 0 ? v1 : 0.f;
-            x2 += k2 <= 63 ? v2 : 0.f;
+            x1 += to_f<T>(*(const T*)(dg1 + qr * (DSTR + 2)));
+            x2 += to_f<T>(*(const T*)(dg2 + qr * (DSTR + 2)));
           }
+          x2 = lane < 15 ? x2 : 0.f;
           P5_WAVE_SYNC();
           const float y1 = __shfl(x1, src), y2 = __shfl(x2, src);
           R[ch] += up ? y1 : 0.f;
@@ -1206,6 +1223,10 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_dq_head_kernel(P5AttnArgs a) 
     }
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
     wave_store_16x64<T>((T*)a.dQ + (size_t)b * a.Lq * a.lddq + h * 64, a.lddq, q0, a.Lq, dq, one, pw, lane);
+    if (do_rel && q0 + 128 < a.Lq) {      // (the store staged dQ over the tile's zero columns)
+      P5_WAVE_SYNC();
+      clear_diag_tile();
+    }
     // the next block's diagonals sit 128 positions lower: J' = J + 2, the accumulators move up by two (the top two wrap to the bottom)
     {
       const float t16 = R[16], t17 = R[17];
@@ -1657,8 +1678,10 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
   const int qic = qok ? qi : a.Lq - 1;
 #pragma unroll
   for (int c = 0; c < 2; ++c) of[c] = qok ? ld16(O + (size_t)qi * a.ldo + c * 32 + g * 8) : zero16();
-  const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
-  stage_bias_mask(a, b, h, sbias, skneg, 128, tid);
+  const float lse_q = qok ? P5_LOG2E * a.lse[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
+  // (round 6, as the long-sequence passes: log2(e) folded into the bias table and the row's log-sum-exp, the key mask added to the
+  //  exponent, a masked score a select on the exponent -- hipcc had turned `ok ? p ... : 0` into a compare + exec-mask branch per score)
+  stage_bias_mask(a, b, h, sbias, skneg, 128, tid, P5_LOG2E, 256);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = tid + i * 512, row = p >> 3, pc = p & 7;
@@ -1690,6 +1713,7 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
   D_q += __shfl_xor(D_q, 32);
   char* myP = mP + qi * TP;
   char* myS = mS + qi * TP;
+  const bool plain = !causal && q0 + 16 <= a.Lq;      // every query of this wave's block exists, no causal mask
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
@@ -1699,12 +1723,8 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
       mma16<T>(dpacc, tile_frag_kc<T>(tV, t * 16, c, lane), dof[c]);
     }
     const int kb = t * 16 + g * 4;
-    const f32x4 kn = *(const f32x4*)(skneg + kb);
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.rel_table) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias[r] = sbias[(kb + r - qic + a.Lq - 1) & 255];
-    }
+    const f32x4 kn = *(const f32x4*)(skneg + kb);          // (0, or -inf for a masked key / a key slot past Lk)
+    const float* pb = sbias + (kb - qic + a.Lq - 1);        // (< 256: Lq, Lk <= 128)
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (do_drop) {
 #pragma unroll
@@ -1714,10 +1734,11 @@ __global__ __launch_bounds__(512) void p5_attn_bwd_fused_kernel(P5AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int kj = kb + r;
-      const bool ok = (kj < a.Lk) & qok & !(causal & (kj > qi)) & (kn[r] == 0.f);
-      const float p = p5_exp<T>((sacc[r] + bias[r]) - lse_q);
-      pv[r] = ok ? p * mk[r] : 0.f;
-      dsv[r] = ok ? p * (dpacc[r] * mk[r] - D_q) : 0.f;
+      float ex = fmaf(sacc[r], P5_LOG2E, pb[r] + (kn[r] - lse_q));
+      if (!plain) ex = (qok & !(causal & (kj > qi))) ? ex : P5_NEG_INF;        // (wave-uniform test: the common case has no select at all)
+      const float p = p5_exp2(ex);
+      pv[r] = p * mk[r];
+      dsv[r] = p * (dpacc[r] * mk[r] - D_q);
     }
     st4<T>(myP + kb * 2, pv);
     st4<T>(myS + kb * 2, dsv);
