@@ -67,6 +67,7 @@ struct P5GemmArgs {
   float alpha;
   P5Drop drop;
   int g4_tiles_n, g4_nk;   // p5_gemm4.h launcher-internal: tiles along N, K-steps (of 64) per work unit
+  int g4_cb;               // p5_gemm5.h launcher-internal: > 0 = the 32 workgroups of an XCD work on a (32 / g4_cb) x g4_cb block of tiles at a time
   // T5LayerNorm folded into the TRAINING GEMMs (bf16 engine): the row statistic travels as `nt` partial sums of squares per row, one
   // per 64-column group of the residual stream, each written by exactly one wave with a plain store (no atomics, no clearing, same
   // bits every run) and summed in a fixed order by the consumer.  0 = the decode step's scalar-per-row form (atomic accumulate).

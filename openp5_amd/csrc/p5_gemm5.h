@@ -67,9 +67,21 @@ __global__ __launch_bounds__(512) void p5_gemm5_kernel(P5GemmGroup grp) {
     const P5GemmArgs& g = grp.p[pi];
     const int local = id - grp.unit_begin[pi];
     const int sp = local % g.splitk, tile = local / g.splitk;
+    int tm = tile / g.g4_tiles_n, tn = tile % g.g4_tiles_n;
+    if (g.g4_cb > 0) {
+      // Rectangular blocks per XCD (round 6; one problem, no split-K, 32 workgroups per XCD: the launcher checks).  With the tiles of an
+      // XCD's range dealt n-fastest, the 32 workgroups of an XCD sit on 32 / tiles_n tile rows x ALL column tiles: at N = 4096 that is one
+      // A panel and the whole of B (8 MB against 4 MB of L2) per round.  As a (32 / cb) x cb block they share 32 / cb A panels and cb B
+      // panels: half the bytes through the fabric, and what the K = 4096, N = 1024 shapes -- whose 8 column tiles make that block by
+      // themselves -- run at (1.11 against 0.78 PFLOP/s at T5-large dims, profiles/r06_call11_c3_c5_kernel_tables.txt).
+      const int il = it * gx + jx, blk = il >> 5, w = il & 31;
+      const int nbc = g.g4_tiles_n / g.g4_cb, rb = 32 / g.g4_cb;
+      tm = xcd * (upx / g.g4_tiles_n) + (blk / nbc) * rb + w / g.g4_cb;
+      tn = (blk % nbc) * g.g4_cb + w % g.g4_cb;
+    }
     u.pi = pi;
-    u.m0 = (tile / g.g4_tiles_n) * BM;
-    u.n0 = (tile % g.g4_tiles_n) * BN;
+    u.m0 = tm * BM;
+    u.n0 = tn * BN;
     u.nk = g.g4_nk;
     u.kb = sp * g.g4_nk * 64;
     return u;

@@ -27,6 +27,7 @@ int g_opt_split_pipe = getenv("P5_SPLIT_PIPE") ? atoi(getenv("P5_SPLIT_PIPE")) :
 int g_opt_split_big_tiles = getenv("P5_SPLIT_BIG_TILES") ? atoi(getenv("P5_SPLIT_BIG_TILES")) : 0;    // split-f16 fp32 GEMMs: 128x128 tiles from this many of them (0 = the fp32 rule: from 512; measured on the verification pass, 64x64 tiles win below that: 5.05 vs 5.30 ms per batch)
 int g_opt_gemm_ws128 = getenv("P5_GEMM_WS128") ? atoi(getenv("P5_GEMM_WS128")) : 1;    // N = d_model outputs (128..256 tiles of 128x128) on the wave-specialised 128x128 instance, from K = gemm_ws128_min_k
 int g_opt_gemm_ws128_min_k = getenv("P5_GEMM_WS128_MIN_K") ? atoi(getenv("P5_GEMM_WS128_MIN_K")) : 512;
+int g_opt_gemm_rect = getenv("P5_GEMM_RECT") ? atoi(getenv("P5_GEMM_RECT")) : 1;     // wave-specialised kernel: (32 / cb) x cb tile blocks per XCD round instead of n-fastest runs
 int g_opt_gemm_ws = getenv("P5_GEMM_WS") ? atoi(getenv("P5_GEMM_WS")) : 3;          // 256x128 tiles on the wave-specialised kernel (p5_gemm5.h): bit 0 K-contiguous (forward / dgrad), bit 1 K-strided (wgrad groups)
 
 template <class T, int BM, int BN>
@@ -150,6 +151,19 @@ static int launch_gemm5(P5GemmGroup& grp, hipStream_t s) {     // same unit book
   grp.total_units = units;
   int nwg = ((units + 7) / 8) * 8;
   if (nwg > g_opt_g4_wgs) nwg = g_opt_g4_wgs;
+  for (int i = 0; i < grp.nprob; ++i) grp.p[i].g4_cb = 0;
+  // (option 1: only where the B operand does not fit an XCD's 4 MiB L2 beside the A panels -- measured in one call: T5-large 115.2 -> 112.8 ms
+  //  per step, T5-base 12.43 -> 12.42, T5-small 4.145 -> 4.174 with it everywhere (profiles/r06_call15_rect_blocks.txt); 2: wherever whole blocks fit)
+  const bool rect_pays = g_opt_gemm_rect >= 2 || (long long)grp.p[0].N * grp.p[0].K * 2 >= (6ll << 20);
+  if (!KS && g_opt_gemm_rect && rect_pays && grp.nprob == 1 && grp.p[0].splitk == 1 && nwg == 256 && units % 8 == 0) {
+    // rectangular per-XCD tile blocks (p5_gemm5.h decode): whole blocks must tile the XCD's range of tile rows
+    const int tn = grp.p[0].g4_tiles_n, upx = units / 8;
+    if (upx % tn == 0) {
+      const int rows = upx / tn;
+      for (int cb = 8; cb >= 4 && grp.p[0].g4_cb == 0; cb >>= 1)
+        if (tn % cb == 0 && tn > cb && rows % (32 / cb) == 0) grp.p[0].g4_cb = cb;
+    }
+  }
   {
     double fl = 0.0;
     for (int i = 0; i < grp.nprob; ++i) fl += 2.0 * grp.p[i].M * grp.p[i].N * grp.p[i].K;

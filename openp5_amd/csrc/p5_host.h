@@ -52,6 +52,7 @@ extern int g_opt_g4_nst;
 extern int g_opt_g4_wgs;
 extern int g_opt_gemm_ws;
 extern int g_opt_gemm_ws128;
+extern int g_opt_gemm_rect;
 extern int g_opt_gemm_ws128_min_k;
 extern int g_opt_attn_fwd_wg;
 extern int g_opt_attn_fwd_head;

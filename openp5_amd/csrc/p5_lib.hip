@@ -2217,6 +2217,7 @@ int p5_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm_wide")) g_opt_gemm_wide = value;
   else if (!strcmp(name, "gemm_ws")) g_opt_gemm_ws = value;
   else if (!strcmp(name, "gemm_ws128")) g_opt_gemm_ws128 = value;
+  else if (!strcmp(name, "gemm_rect")) g_opt_gemm_rect = value;
   else if (!strcmp(name, "gemm_ws128_min_k")) g_opt_gemm_ws128_min_k = value;
   else if (!strcmp(name, "gate_fuse")) g_opt_gate_fuse = value;
   else if (!strcmp(name, "norm_bwd_blocks")) g_opt_norm_bwd_blocks = value;

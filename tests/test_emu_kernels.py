@@ -122,6 +122,17 @@ def test_attention_backward_row_sums(emu, L, mode):
     cases.attn_rowdot_case(emu, 2, 2, L, mode=mode)
 
 
+def test_gemm_wave_specialised_rectangular_xcd_blocks(emu):
+    """p5_gemm5.h unit order with (32 / cb) x cb tile blocks per XCD round (one problem, 256 workgroups, whole blocks): every tile of the
+    output computed exactly once -- 128-row instance, 32 x 16 tiles -> 4 x 8 blocks; against the n-fastest order (option gemm_rect 0)."""
+    try:
+        for rect in (2, 0):          # (2 = wherever whole blocks fit; the default 1 asks for a B operand beyond the L2 as well)
+            emu.check(emu.lib.p5_set_option(b"gemm_rect", rect), "opt")
+            cases.gemm_group_case(emu, 4, 0, [(4096, 2048, 64, 2, 0, 1)], wgs=256, drop_p=0.1, seed=rect)
+    finally:
+        emu.lib.p5_set_option(b"gemm_rect", 1)
+
+
 def test_gemm_wave_specialised_wgrad(emu):
     """p5_gemm5.h on two K-strided operands (grouped weight gradients): C +=, split-K atomics, plain store; ragged outputs."""
     probs = [(264, 200, 128, 6, 1, 1), (256, 128, 384, 4, 1, 2), (40, 264, 640, 6, 1, 1), (520, 72, 192, 0, 1, 1), (8, 8, 64, 4, 1, 1)]

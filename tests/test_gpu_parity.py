@@ -592,6 +592,20 @@ def test_gemm_wave_specialised_128_row_tiles(hip, wgs):
         cases.gemm_group_case(hip, 4, 0, [(8192, 512, 2048, 2, 0, 1), (8192, 512, 1536, 0, 0, 1)], wgs=wgs, drop_p=0.1, seed=rep)
 
 
+def test_gemm_wave_specialised_rectangular_xcd_blocks(hip):
+    """p5_gemm5.h with (32 / cb) x cb tile blocks per XCD round (the order the T5-large GEMMs whose B operand exceeds the L2 take by default;
+    option 2 forces it wherever whole blocks fit): 256x128 tiles at 8192 x 2048 (4 x 8 blocks) and 8192 x 3072 (24 column tiles), 128-row
+    tiles at 4096 x 2048, each against the n-fastest order's reference."""
+    try:
+        for rect in (2, 0):
+            hip.check(hip.lib.p5_set_option(b"gemm_rect", rect), "opt")
+            cases.gemm_group_case(hip, 3, 0, [(8192, 2048, 512, 1, 0, 1)], wgs=256, drop_p=0.1, seed=rect)
+            cases.gemm_group_case(hip, 3, 0, [(8192, 3072, 768, 2, 0, 1)], wgs=256, drop_p=0.1, seed=rect + 1)
+            cases.gemm_group_case(hip, 4, 0, [(4096, 2048, 64, 2, 0, 1)], wgs=256, drop_p=0.1, seed=rect)
+    finally:
+        hip.lib.p5_set_option(b"gemm_rect", 1)
+
+
 def test_backward_writes_every_gradient_after_zero_grad(hip):
     cases.grad_arena_coverage_case(hip, O.T5Cfg.named("t5-small", dropout=0.0), 16, 64, 8)
     cases.grad_arena_coverage_case(hip, O.T5Cfg.named("tiny"), 3, 10, 5)
